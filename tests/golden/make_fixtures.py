@@ -1,0 +1,199 @@
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+Imports /root/reference/python/{NNTools,MixtureOfExpertsAdvanced}.py, instantiates the reference
+model for each configuration, pushes this package's seeded synthetic state dict into it with
+``load_state_dict`` and records the reference's outputs on seeded synthetic sites.  Only data is
+written: inputs (uint8 pileups + counts), the weight seed, and the expected outputs.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py
+
+The reference cannot travel to the GPU box; the committed ``*.npz`` files are what tests replay.
+"""
+import hashlib
+import importlib
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/python")
+warnings.filterwarnings("ignore")
+
+import torch  # noqa: E402
+
+torch.set_num_threads(1)
+import NNTools  # noqa: E402,F401  (reference; registers its layer types on torch.nn)
+import MixtureOfExpertsAdvanced as REF  # noqa: E402  (reference)
+
+from hello_amd import netspec as ns  # noqa: E402
+from hello_amd import synth, weights  # noqa: E402
+
+
+def state_digest(state):
+    h = hashlib.sha256()
+    for k in sorted(state):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(state[k]).tobytes())
+    return h.hexdigest()[:16]
+
+
+def reference_model(config_name, norm):
+    modname = ns.REFERENCE_CONFIG_MODULE[config_name]
+    module = importlib.import_module(modname)
+    module = importlib.reload(module)
+    if norm == "bn":
+        # same architecture with BatchNorm1d instead of weight norm: regenerate the layer lists
+        import architectures.read_convolver as rc
+        import architectures.compressor_conv_small as cc
+        import architectures.xattn_subtract as xs
+        for m in (rc, cc, xs):
+            m.weight_norm = False
+            m.gen_config()
+        cfg = {"read_conv0": rc.config, "compressor0": cc.config, "xattn0": xs.config}
+    else:
+        cfg = module.configDict
+    moe = REF.create_moe_attention_model(cfg)
+    wrapper = REF.createMoEFullMergedAdvancedModelWrapper(moe)
+    wrapper.eval()
+    return wrapper
+
+
+def load_state(wrapper, state):
+    ref_keys = set(wrapper.state_dict().keys())
+    assert ref_keys == set(state.keys()), (sorted(ref_keys ^ set(state.keys()))[:8])
+    wrapper.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+
+
+def run_batched(wrapper, batch):
+    t0 = torch.from_numpy(np.ascontiguousarray(np.transpose(batch.reads0, (0, 2, 1))))
+    t1 = None
+    rpa1 = None
+    if batch.reads1 is not None:
+        t1 = torch.from_numpy(np.ascontiguousarray(np.transpose(batch.reads1, (0, 2, 1))))
+        rpa1 = batch.reads_per_allele1.tolist()
+    seg = torch.from_numpy(batch.ref_onehot).float()
+    captured = {}
+    hook = wrapper.moeMerged.read_convolver0.register_forward_hook(
+        lambda m, i, o: captured.__setitem__("rc0", o.detach().numpy().copy()))
+    with torch.no_grad():
+        out = wrapper.moeMerged((t0, t1), batch.alleles_per_site.tolist(),
+                                (batch.reads_per_allele0.tolist(), rpa1), seg)
+    hook.remove()
+    res = {}
+    if isinstance(out, tuple):
+        experts, meta = out
+        res["logits"] = np.stack([e.numpy()[:, 0] for e in experts], axis=0)
+        res["meta"] = meta.numpy()
+    else:
+        res["logits"] = out.numpy()[:, 0][None, :]
+    rc0 = torch.from_numpy(captured["rc0"])
+    res["frames0"] = REF.reduceSlots(rc0, batch.reads_per_allele0.tolist()).numpy()
+    return res
+
+
+def run_wrapper(wrapper, batch, names):
+    """Per-site plug-in surface: exactly what caller_calling.scoreSite does (its lines 631-652)."""
+    wrapper.providePredictions = True
+    out = {}
+    aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
+    r0off = np.concatenate([[0], np.cumsum(batch.reads_per_allele0)])
+    r1off = None if batch.reads1 is None else np.concatenate([[0], np.cumsum(batch.reads_per_allele1)])
+    for s in range(batch.n_sites):
+        fd = {}
+        for j, a in enumerate(range(aoff[s], aoff[s + 1])):
+            t0 = torch.Tensor(batch.reads0[r0off[a]:r0off[a + 1]])
+            t1 = None if r1off is None else torch.Tensor(batch.reads1[r1off[a]:r1off[a + 1]])
+            fd[names[s][j]] = (t0, t1)
+        seg = torch.from_numpy(batch.ref_onehot[s:s + 1]).float()
+        with torch.no_grad():
+            mix, e0, e1, e2, meta = wrapper(fd, seg)
+        keys = list(mix.keys())
+        out[f"site{s}_pairs"] = np.array(["|".join(k) for k in keys])
+        out[f"site{s}_mix"] = np.array([float(mix[k]) for k in keys], dtype=np.float32)
+        out[f"site{s}_e0"] = np.array([float(e0[k]) for k in keys], dtype=np.float32)
+        out[f"site{s}_e1"] = np.array([float(e1[k]) for k in keys], dtype=np.float32)
+        out[f"site{s}_e2"] = np.array([float(e2[k]) for k in keys], dtype=np.float32)
+        out[f"site{s}_meta"] = meta.numpy().astype(np.float32)
+    return out
+
+
+def force_shapes(batch_kwargs, n_sites, seed, need):
+    """Search seeds until the batch holds the edge cases named in ``need``: a 1-allele site ("one"),
+    a >=3-allele site ("multi"), an unsupported allele carrying the all-zero dummy read ("dummy")."""
+    for s in range(seed, seed + 500):
+        b = synth.make_sites(n_sites, seed=s, **batch_kwargs)
+        have = {
+            "one": (b.alleles_per_site == 1).any(),
+            "multi": (b.alleles_per_site >= 3).any(),
+            "dummy": (b.reads0.reshape(b.reads0.shape[0], -1).max(axis=1) == 0).any(),
+        }
+        if all(have[n] for n in need):
+            return b, s
+    raise RuntimeError("no seed found")
+
+
+CASES = [
+    # name, config, norm, n_sites, weight_seed, make_sites kwargs, with_wrapper, keep_frames
+    ("single_tech_batched", "single_tech", "wn", 6, 11, dict(coverage=30), True, True, ("one", "multi", "dummy")),
+    ("single_tech_bn", "single_tech", "bn", 3, 12, dict(coverage=20), False, False, ("multi",)),
+    ("single_tech_hp", "single_tech_hp", "wn", 4, 13, dict(coverage=(20, 80), channels=7, tech="pacbio"),
+     True, False, ("one", "multi")),
+    ("single_tech_deep", "single_tech", "wn", 3, 14, dict(coverage=(90, 128), tech="pacbio"), False, False, ("multi",)),
+    ("hybrid_no_ensemble", "hybrid_no_ensemble", "wn", 4, 15, dict(coverage=30, hybrid_coverage=15),
+     True, False, ("one", "multi", "dummy")),
+    ("hybrid_full", "hybrid_full", "wn", 3, 16, dict(coverage=25, hybrid_coverage=12), True, False, ("multi",)),
+    ("hybrid_ensemble2", "hybrid_ensemble2", "wn", 3, 17, dict(coverage=25, hybrid_coverage=12),
+     True, False, ("one", "multi")),
+]
+
+
+def sanity_known_answer():
+    """default-initialised reference, torch.manual_seed(1234)."""
+    torch.manual_seed(1234)
+    w = reference_model("single_tech", "wn")
+    g = torch.Generator().manual_seed(99)
+    fd = {}
+    for name, r in (("A", 18), ("AT", 14), ("ATT", 3)):
+        fd[name] = (torch.randint(0, 255, (r, 150, 6), generator=g).float(), None)
+    with torch.no_grad():
+        out = w(fd, torch.zeros(1, 150, 5))
+    got = float(out[("A", "A")])
+    assert abs(got - 0.31904656) < 2e-6, got
+    print("reference import sanity OK:", got)
+
+
+def main():
+    sanity_known_answer()
+    for name, cfg, norm, n_sites, wseed, kw, with_wrapper, keep_frames, need in CASES:
+        spec = ns.build(cfg, norm=norm) if norm != "wn" else ns.build(cfg)
+        state = weights.synth_state(spec, seed=wseed)
+        wrapper = reference_model(cfg, norm)
+        load_state(wrapper, state)
+        batch, iseed = force_shapes(kw, n_sites, 100 + wseed, need)
+        res = run_batched(wrapper, batch)
+        if not keep_frames:
+            res.pop("frames0")
+        if with_wrapper:
+            res.update(run_wrapper(wrapper, batch, synth.allele_names(batch)))
+        payload = dict(
+            config=np.array(cfg), norm=np.array(norm), weight_seed=np.array(wseed),
+            state_digest=np.array(state_digest(state)), input_seed=np.array(iseed),
+            reads0=batch.reads0, reads_per_allele0=batch.reads_per_allele0,
+            alleles_per_site=batch.alleles_per_site, ref_onehot=batch.ref_onehot,
+        )
+        if batch.reads1 is not None:
+            payload.update(reads1=batch.reads1, reads_per_allele1=batch.reads_per_allele1)
+        payload.update({"exp_" + k: v for k, v in res.items()})
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **payload)
+        print(f"{name}: S={batch.n_sites} A={batch.n_alleles} R0={batch.reads0.shape[0]} "
+              f"logits[{res['logits'].min():.3f},{res['logits'].max():.3f}] -> "
+              f"{os.path.getsize(path) / 1024:.0f} KB")
+
+
+if __name__ == "__main__":
+    main()
