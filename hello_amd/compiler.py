@@ -1,0 +1,409 @@
+"""Lower a MoEAttention model (netspec.ModelSpec + state dict) to the engine's flat program.
+
+The reference evaluates the model by walking ``torch.nn.Sequential`` containers inside
+``MoEAttention.forward`` (reference python/MixtureOfExpertsAdvanced.py:117-252).  The engine instead
+receives ONE program: a list of ops over row-domain-typed activation buffers plus a single blob of
+folded weights (include/hello_mi355x.h).  This module performs that lowering once at load time:
+
+  * weight-norm / batch-norm folding (weights.fold);
+  * residual blocks become convs whose epilogue adds the shortcut (ReLU happens before the add,
+    NNTools.py:582-583);
+  * ``reduceSlots`` + ``repeat_interleave`` + ``LinearCombination`` (MixtureOfExpertsAdvanced.py:
+    142-155, xattn_subtract.py:14-42) become SEGSUM + MIX with an owner index, so the per-site sum is
+    never re-expanded in memory;
+  * the site-level compressor call of :136 is dropped when nothing consumes it (it is dead for every
+    xattn_subtract configuration);
+  * a read convolver of the canonical shape is replaced by the fused read-convolver op;
+  * virtual activations are packed into as few physical scratch buffers as liveness allows.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import netspec as ns
+from . import weights as wts
+
+# mirror of include/hello_mi355x.h
+ROWS_READS0, ROWS_READS1, ROWS_ALLELES, ROWS_SITES = 0, 1, 2, 3
+SEG_R0A, SEG_R1A, SEG_AS = 0, 1, 2
+BUF_NONE, BUF_READS0, BUF_READS1, BUF_REF, BUF_FIRST_SCRATCH = -1, 0, 1, 2, 3
+OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED = range(1, 9)
+FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX = 1, 2, 4
+OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
+            8: "readconv_fused"}
+
+
+@dataclass
+class Value:
+    """A virtual activation tensor [rows(domain)][length][channels]."""
+    vid: int
+    domain: int
+    length: int
+    channels: int
+    u8: bool = False
+
+    @property
+    def floats_per_row(self):
+        return self.length * self.channels
+
+
+@dataclass
+class Op:
+    kind: int
+    domain: int
+    src0: int = BUF_NONE      # virtual ids until allocate() rewrites them
+    src1: int = BUF_NONE
+    dst: int = BUF_NONE
+    res: int = BUF_NONE
+    cin: int = 0
+    cout: int = 0
+    k: int = 0
+    stride: int = 1
+    pad: int = 0
+    lin: int = 0
+    lout: int = 0
+    flags: int = 0
+    seg: int = 0
+    c1: int = 0
+    a0: float = 0.0
+    a1: float = 0.0
+    w_off: int = 0
+    b_off: int = 0
+    name: str = ""
+    macs_per_row: int = 0
+
+
+@dataclass
+class Program:
+    spec_name: str
+    window: int
+    channels0: int
+    channels1: int
+    n_experts: int
+    has_meta: bool
+    uses_ref: bool
+    ops: List[Op]
+    buffers: List[Tuple[int, int]]          # (domain, floats_per_row) per physical buffer id
+    weights: np.ndarray                      # float32 blob
+    fused_read_convolver: bool = False
+
+    def describe(self) -> str:
+        lines = [f"program {self.spec_name}: {len(self.ops)} ops, {len(self.buffers)} buffers, "
+                 f"{self.weights.nbytes / 1e6:.2f} MB weights"]
+        for i, o in enumerate(self.ops):
+            lines.append(f"  {i:3d} {OP_NAMES[o.kind]:14s} dom={o.domain} {o.src0}->{o.dst} "
+                         f"cin={o.cin} cout={o.cout} k={o.k} s={o.stride} L {o.lin}->{o.lout} {o.name}")
+        return "\n".join(lines)
+
+
+class _WeightBlob:
+    def __init__(self):
+        self.parts: List[np.ndarray] = []
+        self.size = 0
+
+    def add(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr, dtype=np.float32).ravel()
+        pad = (-self.size) % 4
+        if pad:
+            self.parts.append(np.zeros(pad, np.float32))
+            self.size += pad
+        off = self.size
+        self.parts.append(arr)
+        self.size += arr.size
+        return off
+
+    def finish(self) -> np.ndarray:
+        return np.concatenate(self.parts) if self.parts else np.zeros(0, np.float32)
+
+
+def pack_conv(w: np.ndarray, b: np.ndarray, groups: int = 1):
+    """[cout, cin/groups, k] -> dense [cout_pad32][kpad32] with K index = tap*cin + c (channels-last
+    im2col order); grouped convs are expanded to block-diagonal dense weights."""
+    cout, cg, k = w.shape
+    cin = cg * groups
+    dense = np.zeros((cout, cin, k), np.float32)
+    og = cout // groups
+    for g in range(groups):
+        dense[g * og:(g + 1) * og, g * cg:(g + 1) * cg] = w[g * og:(g + 1) * og]
+    kreal = k * cin
+    kpad = -(-kreal // 32) * 32
+    cpad = -(-cout // 32) * 32
+    packed = np.zeros((cpad, kpad), np.float32)
+    packed[:cout, :kreal] = dense.transpose(0, 2, 1).reshape(cout, kreal)
+    bias = np.zeros(cpad, np.float32)
+    bias[:cout] = b
+    return packed, bias
+
+
+# canonical read-convolver shape the fused kernel implements (architectures/read_convolver.py)
+def _is_canonical_read_convolver(nodes, cin) -> bool:
+    try:
+        ref = ns.read_convolver("x", in_channels=cin)
+    except Exception:
+        return False
+    if len(nodes) != len(ref):
+        return False
+
+    def sig(n):
+        if isinstance(n, ns.Conv):
+            return ("c", n.cin, n.cout, n.k, n.stride, n.pad, n.groups, n.act)
+        if isinstance(n, ns.MaxPool):
+            return ("p", n.k, n.stride, n.pad)
+        if isinstance(n, ns.Residual):
+            return ("r", tuple(sig(m) for m in n.body), tuple(sig(m) for m in n.shortcut))
+        return ("?", type(n).__name__)
+
+    return all(sig(a) == sig(b) for a, b in zip(nodes, ref)) and cin in (6, 7)
+
+
+class _Lowering:
+    def __init__(self, spec: ns.ModelSpec, state, fused: bool):
+        self.spec = spec
+        self.folded = wts.fold(spec, state)
+        self.fused = fused
+        self.ops: List[Op] = []
+        self.values: Dict[int, Value] = {}
+        self.blob = _WeightBlob()
+        self.next_vid = 1000        # virtual ids live above any physical id
+        self.used_fused = False
+        self.uses_ref = False
+
+    # -- values ----------------------------------------------------------------------------
+    def new(self, domain, length, channels) -> Value:
+        v = Value(self.next_vid, domain, length, channels)
+        self.values[v.vid] = v
+        self.next_vid += 1
+        return v
+
+    def input(self, buf, domain, length, channels) -> Value:
+        v = Value(buf, domain, length, channels, u8=True)
+        self.values[buf] = v
+        return v
+
+    # -- single nodes ------------------------------------------------------------------------
+    def conv(self, node: ns.Conv, x: Value, res: Optional[Value] = None) -> Value:
+        if node.act not in ("relu", "none"):
+            raise NotImplementedError(f"activation {node.act!r} is not implemented by the HIP engine")
+        if node.dilation != 1:
+            raise NotImplementedError("dilated convs are not implemented by the HIP engine")
+        assert x.channels == node.cin, (node.key, x.channels, node.cin)
+        w, b = self.folded[node.key]
+        packed, bias = pack_conv(w, b, node.groups)
+        lout = ns.out_length([node], x.length)
+        y = self.new(x.domain, lout, node.cout)
+        self.ops.append(Op(
+            OP_CONV1D, x.domain, src0=x.vid, dst=y.vid, res=res.vid if res is not None else BUF_NONE,
+            cin=node.cin, cout=node.cout, k=node.k, stride=node.stride, pad=node.pad,
+            lin=x.length, lout=lout,
+            flags=(FLAG_RELU if node.act == "relu" else 0) | (FLAG_SRC_U8 if x.u8 else 0),
+            w_off=self.blob.add(packed), b_off=self.blob.add(bias), name=node.key,
+            macs_per_row=lout * node.cout * (node.cin // node.groups) * node.k))
+        return y
+
+    def net(self, nodes, x, head_slot: Optional[int] = None, softmax=False):
+        for node in nodes:
+            if isinstance(node, ns.Conv):
+                x = self.conv(node, x)
+            elif isinstance(node, ns.MaxPool):
+                lout = ns.out_length([node], x.length)
+                y = self.new(x.domain, lout, x.channels)
+                self.ops.append(Op(OP_MAXPOOL, x.domain, src0=x.vid, dst=y.vid, cin=x.channels,
+                                   cout=x.channels, k=node.k, stride=node.stride, pad=node.pad,
+                                   lin=x.length, lout=lout))
+                x = y
+            elif isinstance(node, ns.Residual):
+                short = self.net(node.shortcut, x) if node.shortcut else x
+                h = x
+                for i, sub in enumerate(node.body):
+                    last = i == len(node.body) - 1
+                    if not isinstance(sub, ns.Conv):
+                        raise NotImplementedError("residual bodies must be conv stacks")
+                    h = self.conv(sub, h, res=short if last else None)
+                x = h
+            elif isinstance(node, ns.Head):
+                w, b = self.folded[node.key]
+                assert head_slot is not None
+                self.ops.append(Op(OP_HEAD, x.domain, src0=x.vid, dst=head_slot, cin=x.channels,
+                                   cout=node.cout, lin=x.length, lout=1,
+                                   flags=FLAG_SOFTMAX if softmax else 0,
+                                   w_off=self.blob.add(w), b_off=self.blob.add(b), name=node.key,
+                                   macs_per_row=node.cin * node.cout))
+                x = None
+            elif isinstance(node, ns.Mix):
+                allele, sites = x
+                site = sites[node.pick]
+                assert site is not None and site.domain == ROWS_SITES and allele.domain == ROWS_ALLELES
+                y = self.new(ROWS_ALLELES, allele.length, allele.channels)
+                self.ops.append(Op(OP_MIX, ROWS_ALLELES, src0=allele.vid, src1=site.vid, dst=y.vid,
+                                   cin=allele.channels, lin=allele.length, lout=allele.length,
+                                   a0=float(node.coeffs[0]), a1=float(node.coeffs[1]), seg=SEG_AS))
+                x = y
+            elif isinstance(node, ns.Select):
+                x = x[node.index]
+            elif isinstance(node, ns.Transpose):
+                # the only transposed input is the one-hot reference [S, L, 5] -> [S, 5, L]
+                # (meta_convolver_ref.py:27-36); channels-last storage already is that view
+                if not (isinstance(x, Value) and x.vid == BUF_REF):
+                    raise NotImplementedError("Transpose is only supported on the reference segment input")
+            elif isinstance(node, ns.Concat):
+                a, b = x
+                assert a.domain == b.domain and a.length == b.length
+                y = self.new(a.domain, a.length, a.channels + b.channels)
+                self.ops.append(Op(OP_CONCAT, a.domain, src0=a.vid, src1=b.vid, dst=y.vid, cin=a.channels,
+                                   c1=b.channels, lin=a.length, lout=a.length))
+                x = y
+            else:
+                raise TypeError(node)
+        return x
+
+    def segsum(self, x: Value, seg: int) -> Value:
+        domain = ROWS_SITES if seg == SEG_AS else ROWS_ALLELES
+        y = self.new(domain, x.length, x.channels)
+        self.ops.append(Op(OP_SEGSUM, domain, src0=x.vid, dst=y.vid, cin=x.channels, lin=x.length,
+                           lout=x.length, seg=seg))
+        return y
+
+    def add(self, a: Value, b: Value) -> Value:
+        y = self.new(a.domain, a.length, a.channels)
+        self.ops.append(Op(OP_ADD, a.domain, src0=a.vid, src1=b.vid, dst=y.vid, cin=a.channels,
+                           lin=a.length, lout=a.length))
+        return y
+
+    # -- model -------------------------------------------------------------------------------
+    def read_frames(self, tech: int) -> Value:
+        spec = self.spec
+        name = f"read_convolver{tech}"
+        nodes = spec.nets[name]
+        cin = spec.channels[tech]
+        buf = BUF_READS0 if tech == 0 else BUF_READS1
+        dom = ROWS_READS0 if tech == 0 else ROWS_READS1
+        seg = SEG_R0A if tech == 0 else SEG_R1A
+        x = self.input(buf, dom, spec.window, cin)
+        from . import readconv_pack
+        if (self.fused and readconv_pack.AVAILABLE and spec.window == 150
+                and _is_canonical_read_convolver(nodes, cin)):
+            y = self.new(ROWS_ALLELES, 36, 64)
+            w_off = self.blob.add(readconv_pack.pack(nodes, self.folded, cin))
+            self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=buf, dst=y.vid, cin=cin, cout=64,
+                               lin=150, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name,
+                               flags=FLAG_SRC_U8, macs_per_row=0))
+            self.used_fused = True
+            return y
+        return self.segsum(self.net(nodes, x), seg)
+
+    def compress_and_predict(self, frames: Value, idx: int, slot: Optional[int]):
+        """MixtureOfExpertsAdvanced.py:117-159."""
+        spec = self.spec
+        comp = spec.nets[f"compressor{idx}"]
+        ca = self.net(comp, frames)
+        xattn = f"xattn{idx}"
+        needs_cs0 = spec.has(xattn) and any(isinstance(n, ns.Mix) and n.pick == 0 for n in spec.nets[xattn])
+        cs0 = self.net(comp, self.segsum(frames, SEG_AS)) if needs_cs0 else None
+        cs1 = self.segsum(ca, SEG_AS)
+        if spec.has(xattn):
+            self.net(spec.nets[xattn], (ca, (cs0, cs1)), head_slot=slot)
+        return (cs0, cs1), ca
+
+    def lower(self):
+        spec = self.spec
+        hybrid = spec.has("read_convolver1")
+        has = [spec.has(f"xattn{i}") for i in range(3)]
+        if not hybrid:
+            n_experts, slots = 1, [0, None, None]
+        elif not has[0] and not has[1]:
+            if not has[2]:
+                raise ValueError("no expert prediction is valid")    # reference assert, :239
+            n_experts, slots = 1, [None, None, 0]
+        else:
+            if not (has[0] and has[1]):
+                raise ValueError("hybrid data provided, but only single tech prediction is available")  # :243
+            n_experts, slots = 3, [0, 1, 2]
+        frames0 = self.read_frames(0)
+        f0, ca0 = self.compress_and_predict(frames0, 0, slots[0])
+        has_meta = False
+        if hybrid:
+            frames1 = self.read_frames(1)
+            f1, ca1 = self.compress_and_predict(frames1, 1, slots[1])
+            if spec.has("compressor2"):
+                if not has[2]:
+                    raise ValueError("xattn2 is needed with compressor2")                     # :184
+                frames2 = self.add(frames0, frames1)
+                # meta reads the site-level compressor output f2[0] (:192): force it alive
+                comp2 = spec.nets["compressor2"]
+                ca2 = self.net(comp2, frames2)
+                cs0_2 = self.net(comp2, self.segsum(frames2, SEG_AS))
+                cs1_2 = self.segsum(ca2, SEG_AS)
+                self.net(spec.nets["xattn2"], (ca2, (cs0_2, cs1_2)), head_slot=slots[2])
+                site_frames_for_meta = cs0_2
+            elif has[2]:
+                ca2 = self.net(spec.nets["combiner0"], (ca0, ca1))
+                cs2 = self.net(spec.nets["combiner1"], (f0[1], f1[1]))
+                self.net(spec.nets["xattn2"], (ca2, (None, cs2)), head_slot=slots[2])
+                site_frames_for_meta = cs2
+            else:
+                site_frames_for_meta = None     # built lazily below: only the meta expert reads it
+            if spec.has("meta"):
+                has_meta = True
+                meta_nodes = spec.nets["meta"]
+                pick = next(n.index for n in meta_nodes if isinstance(n, ns.Select))
+                ref = None
+                if pick == 1:
+                    self.uses_ref = True
+                    ref = self.input(BUF_REF, ROWS_SITES, spec.window, 5)
+                elif site_frames_for_meta is None:
+                    site_frames_for_meta = self.segsum(self.add(frames0, frames1), SEG_AS)   # :224-227
+                self.net(meta_nodes, (site_frames_for_meta, ref), head_slot=3, softmax=True)
+        return n_experts, has_meta
+
+
+def _allocate(ops: List[Op], values: Dict[int, Value]):
+    """Greedy liveness packing of virtual activations into physical scratch buffers, per domain."""
+    last_use: Dict[int, int] = {}
+    for i, o in enumerate(ops):
+        for v in (o.src0, o.src1, o.res):
+            if v >= 1000:
+                last_use[v] = i
+    phys: List[Tuple[int, int]] = [(0, 0)] * BUF_FIRST_SCRATCH      # reserved ids
+    free: Dict[int, List[int]] = {d: [] for d in range(4)}
+    assigned: Dict[int, int] = {}
+    for i, o in enumerate(ops):
+        if o.kind != OP_HEAD:
+            v = values[o.dst]
+            need = v.floats_per_row
+            pool = free[v.domain]
+            if pool:
+                # best fit: smallest buffer that is large enough, else the largest one (it grows)
+                fits = [p for p in pool if phys[p][1] >= need]
+                pick = min(fits, key=lambda p: phys[p][1]) if fits else max(pool, key=lambda p: phys[p][1])
+                pool.remove(pick)
+                phys[pick] = (v.domain, max(phys[pick][1], need))
+            else:
+                pick = len(phys)
+                phys.append((v.domain, need))
+            assigned[o.dst] = pick
+        # release inputs whose last use is this op (after the output was placed: no aliasing)
+        for vsrc in {o.src0, o.src1, o.res}:
+            if vsrc >= 1000 and last_use.get(vsrc) == i and vsrc in assigned:
+                free[values[vsrc].domain].append(assigned[vsrc])
+        # an output nobody reads (cannot happen in a well-formed program) would leak; ignore
+    for o in ops:
+        o.src0 = assigned.get(o.src0, o.src0)
+        o.src1 = assigned.get(o.src1, o.src1)
+        o.res = assigned.get(o.res, o.res)
+        if o.kind != OP_HEAD:
+            o.dst = assigned[o.dst]
+    return phys
+
+
+def compile_model(spec: ns.ModelSpec, state, fused: bool = True) -> Program:
+    low = _Lowering(spec, state, fused)
+    n_experts, has_meta = low.lower()
+    buffers = _allocate(low.ops, low.values)
+    return Program(
+        spec_name=spec.name, window=spec.window, channels0=spec.channels[0],
+        channels1=spec.channels[1] if spec.has("read_convolver1") else 0,
+        n_experts=n_experts, has_meta=has_meta, uses_ref=low.uses_ref, ops=low.ops,
+        buffers=buffers, weights=low.blob.finish(), fused_read_convolver=low.used_fused)

@@ -1,0 +1,648 @@
+// C ABI of the engine (include/hello_mi355x.h): model program interpreter, batch CSR preparation,
+// scratch management, stream-ordered execution.  Host code only; kernels live in the other .hip files.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hello_mi355x.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(HELLO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// grow-only device allocation
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) {
+            if (hipFree(p) != hipSuccess) return -1;
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;   // slack so slightly larger batches do not reallocate
+        if (hipMalloc(&p, want) != hipSuccess) return -1;
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return -1;
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct hello_engine {
+    int device = 0;
+    hello_model_desc desc{};
+    std::vector<hello_op> ops;
+    std::vector<hello_buffer> buffers;
+    float* d_weights = nullptr;
+    size_t n_weight_floats = 0;
+
+    std::vector<DevBuf> scratch;     // indexed by buffer id (0..2 = staged inputs when host pointers)
+    DevBuf d_csr;                    // all per-batch index arrays, one allocation
+    PinnedBuf h_csr;
+    DevBuf d_logits, d_meta, d_post, d_rcl0, d_rcl1;
+    DevBuf d_partial;                // fused read convolver partial sums
+    hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev_staged = nullptr;  // H2D of the pinned CSR block finished
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool staged_pending = false;
+    bool timed = false;
+    bool profiling = false;
+    std::vector<hipEvent_t> op_events;
+    int n_timed_ops = 0;
+
+    // device views into d_csr for the current batch
+    int32_t *roff0 = nullptr, *roff1 = nullptr, *aoff = nullptr, *site_of_allele = nullptr;
+    int32_t *allele_of_read0 = nullptr, *allele_of_read1 = nullptr;
+    int32_t *group_slot0 = nullptr, *group_slot1 = nullptr, *slot_off0 = nullptr, *slot_off1 = nullptr;
+    int64_t* pair_off = nullptr;
+};
+
+namespace {
+
+long long rows_of(int domain, int32_t S, int32_t A, int64_t R0, int64_t R1) {
+    switch (domain) {
+        case HELLO_ROWS_READS0: return R0;
+        case HELLO_ROWS_READS1: return R1;
+        case HELLO_ROWS_ALLELES: return A;
+        case HELLO_ROWS_SITES: return S;
+    }
+    return -1;
+}
+
+int validate_model(const hello_model_desc* d) {
+    if (!d) return fail(HELLO_ERR_ARG, "model description is NULL");
+    if (d->abi_version != HELLO_ABI_VERSION)
+        return fail(HELLO_ERR_MODEL, "abi_version %d != %d", d->abi_version, HELLO_ABI_VERSION);
+    if (d->window <= 0 || d->channels0 <= 0 || d->channels1 < 0)
+        return fail(HELLO_ERR_MODEL, "bad window/channels");
+    if (d->n_experts != 1 && d->n_experts != 3) return fail(HELLO_ERR_MODEL, "n_experts must be 1 or 3");
+    if (d->n_buffers < HELLO_BUF_FIRST_SCRATCH || !d->buffers) return fail(HELLO_ERR_MODEL, "bad buffer table");
+    if (d->n_ops <= 0 || !d->ops) return fail(HELLO_ERR_MODEL, "empty program");
+    for (int i = HELLO_BUF_FIRST_SCRATCH; i < d->n_buffers; ++i) {
+        if (d->buffers[i].domain < 0 || d->buffers[i].domain > 3 || d->buffers[i].floats_per_row <= 0)
+            return fail(HELLO_ERR_MODEL, "buffer %d malformed", i);
+    }
+    auto buf_ok = [&](int id, bool allow_none) {
+        if (id == HELLO_BUF_NONE) return allow_none;
+        return id >= 0 && id < d->n_buffers;
+    };
+    for (int i = 0; i < d->n_ops; ++i) {
+        const hello_op& o = d->ops[i];
+        if (o.kind < HELLO_OP_CONV1D || o.kind > HELLO_OP_READCONV_FUSED)
+            return fail(HELLO_ERR_MODEL, "op %d: unknown kind %d", i, o.kind);
+        if (o.domain < 0 || o.domain > 3) return fail(HELLO_ERR_MODEL, "op %d: bad domain", i);
+        if (!buf_ok(o.src0, false)) return fail(HELLO_ERR_MODEL, "op %d: bad src0", i);
+        if (!buf_ok(o.src1, true) || !buf_ok(o.res, true)) return fail(HELLO_ERR_MODEL, "op %d: bad src1/res", i);
+        if (o.kind == HELLO_OP_HEAD) {
+            if (o.dst < 0 || o.dst > 3 || o.cout < 1 || o.cout > 4)
+                return fail(HELLO_ERR_MODEL, "op %d: bad head slot/cout", i);
+        } else if (o.dst < HELLO_BUF_FIRST_SCRATCH || o.dst >= d->n_buffers) {
+            return fail(HELLO_ERR_MODEL, "op %d: dst must be a scratch buffer", i);
+        }
+        if (o.kind == HELLO_OP_CONV1D) {
+            if (o.cin <= 0 || o.cout <= 0 || (o.cout % 4) || o.k <= 0 || o.stride <= 0 || o.pad < 0 ||
+                o.lin <= 0 || o.lout <= 0 || o.w_off < 0 || o.b_off < 0)
+                return fail(HELLO_ERR_MODEL, "op %d: bad conv geometry", i);
+            if ((o.lin + 2 * o.pad - o.k) / o.stride + 1 != o.lout)
+                return fail(HELLO_ERR_MODEL, "op %d: lout inconsistent", i);
+        }
+        if ((o.kind == HELLO_OP_SEGSUM || o.kind == HELLO_OP_MIX || o.kind == HELLO_OP_READCONV_FUSED) &&
+            (o.seg < 0 || o.seg > 2))
+            return fail(HELLO_ERR_MODEL, "op %d: bad segment kind", i);
+    }
+    return 0;
+}
+
+template <typename T>
+T* carve(char*& cursor, size_t count) {
+    T* p = reinterpret_cast<T*>(cursor);
+    cursor += (count * sizeof(T) + 15) & ~size_t(15);
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hello_last_error(void) { return g_last_error.c_str(); }
+int hello_abi_version(void) { return HELLO_ABI_VERSION; }
+
+int hello_engine_create(const hello_model_desc* desc, const void* folded_weights, size_t nbytes,
+                        int hip_device, hello_engine** out) {
+    if (!out) return fail(HELLO_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (int rc = validate_model(desc)) return rc;
+    if (!folded_weights || nbytes == 0 || (nbytes % 4)) return fail(HELLO_ERR_ARG, "bad weight blob");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(HELLO_ERR_NOGPU, "no HIP device visible: the HIP engine cannot run");
+    if (hip_device < 0 || hip_device >= n_dev) return fail(HELLO_ERR_ARG, "device %d out of range", hip_device);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, hip_device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HELLO_ERR_NOGPU, "device %d is %s; this engine is built for gfx950 only", hip_device,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(hip_device));
+
+    hello_engine* e = new hello_engine();
+    e->device = hip_device;
+    e->desc = *desc;
+    e->ops.assign(desc->ops, desc->ops + desc->n_ops);
+    e->buffers.assign(desc->buffers, desc->buffers + desc->n_buffers);
+    e->desc.ops = e->ops.data();
+    e->desc.buffers = e->buffers.data();
+    e->n_weight_floats = nbytes / 4;
+    for (const hello_op& o : e->ops) {
+        if ((o.kind == HELLO_OP_CONV1D || o.kind == HELLO_OP_HEAD || o.kind == HELLO_OP_READCONV_FUSED) &&
+            ((size_t)o.w_off >= e->n_weight_floats || (size_t)o.b_off >= e->n_weight_floats)) {
+            delete e;
+            return fail(HELLO_ERR_MODEL, "weight offset outside the blob");
+        }
+    }
+    e->scratch.resize(desc->n_buffers);
+    e->op_events.resize(desc->n_ops + 1, nullptr);
+    hipError_t err = hipMalloc((void**)&e->d_weights, nbytes);
+    if (err == hipSuccess) err = hipMemcpy(e->d_weights, folded_weights, nbytes, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_staged, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev_start);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev_stop);
+    if (err != hipSuccess) {
+        hello_engine_destroy(e);
+        return fail(HELLO_ERR_HIP, "engine setup failed: %s", hipGetErrorString(err));
+    }
+    *out = e;
+    return HELLO_OK;
+}
+
+void hello_engine_destroy(hello_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (auto& b : e->scratch) b.release();
+    e->d_csr.release();
+    e->h_csr.release();
+    e->d_logits.release();
+    e->d_meta.release();
+    e->d_post.release();
+    e->d_rcl0.release();
+    e->d_rcl1.release();
+    e->d_partial.release();
+    if (e->d_weights) (void)hipFree(e->d_weights);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    if (e->ev_staged) (void)hipEventDestroy(e->ev_staged);
+    if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+    if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+    for (auto ev : e->op_events)
+        if (ev) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+int hello_engine_synchronize(hello_engine* e) {
+    if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->last_stream ? e->last_stream : e->own_stream));
+    return HELLO_OK;
+}
+
+int hello_engine_last_forward_ms(hello_engine* e, float* ms) {
+    if (!e || !ms) return fail(HELLO_ERR_ARG, "NULL argument");
+    if (!e->timed) return fail(HELLO_ERR_ARG, "no forward has run yet");
+    HIP_TRY(hipEventSynchronize(e->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev_start, e->ev_stop));
+    return HELLO_OK;
+}
+
+int hello_engine_set_profiling(hello_engine* e, int enabled) {
+    if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
+    e->profiling = enabled != 0;
+    if (e->profiling) {
+        for (auto& ev : e->op_events)
+            if (!ev) HIP_TRY(hipEventCreate(&ev));
+    }
+    return HELLO_OK;
+}
+
+int hello_engine_op_times_ms(hello_engine* e, float* ms, int32_t capacity, int32_t* n_ops) {
+    if (!e || !ms || !n_ops) return fail(HELLO_ERR_ARG, "NULL argument");
+    if (!e->profiling || e->n_timed_ops == 0) return fail(HELLO_ERR_ARG, "profiling was not enabled for the last forward");
+    const int n = e->n_timed_ops < capacity ? e->n_timed_ops : capacity;
+    HIP_TRY(hipEventSynchronize(e->op_events[e->n_timed_ops]));
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], e->op_events[i], e->op_events[i + 1]));
+    *n_ops = n;
+    return HELLO_OK;
+}
+
+// Build every per-batch index array on the host (pinned), ship them in one copy.
+static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32_t* rpa1,
+                               const int32_t* aps, int32_t S, int32_t A, int64_t R0, int64_t R1,
+                               bool two_tech, hipStream_t stream) {
+    const int G = hello::readconv_reads_per_group();
+    const int64_t n_groups0 = (R0 + G - 1) / G, n_groups1 = two_tech ? (R1 + G - 1) / G : 0;
+    size_t bytes = 0;
+    auto add = [&](size_t count, size_t elem) { bytes += (count * elem + 15) & ~size_t(15); };
+    add(A + 1, 4); add(A + 1, 4); add(S + 1, 4); add(A, 4);          // roff0 roff1 aoff site_of_allele
+    add(R0, 4); add(R1, 4);                                          // allele_of_read0/1
+    add(n_groups0 + 1, 4); add(n_groups1 + 1, 4);                    // group_slot0/1
+    add(A + 1, 4); add(A + 1, 4);                                    // slot_off0/1
+    add(S + 1, 8);                                                   // pair_off
+    if (e->staged_pending) {
+        HIP_TRY(hipEventSynchronize(e->ev_staged));   // previous batch's copy has left the pinned block
+        e->staged_pending = false;
+    }
+    if (e->h_csr.ensure(bytes)) return fail(HELLO_ERR_HIP, "pinned allocation of %zu bytes failed", bytes);
+    if (bytes > e->d_csr.cap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (e->d_csr.ensure(bytes)) return fail(HELLO_ERR_HIP, "device allocation of %zu bytes failed", bytes);
+    }
+    char* hc = (char*)e->h_csr.p;
+    char* hbase = hc;
+    int32_t* h_roff0 = carve<int32_t>(hc, A + 1);
+    int32_t* h_roff1 = carve<int32_t>(hc, A + 1);
+    int32_t* h_aoff = carve<int32_t>(hc, S + 1);
+    int32_t* h_soa = carve<int32_t>(hc, A);
+    int32_t* h_aor0 = carve<int32_t>(hc, R0);
+    int32_t* h_aor1 = carve<int32_t>(hc, R1);
+    int32_t* h_gs0 = carve<int32_t>(hc, n_groups0 + 1);
+    int32_t* h_gs1 = carve<int32_t>(hc, n_groups1 + 1);
+    int32_t* h_so0 = carve<int32_t>(hc, A + 1);
+    int32_t* h_so1 = carve<int32_t>(hc, A + 1);
+    int64_t* h_poff = carve<int64_t>(hc, S + 1);
+
+    auto build_reads = [&](const int32_t* rpa, int64_t R, int32_t* roff, int32_t* aor, int32_t* gslot,
+                           int32_t* soff, int64_t n_groups, const char* which) -> int {
+        int64_t acc = 0;
+        for (int32_t a = 0; a < A; ++a) {
+            if (rpa[a] <= 0)
+                return fail(HELLO_ERR_SHAPE, "%s[%d] = %d: every allele needs >= 1 read (dummy zero read)",
+                            which, a, rpa[a]);
+            roff[a] = (int32_t)acc;
+            for (int32_t r = 0; r < rpa[a]; ++r) {
+                if (acc + r < R) aor[acc + r] = a;
+            }
+            acc += rpa[a];
+            if (acc > R) return fail(HELLO_ERR_SHAPE, "sum(%s) exceeds n_reads = %lld", which, (long long)R);
+        }
+        roff[A] = (int32_t)acc;
+        if (acc != R)
+            return fail(HELLO_ERR_SHAPE, "sum(%s) = %lld != n_reads = %lld", which, (long long)acc, (long long)R);
+        // partial-sum slots of the fused read convolver: one slot per (read group, allele) incidence,
+        // numbered in (group, allele) order == (allele, group) order because both are monotone in the read index
+        int64_t slot = 0;
+        int32_t a_lo = 0;
+        // slot_off[a] = first slot of allele a; group_slot[g] = first slot of group g
+        for (int32_t a = 0; a <= A; ++a) soff[a] = 0;
+        for (int64_t g = 0; g < n_groups; ++g) {
+            gslot[g] = (int32_t)slot;
+            const int64_t r_lo = g * G, r_hi = (r_lo + G < R) ? r_lo + G : R;
+            const int32_t first = aor[r_lo], last = aor[r_hi - 1];
+            slot += (last - first + 1);
+            (void)a_lo;
+        }
+        gslot[n_groups] = (int32_t)slot;
+        // an allele's slots: one per group it intersects
+        int64_t s = 0;
+        for (int32_t a = 0; a < A; ++a) {
+            soff[a] = (int32_t)s;
+            const int64_t g_first = roff[a] / G, g_last = (roff[a + 1] - 1) / G;
+            s += (g_last - g_first + 1);
+        }
+        soff[A] = (int32_t)s;
+        if (s != slot) return fail(HELLO_ERR_ARG, "internal: slot accounting mismatch");
+        return 0;
+    };
+    if (int rc = build_reads(rpa0, R0, h_roff0, h_aor0, h_gs0, h_so0, n_groups0, "reads_per_allele0")) return rc;
+    if (two_tech) {
+        if (int rc = build_reads(rpa1, R1, h_roff1, h_aor1, h_gs1, h_so1, n_groups1, "reads_per_allele1")) return rc;
+    } else {
+        h_gs1[0] = 0;
+    }
+    int64_t acc = 0, pacc = 0;
+    for (int32_t s = 0; s < S; ++s) {
+        if (aps[s] <= 0) return fail(HELLO_ERR_SHAPE, "alleles_per_site[%d] = %d", s, aps[s]);
+        h_aoff[s] = (int32_t)acc;
+        h_poff[s] = pacc;
+        for (int32_t k = 0; k < aps[s] && acc + k < A; ++k) h_soa[acc + k] = s;
+        acc += aps[s];
+        pacc += (int64_t)aps[s] * (aps[s] + 1) / 2;
+        if (acc > A) return fail(HELLO_ERR_SHAPE, "sum(alleles_per_site) exceeds n_alleles = %d", A);
+    }
+    h_aoff[S] = (int32_t)acc;
+    h_poff[S] = pacc;
+    if (acc != A) return fail(HELLO_ERR_SHAPE, "sum(alleles_per_site) = %lld != n_alleles = %d", (long long)acc, A);
+
+    HIP_TRY(hipMemcpyAsync(e->d_csr.p, hbase, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(e->ev_staged, stream));
+    e->staged_pending = true;
+    char* dbase = (char*)e->d_csr.p;
+    auto dev = [&](void* hp) { return dbase + ((char*)hp - hbase); };
+    e->roff0 = (int32_t*)dev(h_roff0);
+    e->roff1 = (int32_t*)dev(h_roff1);
+    e->aoff = (int32_t*)dev(h_aoff);
+    e->site_of_allele = (int32_t*)dev(h_soa);
+    e->allele_of_read0 = (int32_t*)dev(h_aor0);
+    e->allele_of_read1 = (int32_t*)dev(h_aor1);
+    e->group_slot0 = (int32_t*)dev(h_gs0);
+    e->group_slot1 = (int32_t*)dev(h_gs1);
+    e->slot_off0 = (int32_t*)dev(h_so0);
+    e->slot_off1 = (int32_t*)dev(h_so1);
+    e->pair_off = (int64_t*)dev(h_poff);
+    return 0;
+}
+
+int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* rpa0,
+                         const uint8_t* reads1, const int32_t* rpa1, const int32_t* aps,
+                         const uint8_t* ref_onehot, int32_t S, int32_t A, int64_t R0, int64_t R1,
+                         float* logits, float* meta, int32_t flags, void* hip_stream) {
+    if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
+    const hello_model_desc& d = e->desc;
+    const bool two_tech = d.channels1 > 0;
+    if (S <= 0 || A <= 0 || R0 <= 0) return fail(HELLO_ERR_ARG, "empty batch (S=%d A=%d R0=%lld)", S, A, (long long)R0);
+    if (A < S) return fail(HELLO_ERR_SHAPE, "n_alleles %d < n_sites %d", A, S);
+    if (!reads0 || !rpa0 || !aps || !logits) return fail(HELLO_ERR_ARG, "NULL input/output pointer");
+    if (two_tech && (!reads1 || !rpa1 || R1 <= 0)) return fail(HELLO_ERR_ARG, "model needs a second read set");
+    if (!two_tech) R1 = 0;
+    if (d.uses_ref && !ref_onehot) return fail(HELLO_ERR_ARG, "model needs ref_onehot");
+    if (d.has_meta && !meta) return fail(HELLO_ERR_ARG, "model produces meta weights: meta output is NULL");
+    if (R0 > 0x7fffffffLL || R1 > 0x7fffffffLL) return fail(HELLO_ERR_ARG, "more than 2^31 reads in one batch");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    e->last_stream = stream;
+    const bool in_dev = flags & HELLO_IN_DEVICE, out_dev = flags & HELLO_OUT_DEVICE;
+
+    if (int rc = stage_batch_indices(e, rpa0, rpa1, aps, S, A, R0, R1, two_tech, stream)) return rc;
+
+    // ---- scratch sizing (grow-only; growth synchronises the stream first) ----------------------
+    bool synced = false;
+    auto ensure = [&](DevBuf& b, size_t bytes) -> int {
+        if (bytes <= b.cap) return 0;
+        if (!synced) {
+            if (hipStreamSynchronize(stream) != hipSuccess) return fail(HELLO_ERR_HIP, "stream sync failed");
+            synced = true;
+        }
+        if (b.ensure(bytes)) return fail(HELLO_ERR_HIP, "device allocation of %zu bytes failed", bytes);
+        return 0;
+    };
+    for (int i = HELLO_BUF_FIRST_SCRATCH; i < d.n_buffers; ++i) {
+        const long long rows = rows_of(e->buffers[i].domain, S, A, R0, R1);
+        if (int rc = ensure(e->scratch[i], (size_t)rows * e->buffers[i].floats_per_row * sizeof(float))) return rc;
+    }
+    const size_t in_bytes0 = (size_t)R0 * d.window * d.channels0;
+    const size_t in_bytes1 = (size_t)R1 * d.window * d.channels1;
+    const size_t ref_bytes = (size_t)S * d.window * 5;
+    const void* in_ptr[3] = {reads0, reads1, ref_onehot};
+    const size_t in_bytes[3] = {in_bytes0, two_tech ? in_bytes1 : 0, (d.uses_ref ? ref_bytes : 0)};
+    const void* buf_ptr[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; ++i) {
+        if (!in_bytes[i]) continue;
+        if (in_dev) {
+            buf_ptr[i] = in_ptr[i];
+        } else {
+            if (int rc = ensure(e->scratch[i], in_bytes[i])) return rc;
+            HIP_TRY(hipMemcpyAsync(e->scratch[i].p, in_ptr[i], in_bytes[i], hipMemcpyHostToDevice, stream));
+            buf_ptr[i] = e->scratch[i].p;
+        }
+    }
+    if (flags & HELLO_LAYOUT_RCL) {
+        if (int rc = ensure(e->d_rcl0, in_bytes0)) return rc;
+        HIP_TRY(hello::launch_rcl_to_rlc((const uint8_t*)buf_ptr[0], (uint8_t*)e->d_rcl0.p, R0, d.window, d.channels0, stream));
+        buf_ptr[0] = e->d_rcl0.p;
+        if (two_tech) {
+            if (int rc = ensure(e->d_rcl1, in_bytes1)) return rc;
+            HIP_TRY(hello::launch_rcl_to_rlc((const uint8_t*)buf_ptr[1], (uint8_t*)e->d_rcl1.p, R1, d.window, d.channels1, stream));
+            buf_ptr[1] = e->d_rcl1.p;
+        }
+    }
+    float* d_logits = logits;
+    float* d_meta = meta;
+    const size_t logit_bytes = (size_t)d.n_experts * A * sizeof(float), meta_bytes = (size_t)S * 3 * sizeof(float);
+    if (!out_dev) {
+        if (int rc = ensure(e->d_logits, logit_bytes)) return rc;
+        d_logits = (float*)e->d_logits.p;
+        if (d.has_meta) {
+            if (int rc = ensure(e->d_meta, meta_bytes)) return rc;
+            d_meta = (float*)e->d_meta.p;
+        }
+    }
+    // fused read convolver partial slots (worst case: one per read + one per group)
+    bool has_fused = false;
+    for (const hello_op& o : e->ops) has_fused |= (o.kind == HELLO_OP_READCONV_FUSED);
+    if (has_fused) {
+        const int G = hello::readconv_reads_per_group();
+        const int64_t Rmax = R0 > R1 ? R0 : R1;
+        const size_t slots = (size_t)A + (size_t)((Rmax + G - 1) / G) + 1;
+        if (int rc = ensure(e->d_partial, slots * 36 * 64 * sizeof(float))) return rc;
+    }
+    // experts without a head (ensemble of two: third expert is all-zero logits, :244) stay zero
+    if (d.n_experts == 3) HIP_TRY(hipMemsetAsync(d_logits, 0, logit_bytes, stream));
+
+    auto ptr = [&](int id) -> void* {
+        if (id == HELLO_BUF_NONE) return nullptr;
+        if (id < HELLO_BUF_FIRST_SCRATCH) return const_cast<void*>(buf_ptr[id]);
+        return e->scratch[id].p;
+    };
+
+    HIP_TRY(hipEventRecord(e->ev_start, stream));
+    int op_index = 0;
+    for (const hello_op& o : e->ops) {
+        if (e->profiling) HIP_TRY(hipEventRecord(e->op_events[op_index], stream));
+        const long long rows = rows_of(o.domain, S, A, R0, R1);
+        switch (o.kind) {
+            case HELLO_OP_CONV1D: {
+                hello::ConvArgs a{};
+                a.src = ptr(o.src0);
+                a.dst = (float*)ptr(o.dst);
+                a.res = (const float*)ptr(o.res);
+                a.w = e->d_weights + o.w_off;
+                a.bias = e->d_weights + o.b_off;
+                a.m_total = rows * o.lout;
+                a.lin = o.lin; a.lout = o.lout; a.cin = o.cin; a.cout = o.cout;
+                a.k = o.k; a.stride = o.stride; a.pad = o.pad;
+                a.kpad = ((o.k * o.cin + 31) / 32) * 32;
+                a.cout_pad = ((o.cout + 31) / 32) * 32;
+                a.relu = (o.flags & HELLO_FLAG_RELU) ? 1 : 0;
+                a.src_u8 = (o.flags & HELLO_FLAG_SRC_U8) ? 1 : 0;
+                if (!a.src) return fail(HELLO_ERR_ARG, "op %d reads an input the caller did not supply", op_index);
+                HIP_TRY(hello::launch_conv1d(a, stream));
+                break;
+            }
+            case HELLO_OP_MAXPOOL:
+                HIP_TRY(hello::launch_maxpool((const float*)ptr(o.src0), (float*)ptr(o.dst), rows, o.lin, o.lout,
+                                              o.cin, o.k, o.stride, o.pad, stream));
+                break;
+            case HELLO_OP_SEGSUM: {
+                const int32_t* off = o.seg == HELLO_SEG_READS0_TO_ALLELES ? e->roff0
+                                     : o.seg == HELLO_SEG_READS1_TO_ALLELES ? e->roff1 : e->aoff;
+                HIP_TRY(hello::launch_segsum((const float*)ptr(o.src0), (float*)ptr(o.dst), off, (int)rows,
+                                             o.lin * o.cin, stream));
+                break;
+            }
+            case HELLO_OP_MIX:
+                HIP_TRY(hello::launch_mix((const float*)ptr(o.src0), (const float*)ptr(o.src1), (float*)ptr(o.dst),
+                                          e->site_of_allele, rows, o.lin * o.cin, o.a0, o.a1, stream));
+                break;
+            case HELLO_OP_HEAD: {
+                float* outp;
+                long long so, sr;
+                if (o.dst == 3) { outp = d_meta; so = 1; sr = 3; }
+                else { outp = d_logits + (long long)o.dst * A; so = 0; sr = 1; }
+                HIP_TRY(hello::launch_head((const float*)ptr(o.src0), e->d_weights + o.w_off, e->d_weights + o.b_off,
+                                           outp, rows, o.lin, o.cin, o.cout, so, sr,
+                                           (o.flags & HELLO_FLAG_SOFTMAX) ? 1 : 0, stream));
+                break;
+            }
+            case HELLO_OP_CONCAT:
+                HIP_TRY(hello::launch_concat((const float*)ptr(o.src0), (const float*)ptr(o.src1), (float*)ptr(o.dst),
+                                             rows * o.lin, o.cin, o.c1, stream));
+                break;
+            case HELLO_OP_ADD:
+                HIP_TRY(hello::launch_add((const float*)ptr(o.src0), (const float*)ptr(o.src1), (float*)ptr(o.dst),
+                                          rows * o.lin * o.cin, stream));
+                break;
+            case HELLO_OP_READCONV_FUSED: {
+                const bool t1 = o.seg == HELLO_SEG_READS1_TO_ALLELES;
+                hello::ReadConvArgs a{};
+                a.reads = (const uint8_t*)ptr(o.src0);
+                a.w = e->d_weights + o.w_off;
+                a.partial = (float*)e->d_partial.p;
+                a.allele_of_read = t1 ? e->allele_of_read1 : e->allele_of_read0;
+                a.slot_of_group = t1 ? e->group_slot1 : e->group_slot0;
+                a.n_reads = t1 ? R1 : R0;
+                a.channels = o.cin;
+                HIP_TRY(hello::launch_readconv_fused(a, stream));
+                HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,
+                                                        (float*)ptr(o.dst), A, stream));
+                break;
+            }
+        }
+        ++op_index;
+    }
+    if (e->profiling) {
+        HIP_TRY(hipEventRecord(e->op_events[op_index], stream));
+        e->n_timed_ops = op_index;
+    } else {
+        e->n_timed_ops = 0;
+    }
+    HIP_TRY(hipEventRecord(e->ev_stop, stream));
+    e->timed = true;
+
+    if (!out_dev) {
+        HIP_TRY(hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, stream));
+        if (d.has_meta) HIP_TRY(hipMemcpyAsync(meta, d_meta, meta_bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return HELLO_OK;
+}
+
+int hello_engine_posteriors(hello_engine* e, const float* logits, const float* meta, const int32_t* aps,
+                            int32_t S, int32_t A, int64_t n_pairs_total, float* out, int32_t flags,
+                            void* hip_stream) {
+    if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
+    if (!logits || !aps || !out || S <= 0 || A <= 0) return fail(HELLO_ERR_ARG, "bad argument");
+    const hello_model_desc& d = e->desc;
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    e->last_stream = stream;
+    const bool in_dev = flags & HELLO_IN_DEVICE, out_dev = flags & HELLO_OUT_DEVICE;
+    // own small CSR block (allele offsets + pair offsets)
+    std::vector<int32_t> aoff(S + 1);
+    std::vector<int64_t> poff(S + 1);
+    int64_t acc = 0, pacc = 0;
+    for (int32_t s = 0; s < S; ++s) {
+        if (aps[s] <= 0) return fail(HELLO_ERR_SHAPE, "alleles_per_site[%d] = %d", s, aps[s]);
+        aoff[s] = (int32_t)acc;
+        poff[s] = pacc;
+        acc += aps[s];
+        pacc += (int64_t)aps[s] * (aps[s] + 1) / 2;
+    }
+    aoff[S] = (int32_t)acc;
+    poff[S] = pacc;
+    if (acc != A) return fail(HELLO_ERR_SHAPE, "sum(alleles_per_site) = %lld != n_alleles = %d", (long long)acc, A);
+    if (pacc != n_pairs_total)
+        return fail(HELLO_ERR_SHAPE, "n_pairs_total = %lld, expected %lld", (long long)n_pairs_total, (long long)pacc);
+    const size_t a_bytes = (S + 1) * sizeof(int32_t), p_bytes = (S + 1) * sizeof(int64_t);
+    const size_t a_pad = (a_bytes + 15) & ~size_t(15);
+    const size_t l_bytes = (size_t)d.n_experts * A * sizeof(float), m_bytes = (size_t)S * 3 * sizeof(float);
+    const size_t o_bytes = (size_t)4 * n_pairs_total * sizeof(float);
+    const size_t l_pad = (l_bytes + 15) & ~size_t(15), m_pad = (m_bytes + 15) & ~size_t(15);
+    const size_t total = a_pad + ((p_bytes + 15) & ~size_t(15)) + l_pad + m_pad + o_bytes;
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (e->d_post.ensure(total)) return fail(HELLO_ERR_HIP, "device allocation of %zu bytes failed", total);
+    char* base = (char*)e->d_post.p;
+    int32_t* d_aoff = (int32_t*)base;
+    int64_t* d_poff = (int64_t*)(base + a_pad);
+    float* d_l = (float*)(base + a_pad + ((p_bytes + 15) & ~size_t(15)));
+    float* d_m = (float*)((char*)d_l + l_pad);
+    float* d_o = (float*)((char*)d_m + m_pad);
+    HIP_TRY(hipMemcpyAsync(d_aoff, aoff.data(), a_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(d_poff, poff.data(), p_bytes, hipMemcpyHostToDevice, stream));
+    const float* lp = logits;
+    const float* mp = meta;
+    if (!in_dev) {
+        HIP_TRY(hipMemcpyAsync(d_l, logits, l_bytes, hipMemcpyHostToDevice, stream));
+        lp = d_l;
+        if (meta) {
+            HIP_TRY(hipMemcpyAsync(d_m, meta, m_bytes, hipMemcpyHostToDevice, stream));
+            mp = d_m;
+        }
+    }
+    float* op = out_dev ? out : d_o;
+    HIP_TRY(hello::launch_posteriors(lp, (d.n_experts == 3) ? mp : nullptr, d_aoff, d_poff, S, A, d.n_experts,
+                                     n_pairs_total, op, stream));
+    if (!out_dev) HIP_TRY(hipMemcpyAsync(out, d_o, o_bytes, hipMemcpyDeviceToHost, stream));
+    // the host vectors above die with this frame: the copies from them must have completed
+    HIP_TRY(hipStreamSynchronize(stream));
+    return HELLO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Launchers of the gfx950 kernels behind the C ABI (include/hello_mi355x.h).
+// Activations: float32, channels-last [rows][length][channels].  All launchers are asynchronous on
+// `stream` and return the hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hello {
+
+struct ConvArgs {
+    const void* src;      // float or uint8 [rows][lin][cin]
+    float* dst;           // [rows][lout][cout]
+    const float* res;     // optional residual, same shape as dst, added after the activation
+    const float* w;       // packed [cout_pad][kpad], k index = tap*cin + c, zero padded
+    const float* bias;    // [cout_pad]
+    long long m_total;    // rows * lout
+    int lin, lout, cin, cout, k, stride, pad;
+    int kpad;             // multiple of 32
+    int cout_pad;         // multiple of 32
+    int relu;
+    int src_u8;
+};
+hipError_t launch_conv1d(const ConvArgs& a, hipStream_t stream);
+
+hipError_t launch_maxpool(const float* src, float* dst, long long rows, int lin, int lout, int c,
+                          int k, int stride, int pad, hipStream_t stream);
+
+// dst[s][e] = sum_{r in [off[s], off[s+1])} src[r][e], e < row_floats (row_floats % 4 == 0)
+hipError_t launch_segsum(const float* src, float* dst, const int32_t* off, int n_seg, int row_floats,
+                         hipStream_t stream);
+
+// dst[a][e] = a0*src0[a][e] + a1*src1[owner[a]][e]
+hipError_t launch_mix(const float* src0, const float* src1, float* dst, const int32_t* owner,
+                      long long rows, int row_floats, float a0, float a1, hipStream_t stream);
+
+// out[o*out_stride_o + row*out_stride_row] = b[o] + sum_c W[o][c] * mean_l src[row][l][c]; optional softmax over o
+hipError_t launch_head(const float* src, const float* w, const float* b, float* out, long long rows,
+                       int len, int c, int cout, long long out_stride_o, long long out_stride_row,
+                       int softmax, hipStream_t stream);
+
+hipError_t launch_concat(const float* src0, const float* src1, float* dst, long long rows_x_len, int c0,
+                         int c1, hipStream_t stream);
+
+hipError_t launch_add(const float* src0, const float* src1, float* dst, long long n, hipStream_t stream);
+
+// uint8 [R][C][L] -> uint8 [R][L][C]
+hipError_t launch_rcl_to_rlc(const uint8_t* src, uint8_t* dst, long long rows, int len, int c,
+                             hipStream_t stream);
+
+// MoEMergedWrapperAdvanced posterior section; out rows: mix, e0, e1, e2, each [n_pairs_total]
+hipError_t launch_posteriors(const float* logits, const float* meta, const int32_t* allele_off,
+                             const int64_t* pair_off, int n_sites, long long n_alleles, int n_experts,
+                             long long n_pairs_total, float* out, hipStream_t stream);
+
+// ---- fused read convolver (readconv_fused.hip) ------------------------------------------------
+struct ReadConvArgs {
+    const uint8_t* reads;      // [R][150][C]
+    const float* w;            // packed block, see compiler.pack_readconv
+    float* partial;            // [n_groups * reads_per_group][36][64] worst case; slot-compacted
+    const int32_t* allele_of_read;   // [R]
+    const int32_t* slot_of_group;    // [n_groups + 1] first partial slot of each read group
+    long long n_reads;
+    int channels;
+};
+int readconv_reads_per_group();
+hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
+// frames[a] = sum of the partial slots of allele a, in slot order
+hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames,
+                                    int n_alleles, hipStream_t stream);
+
+}  // namespace hello

@@ -1,0 +1,232 @@
+"""ctypes binding of libhello_mi355x.so (include/hello_mi355x.h) and the batched operator surface.
+
+``Engine.forward`` mirrors the reference's batched call
+``dnn(tensors, numAllelesPerSite, numReadsPerAllele, reference_segments, *extra)``
+(reference python/MixtureOfExpertsDNNFast.py:128-134 -> MixtureOfExpertsAdvanced.py:161).  There is no
+CPU fallback: if the HIP library or a gfx950 device is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import compiler
+from . import netspec as ns
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhello_mi355x.so")
+HELLO_IN_DEVICE, HELLO_OUT_DEVICE, HELLO_LAYOUT_RCL = 1, 2, 4
+
+
+class HelloOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("domain", C.c_int32), ("src0", C.c_int32), ("src1", C.c_int32),
+                ("dst", C.c_int32), ("res", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("lin", C.c_int32),
+                ("lout", C.c_int32), ("flags", C.c_int32), ("seg", C.c_int32), ("c1", C.c_int32),
+                ("a0", C.c_float), ("a1", C.c_float), ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
+class HelloBuffer(C.Structure):
+    _fields_ = [("domain", C.c_int32), ("floats_per_row", C.c_int32)]
+
+
+class HelloModelDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("window", C.c_int32), ("channels0", C.c_int32),
+                ("channels1", C.c_int32), ("n_experts", C.c_int32), ("has_meta", C.c_int32),
+                ("uses_ref", C.c_int32), ("n_buffers", C.c_int32), ("buffers", C.POINTER(HelloBuffer)),
+                ("n_ops", C.c_int32), ("ops", C.POINTER(HelloOp))]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library (built by __graft_entry__.build() / hello_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` (there is no CPU fallback for the scoring path)")
+    try:
+        import torch  # noqa: F401  -- loads the HIP runtime torch ships, which the library then shares
+    except Exception:
+        pass
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+    lib.hello_last_error.restype = C.c_char_p
+    lib.hello_abi_version.restype = C.c_int
+    lib.hello_engine_create.argtypes = [C.POINTER(HelloModelDesc), vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.hello_engine_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, f32p, f32p, i32, vp]
+    lib.hello_engine_posteriors.argtypes = [vp, f32p, f32p, vp, i32, i32, i64, f32p, i32, vp]
+    lib.hello_engine_synchronize.argtypes = [vp]
+    lib.hello_engine_last_forward_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.hello_engine_set_profiling.argtypes = [vp, C.c_int]
+    lib.hello_engine_op_times_ms.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(i32)]
+    lib.hello_engine_destroy.argtypes = [vp]
+    lib.hello_engine_destroy.restype = None
+    for fn in ("hello_engine_create", "hello_engine_forward", "hello_engine_posteriors",
+               "hello_engine_synchronize", "hello_engine_last_forward_ms", "hello_engine_set_profiling",
+               "hello_engine_op_times_ms"):
+        getattr(lib, fn).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"hello_mi355x: {load_library().hello_last_error().decode()} (status {rc})")
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _i32_host(x) -> np.ndarray:
+    if _is_torch(x):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+
+
+def n_pairs(alleles_per_site) -> int:
+    a = np.asarray(alleles_per_site, dtype=np.int64)
+    return int((a * (a + 1) // 2).sum())
+
+
+class Engine:
+    """One compiled model resident on one GPU (one instance per process and device)."""
+
+    def __init__(self, spec: ns.ModelSpec, state, device: int = 0, fused: bool = True):
+        self.lib = load_library()
+        self.spec = spec
+        self.program = compiler.compile_model(spec, state, fused=fused)
+        p = self.program
+        self._ops = (HelloOp * len(p.ops))()
+        for dst, o in zip(self._ops, p.ops):
+            for name, _ in HelloOp._fields_:
+                setattr(dst, name, getattr(o, name))
+        self._bufs = (HelloBuffer * len(p.buffers))()
+        for dst, (dom, fpr) in zip(self._bufs, p.buffers):
+            dst.domain, dst.floats_per_row = dom, fpr
+        desc = HelloModelDesc(1, p.window, p.channels0, p.channels1, p.n_experts, int(p.has_meta),
+                              int(p.uses_ref), len(p.buffers), self._bufs, len(p.ops), self._ops)
+        blob = np.ascontiguousarray(p.weights, dtype=np.float32)
+        handle = C.c_void_p()
+        _check(self.lib.hello_engine_create(C.byref(desc), blob.ctypes.data, blob.nbytes, device,
+                                            C.byref(handle)))
+        self.handle = handle
+        self.device = device
+        self.n_experts = p.n_experts
+        self.has_meta = p.has_meta
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hello_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- batched operator --------------------------------------------------------------------
+    def forward(self, reads0, reads_per_allele0, alleles_per_site, reads1=None, reads_per_allele1=None,
+                ref_onehot=None, stream: Optional[int] = None, layout_rcl: bool = False,
+                out: Optional[Tuple] = None):
+        """reads*: uint8 [R, L, C] NumPy arrays (host path) or torch CUDA tensors (device path; the
+        results are then torch CUDA tensors and the call is asynchronous on ``stream``).
+        Returns (logits [n_experts, A] float32, meta [S, 3] | None)."""
+        rpa0 = _i32_host(reads_per_allele0)
+        aps = _i32_host(alleles_per_site)
+        rpa1 = _i32_host(reads_per_allele1) if reads_per_allele1 is not None else None
+        S, A = int(aps.shape[0]), int(rpa0.shape[0])
+        on_device = _is_torch(reads0) and reads0.is_cuda
+        flags = HELLO_LAYOUT_RCL if layout_rcl else 0
+
+        def prep(x):
+            if x is None:
+                return None, 0, None
+            if on_device:
+                import torch
+                assert x.is_cuda and x.dtype == torch.uint8 and x.is_contiguous()
+                return x, x.data_ptr(), x
+            arr = np.ascontiguousarray(x.cpu().numpy() if _is_torch(x) else x)
+            if arr.dtype != np.uint8:
+                raise TypeError("pileup tensors must be uint8")
+            return arr, arr.ctypes.data, arr
+
+        r0, p0, keep0 = prep(reads0)
+        r1, p1, keep1 = prep(reads1)
+        rf, pf, keepf = prep(ref_onehot)
+        n0 = int(r0.shape[0])
+        n1 = int(r1.shape[0]) if r1 is not None else 0
+        if on_device:
+            import torch
+            flags |= HELLO_IN_DEVICE | HELLO_OUT_DEVICE
+            if out is not None:
+                logits, meta = out
+            else:
+                logits = torch.empty((self.n_experts, A), dtype=torch.float32, device=reads0.device)
+                meta = torch.empty((S, 3), dtype=torch.float32, device=reads0.device) if self.has_meta else None
+            lp = logits.data_ptr()
+            mp = meta.data_ptr() if meta is not None else None
+            if stream is None:
+                stream = torch.cuda.current_stream(reads0.device).cuda_stream
+        else:
+            logits = np.empty((self.n_experts, A), dtype=np.float32)
+            meta = np.empty((S, 3), dtype=np.float32) if self.has_meta else None
+            lp = logits.ctypes.data
+            mp = meta.ctypes.data if meta is not None else None
+        _check(self.lib.hello_engine_forward(
+            self.handle, p0, rpa0.ctypes.data, p1 or None, rpa1.ctypes.data if rpa1 is not None else None,
+            aps.ctypes.data, pf or None, S, A, n0, n1, lp, mp, flags, stream))
+        return logits, meta
+
+    def posteriors(self, logits, meta, alleles_per_site, stream: Optional[int] = None):
+        """Genotype-pair posteriors [4, P] (rows mix, expert0, expert1, expert2) for the logits/meta
+        of a forward; pairs per site in first-seen itertools.product order."""
+        aps = _i32_host(alleles_per_site)
+        S, A = int(aps.shape[0]), int(logits.shape[1])
+        P = n_pairs(aps)
+        on_device = _is_torch(logits) and logits.is_cuda
+        if on_device:
+            import torch
+            out = torch.empty((4, P), dtype=torch.float32, device=logits.device)
+            flags = HELLO_IN_DEVICE | HELLO_OUT_DEVICE
+            lp, mp, op = logits.data_ptr(), (meta.data_ptr() if meta is not None else None), out.data_ptr()
+            if stream is None:
+                stream = torch.cuda.current_stream(logits.device).cuda_stream
+        else:
+            logits = np.ascontiguousarray(logits, dtype=np.float32)
+            meta = np.ascontiguousarray(meta, dtype=np.float32) if meta is not None else None
+            out = np.empty((4, P), dtype=np.float32)
+            flags = 0
+            lp, mp, op = logits.ctypes.data, (meta.ctypes.data if meta is not None else None), out.ctypes.data
+        _check(self.lib.hello_engine_posteriors(self.handle, lp, mp, aps.ctypes.data, S, A, P, op, flags, stream))
+        return out
+
+    def synchronize(self):
+        _check(self.lib.hello_engine_synchronize(self.handle))
+
+    def last_forward_ms(self) -> float:
+        ms = C.c_float()
+        _check(self.lib.hello_engine_last_forward_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def set_profiling(self, enabled: bool):
+        _check(self.lib.hello_engine_set_profiling(self.handle, int(enabled)))
+
+    def op_times_ms(self):
+        n = len(self.program.ops)
+        buf = (C.c_float * n)()
+        got = C.c_int32()
+        _check(self.lib.hello_engine_op_times_ms(self.handle, buf, n, C.byref(got)))
+        return [(compiler.OP_NAMES[o.kind], o.name, float(buf[i])) for i, o in enumerate(self.program.ops[:got.value])]
+
+    def forward_batch(self, batch, **kw):
+        """Convenience over a hello_amd.synth.SiteBatch."""
+        return self.forward(batch.reads0, batch.reads_per_allele0, batch.alleles_per_site, batch.reads1,
+                            batch.reads_per_allele1, batch.ref_onehot if self.program.uses_ref else None, **kw)

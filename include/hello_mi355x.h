@@ -1,0 +1,177 @@
+/* hello_mi355x.h -- C ABI of the MI355X (gfx950) engine for HELLO's variant-scoring hot path.
+ *
+ * The reference has no native interface on this path: the network is a pickled torch module that
+ * python/caller_calling.py:863-868 loads and :651-652 calls per site, and that
+ * python/MixtureOfExpertsDNNFast.py:120-134 calls per batch.  This header is the boundary a
+ * maintainer binds instead (ctypes stub in INTEGRATION.md); each entry point names the reference
+ * interface it stands in for.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative hello_status; it never throws; the message
+ *     for the calling thread's last failure is hello_last_error().
+ *   - pileup tensors are uint8, channels-last [reads][window][channels], exactly what the C++
+ *     featurizer emits (c++/src/AlleleSearcherLiteFiltered.cpp:1045,1172).  HELLO_LAYOUT_RCL accepts
+ *     the training-storage layout [reads][channels][window] (python/MemmapDatasetLoader.py:68-74).
+ *   - count arrays (reads per allele, alleles per site) are ALWAYS host memory (they are tiny and the
+ *     engine builds its CSR offsets from them on the host); the large tensors and the outputs are
+ *     host or device memory according to `flags`.
+ *   - an engine instance is not re-entrant: one instance per (process, device), calls issued from one
+ *     thread at a time, all on the same stream.  With device outputs the call is asynchronous and
+ *     stream-ordered; with host outputs it returns after the results have landed.
+ */
+#ifndef HELLO_MI355X_H
+#define HELLO_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HELLO_ABI_VERSION 1
+
+typedef enum hello_status {
+    HELLO_OK = 0,
+    HELLO_ERR_ARG = -1,      /* NULL / negative / inconsistent argument                      */
+    HELLO_ERR_SHAPE = -2,    /* counts do not add up (sum reads_per_allele != n_reads, ...)  */
+    HELLO_ERR_MODEL = -3,    /* malformed model description                                  */
+    HELLO_ERR_HIP = -4,      /* a HIP runtime call failed                                    */
+    HELLO_ERR_NOGPU = -5     /* no gfx950 device visible                                     */
+} hello_status;
+
+/* ---- model description: a flat program over activation buffers ------------------------------
+ * The Python host (hello_amd/compiler.py) lowers a MoEAttention model
+ * (python/MixtureOfExpertsAdvanced.py:71-252, built from python/NNTools.py:633-657 layer lists) into
+ * this program once, with weight-norm / batch-norm already folded into the weights
+ * (python/NNTools.py:780-799).  Activations are float32, channels-last [rows][length][channels]. */
+
+typedef enum hello_domain {          /* what a buffer's rows are */
+    HELLO_ROWS_READS0 = 0,
+    HELLO_ROWS_READS1 = 1,
+    HELLO_ROWS_ALLELES = 2,
+    HELLO_ROWS_SITES = 3
+} hello_domain;
+
+typedef enum hello_segment {         /* which ragged reduction (reduceSlots, MixtureOfExpertsAdvanced.py:23-34) */
+    HELLO_SEG_READS0_TO_ALLELES = 0,
+    HELLO_SEG_READS1_TO_ALLELES = 1,
+    HELLO_SEG_ALLELES_TO_SITES = 2
+} hello_segment;
+
+/* reserved buffer ids: the caller's inputs */
+#define HELLO_BUF_NONE   (-1)
+#define HELLO_BUF_READS0 0           /* uint8 [R0][L][C0] */
+#define HELLO_BUF_READS1 1           /* uint8 [R1][L][C1] */
+#define HELLO_BUF_REF    2           /* uint8 [S][L][5]  one-hot reference (caller_calling.py:53-97) */
+#define HELLO_BUF_FIRST_SCRATCH 3
+
+typedef enum hello_op_kind {
+    HELLO_OP_CONV1D = 1,     /* Conv1d + bias (+ReLU) (+ residual add after the activation)          */
+    HELLO_OP_MAXPOOL = 2,    /* MaxPool1d(k, stride, pad), floor mode                                 */
+    HELLO_OP_SEGSUM = 3,     /* dst[seg] = sum of src rows of the segment (reduceSlots)               */
+    HELLO_OP_MIX = 4,        /* dst[a] = a0*src0[a] + a1*src1[site(a)]  (xattn_subtract.py:14-42)      */
+    HELLO_OP_HEAD = 5,       /* mean over length, Linear C->cout (terminus, NNTools.py:517-566);      */
+                             /* writes output slot `dst`: 0..2 expert logits, 3 meta (+softmax)       */
+    HELLO_OP_CONCAT = 6,     /* channel concat of src0 (cin ch) and src1 (c1 ch)                      */
+    HELLO_OP_ADD = 7,        /* dst = src0 + src1                                                     */
+    HELLO_OP_READCONV_FUSED = 8 /* whole read convolver + reads->alleles segment sum in one kernel    */
+} hello_op_kind;
+
+#define HELLO_FLAG_RELU     1
+#define HELLO_FLAG_SRC_U8   2        /* src0 is one of the uint8 input buffers                       */
+#define HELLO_FLAG_SOFTMAX  4        /* HEAD: softmax over cout (meta expert, :229-232)              */
+
+typedef struct hello_op {
+    int32_t kind;        /* hello_op_kind */
+    int32_t domain;      /* hello_domain of dst rows */
+    int32_t src0, src1;  /* buffer ids */
+    int32_t dst;         /* buffer id; HEAD: output slot */
+    int32_t res;         /* residual buffer id or HELLO_BUF_NONE */
+    int32_t cin, cout;   /* channels */
+    int32_t k, stride, pad;
+    int32_t lin, lout;   /* positions per row before / after */
+    int32_t flags;
+    int32_t seg;         /* hello_segment (SEGSUM / MIX / READCONV_FUSED) */
+    int32_t c1;          /* CONCAT: channels of src1 */
+    float a0, a1;        /* MIX coefficients */
+    int64_t w_off;       /* float offset of the packed weights in the weight blob */
+    int64_t b_off;       /* float offset of the bias */
+} hello_op;
+
+typedef struct hello_buffer {        /* scratch buffer i (i >= HELLO_BUF_FIRST_SCRATCH) */
+    int32_t domain;                  /* hello_domain: rows scale with the batch */
+    int32_t floats_per_row;          /* max length*channels over all uses */
+} hello_buffer;
+
+typedef struct hello_model_desc {
+    int32_t abi_version;             /* HELLO_ABI_VERSION */
+    int32_t window;                  /* L, 150 for the shipped models (python/call.py:187) */
+    int32_t channels0, channels1;    /* 6 (7 with the haplotag channel); channels1 = 0: single tech */
+    int32_t n_experts;               /* rows of `logits`: 1 (single expert) or 3 (ensemble) */
+    int32_t has_meta;                /* meta mixing weights are produced */
+    int32_t uses_ref;                /* HELLO_BUF_REF is read (meta_convolver_ref models) */
+    int32_t n_buffers;               /* including the 3 reserved ids */
+    const hello_buffer* buffers;     /* [n_buffers]; entries 0..2 ignored */
+    int32_t n_ops;
+    const hello_op* ops;
+} hello_model_desc;
+
+typedef struct hello_engine hello_engine;
+
+/* ---- flags of hello_engine_forward ---------------------------------------------------------- */
+#define HELLO_IN_DEVICE   1          /* reads0 / reads1 / ref_onehot are device pointers             */
+#define HELLO_OUT_DEVICE  2          /* logits / meta / posteriors are device pointers               */
+#define HELLO_LAYOUT_RCL  4          /* reads are [R][C][L] instead of [R][L][C]                     */
+
+/* Stands in for: torch.load(args.network) + network.eval() (caller_calling.py:863-868); the model is
+ * replicated per process like the reference's per-worker copy (call.py:215-221).  `folded_weights`
+ * (host, nbytes) is copied to the device. */
+int hello_engine_create(const hello_model_desc* desc, const void* folded_weights, size_t nbytes,
+                        int hip_device, hello_engine** out);
+
+/* Stands in for: MoEAttention.forward(tensors, numAllelesPerSite, numReadsPerAllele,
+ * reference_segments) (MixtureOfExpertsAdvanced.py:161; batched callers
+ * MixtureOfExpertsDNNFast.py:128-134).
+ *   reads0 [R0][L][C0], reads_per_allele0 [A] (host), reads1/reads_per_allele1 likewise or NULL,
+ *   alleles_per_site [S] (host), ref_onehot [S][L][5] or NULL,
+ *   logits out [n_experts][A], meta out [S][3] or NULL.
+ * Every allele must own >= 1 read (the featurizer inserts an all-zero dummy read,
+ * AlleleSearcherLiteFiltered.cpp:1037-1043); violations are HELLO_ERR_SHAPE. */
+int hello_engine_forward(hello_engine* engine,
+                         const uint8_t* reads0, const int32_t* reads_per_allele0,
+                         const uint8_t* reads1, const int32_t* reads_per_allele1,
+                         const int32_t* alleles_per_site, const uint8_t* ref_onehot,
+                         int32_t n_sites, int32_t n_alleles, int64_t n_reads0, int64_t n_reads1,
+                         float* logits, float* meta, int32_t flags, void* hip_stream);
+
+/* Stands in for: the posterior section of MoEMergedWrapperAdvanced.forward
+ * (MixtureOfExpertsAdvanced.py:530-589): sigmoid, probability of every unordered allele pair in
+ * first-seen itertools.product order, mixture over experts.  n_pairs_total = sum_s A_s(A_s+1)/2.
+ *   logits [n_experts][A] and meta [S][3] as written by hello_engine_forward (meta NULL => [1,0,0]),
+ *   out [4][n_pairs_total]: rows mix, expert0, expert1, expert2.
+ * `flags`: HELLO_IN_DEVICE for logits/meta, HELLO_OUT_DEVICE for out. */
+int hello_engine_posteriors(hello_engine* engine, const float* logits, const float* meta,
+                            const int32_t* alleles_per_site, int32_t n_sites, int32_t n_alleles,
+                            int64_t n_pairs_total, float* out, int32_t flags, void* hip_stream);
+
+/* Wait for everything the engine has enqueued on its last stream. */
+int hello_engine_synchronize(hello_engine* engine);
+
+/* Seconds of device time between the start and end of the most recent forward (HIP events on the
+ * call's stream); negative if unavailable.  Used by bench.py's roofline leg. */
+int hello_engine_last_forward_ms(hello_engine* engine, float* ms);
+
+/* Per-op device time of the most recent forward when profiling was enabled (see below). */
+int hello_engine_set_profiling(hello_engine* engine, int enabled);
+int hello_engine_op_times_ms(hello_engine* engine, float* ms, int32_t capacity, int32_t* n_ops);
+
+void hello_engine_destroy(hello_engine* engine);
+
+const char* hello_last_error(void);
+int hello_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELLO_MI355X_H */

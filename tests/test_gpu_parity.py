@@ -1,0 +1,139 @@
+"""GPU parity: the HIP engine, called through the C ABI, against the golden vectors captured from
+the reference and against the CPU oracle on fresh seeded batches.  Tolerance: the north star asks for
+allele posteriors within 1e-4 of the reference CPU forward; logits are held to 2e-4 absolute
+(sigmoid' <= 1/4 keeps probabilities well inside 1e-4) plus 2e-5 relative."""
+import numpy as np
+import pytest
+
+from hello_amd import netspec as ns, synth, weights
+from tests.util import FIXTURES, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = dict(rtol=2e-5, atol=2e-4)
+PROB_ATOL = 1e-4
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+
+
+@pytest.fixture(scope="module")
+def engines():
+    cache = {}
+    yield cache
+    for e in cache.values():
+        e.close()
+
+
+def get_engine(cache, name, spec, state, fused):
+    from hello_amd.engine import Engine
+    key = (name, fused)
+    if key not in cache:
+        cache[key] = Engine(spec, state, device=0, fused=fused)
+    return cache[key]
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_golden_logits(engines, name, fused):
+    spec, state, batch, exp = load_fixture(name)
+    eng = get_engine(engines, name, spec, state, fused)
+    logits, meta = eng.forward_batch(batch)
+    np.testing.assert_allclose(logits, exp["logits"], **LOGIT_TOL)
+    assert np.abs(sigmoid(logits) - sigmoid(exp["logits"])).max() < PROB_ATOL
+    if "meta" in exp:
+        np.testing.assert_allclose(meta, exp["meta"], rtol=1e-4, atol=PROB_ATOL)
+    else:
+        assert meta is None
+
+
+@pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_full", "hybrid_ensemble2", "hybrid_no_ensemble"])
+def test_golden_posteriors(engines, name):
+    spec, state, batch, exp = load_fixture(name)
+    eng = get_engine(engines, name, spec, state, True)
+    logits, meta = eng.forward_batch(batch)
+    post = eng.posteriors(logits, meta, batch.alleles_per_site)
+    col = 0
+    for s in range(batch.n_sites):
+        n = len(exp[f"site{s}_pairs"])
+        for row, key in enumerate(("mix", "e0", "e1", "e2")):
+            np.testing.assert_allclose(post[row, col:col + n], exp[f"site{s}_{key}"], rtol=2e-4, atol=PROB_ATOL)
+        col += n
+    assert col == post.shape[1]
+
+
+@pytest.mark.parametrize("cfg,kw", [
+    ("single_tech", dict(coverage=30)),
+    ("single_tech_hp", dict(coverage=(20, 80), channels=7, tech="pacbio")),
+    ("hybrid_no_ensemble", dict(coverage=30, hybrid_coverage=15)),
+])
+def test_fresh_batches_match_oracle(engines, cfg, kw):
+    from oracle import moe_oracle as mo
+    spec = ns.build(cfg)
+    state = weights.synth_state(spec, seed=21)
+    batch = synth.make_sites(40, seed=77, **kw)
+    eng = get_engine(engines, "fresh_" + cfg, spec, state, True)
+    logits, _ = eng.forward_batch(batch)
+    want, _ = mo.forward_batch(mo.Oracle(spec, state), batch, chunk_sites=8)
+    np.testing.assert_allclose(logits, want, **LOGIT_TOL)
+
+
+def test_device_pointers_and_determinism(engines):
+    import torch
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=21)
+    batch = synth.make_sites(64, seed=3, coverage=30)
+    eng = get_engine(engines, "fresh_single_tech", spec, state, True)
+    host_logits, _ = eng.forward_batch(batch)
+    r0 = torch.from_numpy(batch.reads0).cuda()
+    a, _ = eng.forward(r0, batch.reads_per_allele0, batch.alleles_per_site)
+    b, _ = eng.forward(r0, batch.reads_per_allele0, batch.alleles_per_site)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)                                      # bit-reproducible run to run
+    np.testing.assert_array_equal(a.cpu().numpy(), host_logits)   # host and device entries agree bit for bit
+
+
+def test_site_independence(engines):
+    """Scores of a site must not depend on what else is in the batch (sites are independent,
+    SURVEY.md 8e): score sites alone and inside a batch, bit for bit."""
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=21)
+    batch = synth.make_sites(12, seed=9, coverage=30)
+    eng = get_engine(engines, "fresh_single_tech", spec, state, True)
+    full, _ = eng.forward_batch(batch)
+    aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
+    for s in (0, 5, 11):
+        one, _ = eng.forward_batch(batch.site_slice(s, s + 1))
+        np.testing.assert_allclose(one[0], full[0, aoff[s]:aoff[s + 1]], rtol=1e-5, atol=1e-5)
+
+
+def test_rcl_layout_flag(engines):
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=21)
+    batch = synth.make_sites(6, seed=4, coverage=20)
+    eng = get_engine(engines, "fresh_single_tech", spec, state, True)
+    a, _ = eng.forward_batch(batch)
+    rcl = np.ascontiguousarray(np.transpose(batch.reads0, (0, 2, 1)))
+    b, _ = eng.forward(rcl, batch.reads_per_allele0, batch.alleles_per_site, layout_rcl=True)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_error_paths(engines):
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=21)
+    batch = synth.make_sites(4, seed=4, coverage=20)
+    eng = get_engine(engines, "fresh_single_tech", spec, state, True)
+    bad = batch.reads_per_allele0.copy()
+    bad[0] += 1
+    with pytest.raises(RuntimeError, match="n_reads"):
+        eng.forward(batch.reads0, bad, batch.alleles_per_site)
+    bad = batch.reads_per_allele0.copy()
+    bad[1] = 0
+    with pytest.raises(RuntimeError, match="dummy"):
+        eng.forward(batch.reads0, bad, batch.alleles_per_site)
+    aps = batch.alleles_per_site.copy()
+    aps[0] += 1
+    with pytest.raises(RuntimeError, match="alleles_per_site"):
+        eng.forward(batch.reads0, batch.reads_per_allele0, aps)
+    eng.forward_batch(batch)      # the engine stays usable after a rejected call
