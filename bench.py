@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: candidate sites/s of the variant-scoring hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): Illumina 30x single-tech model
+(moe_attention_config_single_tech_old_equivalent_weight_norm), synthetic sites from the seeded
+generator, seeded synthetic weights.  One *step* = one forward of the hot path over one batch of
+``--sites`` candidate sites already resident in HBM: uint8 pileups + CSR counts -> allele logits ->
+genotype-pair posteriors, all on the GPU.  ``value`` = sites processed by all ranks / wall time of
+exactly K steps (barrier + synchronize on both sides, max over ranks).  With N > 1 every rank scores
+its own shard of sites (weak scaling, no data-path collective) and the per-rank logits are gathered
+once to rank 0 over RCCL inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+
+def site_flops(spec, batch):
+    """Algorithmic FLOPs of one batch (2 * MAC; dead site-level compressor excluded)."""
+    from hello_amd import netspec as ns
+    per_read = 2 * ns.macs(spec.nets["read_convolver0"], spec.window)
+    per_allele = 2 * (ns.macs(spec.nets["compressor0"], 36) + ns.macs(spec.nets["xattn0"], 18))
+    return per_read * batch.reads0.shape[0] + per_allele * batch.n_alleles, per_read, per_allele
+
+
+def cpu_baseline(spec, state, seed, budget_s=20.0):
+    """Time the CPU oracle (torch-CPU conv back end = the reference's own third-party kernels) on a
+    bounded sample of the same workload, all host cores, batched call form."""
+    import torch
+    from hello_amd import synth
+    from oracle import moe_oracle as mo
+    cores = torch.get_num_threads()
+    oracle = mo.Oracle(spec, state, backend="torch")
+    chunk = 64
+    sample = synth.make_sites(chunk * 16, seed=seed + 999, coverage=30)
+    done, t0 = 0, time.perf_counter()
+    mo.forward_batch(oracle, sample.site_slice(0, 8), chunk_sites=8)      # warm
+    t0 = time.perf_counter()
+    while done < sample.n_sites:
+        mo.forward_batch(oracle, sample.site_slice(done, done + chunk), chunk_sites=chunk)
+        done += chunk
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 2), "unit": "sites/s", "cores": int(cores), "kind": "port",
+            "sample": f"{done} synthetic sites (cov 30), oracle/moe_oracle.py batched in chunks of {chunk}, "
+                      f"torch-CPU conv back end, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sites", type=int, default=8192, help="candidate sites per step per GPU")
+    ap.add_argument("--pool", type=int, default=2, help="distinct resident batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="layer-by-layer read convolver")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--op-times", action="store_true", help="print per-op device times to stderr")
+    args = ap.parse_args()
+
+    import torch
+    from hello_amd import netspec as ns, synth, weights
+    from hello_amd.engine import Engine, n_pairs
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=args.seed)
+    eng = Engine(spec, state, device=local_rank, fused=not args.no_fused)
+
+    # resident pool of synthetic batches (every rank its own sites: shard = rank)
+    pool = []
+    for i in range(args.pool):
+        b = synth.make_sites(args.sites, seed=1000 * (rank + 1) + i + args.seed, coverage=30)
+        pool.append(dict(
+            batch=b, reads=torch.from_numpy(b.reads0).to(dev), rpa=b.reads_per_allele0,
+            aps=b.alleles_per_site, pairs=n_pairs(b.alleles_per_site)))
+    max_a = max(p["batch"].n_alleles for p in pool)
+    max_p = max(p["pairs"] for p in pool)
+    # outputs of every timed step stay on the device until the single gather at the end
+    out_logits = torch.zeros((args.steps, max_a), dtype=torch.float32, device=dev)
+    out_post = torch.zeros((4, max_p), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step(i, record=None):
+        p = pool[i % len(pool)]
+        a = p["batch"].n_alleles
+        lg = out_logits[record if record is not None else 0, :a].view(1, a)
+        eng.forward(p["reads"], p["rpa"], p["aps"], stream=stream,
+                    out=(lg, None, out_post[:, :p["pairs"]]), posteriors=True)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    eng.set_profiling(args.steps)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, record=i)
+    gathered = None
+    if dist is not None:
+        # the one collective of the path: per-rank logits -> rank 0
+        gathered = [torch.empty_like(out_logits) for _ in range(world)] if rank == 0 else None
+        dist.gather(out_logits, gathered, dst=0)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    sites_local = sum(pool[i % len(pool)]["batch"].n_sites for i in range(args.steps))
+    sites_total = sites_local * world
+    value = sites_total / dt
+
+    # ---- roofline of the dominant kernel, from HIP events recorded around every op of the timed steps
+    op_rows, n_fw = eng.op_times_ms()
+    eng.set_profiling(0)
+    if args.op_times and rank == 0:
+        for i, (k, n, ms) in enumerate(op_rows):
+            print(f"  op {i:3d} {k:15s} {ms:9.4f} ms  {n}", file=sys.stderr)
+        print(f"  sum of ops {sum(r[2] for r in op_rows):.3f} ms over {n_fw} forwards", file=sys.stderr)
+    flops_step = np.mean([site_flops(spec, pool[i % len(pool)]["batch"])[0] for i in range(args.steps)])
+    reads_step = np.mean([pool[i % len(pool)]["batch"].reads0.shape[0] for i in range(args.steps)])
+    _, per_read, per_allele = site_flops(spec, pool[0]["batch"])
+    read_ops = [(k, n, ms) for (k, n, ms) in op_rows
+                if k == "readconv_fused" or (k in ("conv1d", "maxpool") and "read_convolver" in n) or k == "maxpool"]
+    fused = eng.program.fused_read_convolver
+    if fused:
+        dom_ms = sum(ms for k, n, ms in op_rows if k == "readconv_fused")
+        dom_name = "readconv_fused_kernel"
+    else:
+        dom_ms = sum(ms for k, n, ms in read_ops)
+        dom_name = "conv1d_mfma_kernel (read-convolver layers, summed per step)"
+    dom_flops = per_read * reads_step
+    achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        "launch_ms": round(dom_ms, 4), "flop_per_launch": float(dom_flops),
+        "whole_step_frac": round(flops_step / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+        "hbm_algorithmic_gbs": round((900.0 * reads_step) / (dt / args.steps) / 1e9, 3),
+    }
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(spec, state, args.seed)
+        b0 = pool[0]["batch"]
+        line = {
+            "metric": "candidate sites/sec (whole node)", "value": round(value, 1), "unit": "sites/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Illumina 30x single-tech model (moe_attention single_tech weight_norm), "
+                                   "synthetic pileups cov 30, seeded synthetic weights",
+                       "sites_per_step_per_gpu": args.sites, "sites_total": sites_total,
+                       "reads_per_site": round(b0.reads0.shape[0] / b0.n_sites, 2),
+                       "alleles_per_site": round(b0.n_alleles / b0.n_sites, 3),
+                       "window": 150, "channels": 6, "parallelism": f"site-sharded dp{world}",
+                       "fused_read_convolver": bool(fused), "outputs": "logits + genotype-pair posteriors"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,8 +97,9 @@ struct hello_engine {
     bool staged_pending = false;
     bool timed = false;
     bool profiling = false;
-    std::vector<hipEvent_t> op_events;
-    int n_timed_ops = 0;
+    // profiling ring: events[f][i] brackets op i of the f-th profiled forward (i = n_ops: end marker)
+    std::vector<std::vector<hipEvent_t>> prof_events;
+    int prof_count = 0;              // forwards recorded since profiling was (re)enabled
 
     // device views into d_csr for the current batch
     int32_t *roff0 = nullptr, *roff1 = nullptr, *aoff = nullptr, *site_of_allele = nullptr;
@@ -210,7 +211,6 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
         }
     }
     e->scratch.resize(desc->n_buffers);
-    e->op_events.resize(desc->n_ops + 1, nullptr);
     hipError_t err = hipMalloc((void**)&e->d_weights, nbytes);
     if (err == hipSuccess) err = hipMemcpy(e->d_weights, folded_weights, nbytes, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -243,8 +243,9 @@ void hello_engine_destroy(hello_engine* e) {
     if (e->ev_staged) (void)hipEventDestroy(e->ev_staged);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
-    for (auto ev : e->op_events)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto& ring : e->prof_events)
+        for (auto ev : ring)
+            if (ev) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -263,23 +264,39 @@ int hello_engine_last_forward_ms(hello_engine* e, float* ms) {
     return HELLO_OK;
 }
 
-int hello_engine_set_profiling(hello_engine* e, int enabled) {
+int hello_engine_set_profiling(hello_engine* e, int max_forwards) {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
-    e->profiling = enabled != 0;
-    if (e->profiling) {
-        for (auto& ev : e->op_events)
+    if (max_forwards < 0 || max_forwards > 4096) return fail(HELLO_ERR_ARG, "max_forwards out of range");
+    HIP_TRY(hipSetDevice(e->device));
+    e->profiling = max_forwards > 0;
+    e->prof_count = 0;
+    if ((int)e->prof_events.size() < max_forwards) e->prof_events.resize(max_forwards);
+    for (int f = 0; f < max_forwards; ++f) {
+        auto& ring = e->prof_events[f];
+        ring.resize(e->ops.size() + 1, nullptr);
+        for (auto& ev : ring)
             if (!ev) HIP_TRY(hipEventCreate(&ev));
     }
     return HELLO_OK;
 }
 
-int hello_engine_op_times_ms(hello_engine* e, float* ms, int32_t capacity, int32_t* n_ops) {
-    if (!e || !ms || !n_ops) return fail(HELLO_ERR_ARG, "NULL argument");
-    if (!e->profiling || e->n_timed_ops == 0) return fail(HELLO_ERR_ARG, "profiling was not enabled for the last forward");
-    const int n = e->n_timed_ops < capacity ? e->n_timed_ops : capacity;
-    HIP_TRY(hipEventSynchronize(e->op_events[e->n_timed_ops]));
-    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], e->op_events[i], e->op_events[i + 1]));
+int hello_engine_op_times_ms(hello_engine* e, float* ms_sum, int32_t capacity, int32_t* n_ops,
+                             int32_t* n_forwards) {
+    if (!e || !ms_sum || !n_ops || !n_forwards) return fail(HELLO_ERR_ARG, "NULL argument");
+    if (e->prof_count == 0) return fail(HELLO_ERR_ARG, "no forward was recorded with profiling enabled");
+    const int n = (int)e->ops.size() < capacity ? (int)e->ops.size() : capacity;
+    for (int i = 0; i < n; ++i) ms_sum[i] = 0.f;
+    for (int f = 0; f < e->prof_count; ++f) {
+        auto& ring = e->prof_events[f];
+        HIP_TRY(hipEventSynchronize(ring[e->ops.size()]));
+        for (int i = 0; i < n; ++i) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, ring[i], ring[i + 1]));
+            ms_sum[i] += t;
+        }
+    }
     *n_ops = n;
+    *n_forwards = e->prof_count;
     return HELLO_OK;
 }
 
@@ -403,7 +420,7 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
 int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* rpa0,
                          const uint8_t* reads1, const int32_t* rpa1, const int32_t* aps,
                          const uint8_t* ref_onehot, int32_t S, int32_t A, int64_t R0, int64_t R1,
-                         float* logits, float* meta, int32_t flags, void* hip_stream) {
+                         float* logits, float* meta, float* posteriors, int32_t flags, void* hip_stream) {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
     const hello_model_desc& d = e->desc;
     const bool two_tech = d.channels1 > 0;
@@ -465,13 +482,22 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     }
     float* d_logits = logits;
     float* d_meta = meta;
+    float* d_post = posteriors;
+    int64_t n_pairs = 0;
+    if (posteriors)
+        for (int32_t s = 0; s < S; ++s) n_pairs += (int64_t)aps[s] * (aps[s] + 1) / 2;
     const size_t logit_bytes = (size_t)d.n_experts * A * sizeof(float), meta_bytes = (size_t)S * 3 * sizeof(float);
+    const size_t post_bytes = (size_t)4 * n_pairs * sizeof(float);
     if (!out_dev) {
         if (int rc = ensure(e->d_logits, logit_bytes)) return rc;
         d_logits = (float*)e->d_logits.p;
         if (d.has_meta) {
             if (int rc = ensure(e->d_meta, meta_bytes)) return rc;
             d_meta = (float*)e->d_meta.p;
+        }
+        if (posteriors) {
+            if (int rc = ensure(e->d_post, post_bytes)) return rc;
+            d_post = (float*)e->d_post.p;
         }
     }
     // fused read convolver partial slots (worst case: one per read + one per group)
@@ -494,8 +520,12 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
 
     HIP_TRY(hipEventRecord(e->ev_start, stream));
     int op_index = 0;
+    std::vector<hipEvent_t>* ring = nullptr;
+    if (e->profiling && e->prof_count < (int)e->prof_events.size() &&
+        e->prof_events[e->prof_count].size() == e->ops.size() + 1)
+        ring = &e->prof_events[e->prof_count];
     for (const hello_op& o : e->ops) {
-        if (e->profiling) HIP_TRY(hipEventRecord(e->op_events[op_index], stream));
+        if (ring) HIP_TRY(hipEventRecord((*ring)[op_index], stream));
         const long long rows = rows_of(o.domain, S, A, R0, R1);
         switch (o.kind) {
             case HELLO_OP_CONV1D: {
@@ -567,18 +597,20 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
         }
         ++op_index;
     }
-    if (e->profiling) {
-        HIP_TRY(hipEventRecord(e->op_events[op_index], stream));
-        e->n_timed_ops = op_index;
-    } else {
-        e->n_timed_ops = 0;
+    if (ring) {
+        HIP_TRY(hipEventRecord((*ring)[op_index], stream));
+        e->prof_count++;
     }
+    if (posteriors)
+        HIP_TRY(hello::launch_posteriors(d_logits, d.n_experts == 3 ? d_meta : nullptr, e->aoff, e->pair_off, S, A,
+                                         d.n_experts, n_pairs, d_post, stream));
     HIP_TRY(hipEventRecord(e->ev_stop, stream));
     e->timed = true;
 
     if (!out_dev) {
         HIP_TRY(hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, stream));
         if (d.has_meta) HIP_TRY(hipMemcpyAsync(meta, d_meta, meta_bytes, hipMemcpyDeviceToHost, stream));
+        if (posteriors) HIP_TRY(hipMemcpyAsync(posteriors, d_post, post_bytes, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
     return HELLO_OK;

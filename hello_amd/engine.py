@@ -59,12 +59,12 @@ def load_library():
     lib.hello_last_error.restype = C.c_char_p
     lib.hello_abi_version.restype = C.c_int
     lib.hello_engine_create.argtypes = [C.POINTER(HelloModelDesc), vp, C.c_size_t, C.c_int, C.POINTER(vp)]
-    lib.hello_engine_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, f32p, f32p, i32, vp]
+    lib.hello_engine_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, f32p, f32p, f32p, i32, vp]
     lib.hello_engine_posteriors.argtypes = [vp, f32p, f32p, vp, i32, i32, i64, f32p, i32, vp]
     lib.hello_engine_synchronize.argtypes = [vp]
     lib.hello_engine_last_forward_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.hello_engine_set_profiling.argtypes = [vp, C.c_int]
-    lib.hello_engine_op_times_ms.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(i32)]
+    lib.hello_engine_op_times_ms.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(i32), C.POINTER(i32)]
     lib.hello_engine_destroy.argtypes = [vp]
     lib.hello_engine_destroy.restype = None
     for fn in ("hello_engine_create", "hello_engine_forward", "hello_engine_posteriors",
@@ -135,10 +135,12 @@ class Engine:
     # -- batched operator --------------------------------------------------------------------
     def forward(self, reads0, reads_per_allele0, alleles_per_site, reads1=None, reads_per_allele1=None,
                 ref_onehot=None, stream: Optional[int] = None, layout_rcl: bool = False,
-                out: Optional[Tuple] = None):
+                out: Optional[Tuple] = None, posteriors: bool = False):
         """reads*: uint8 [R, L, C] NumPy arrays (host path) or torch CUDA tensors (device path; the
         results are then torch CUDA tensors and the call is asynchronous on ``stream``).
-        Returns (logits [n_experts, A] float32, meta [S, 3] | None)."""
+        Returns (logits [n_experts, A] float32, meta [S, 3] | None), plus the pair posteriors
+        [4, P] as a third element when ``posteriors=True``.  ``out`` = preallocated (logits, meta[,
+        posteriors]) device tensors."""
         rpa0 = _i32_host(reads_per_allele0)
         aps = _i32_host(alleles_per_site)
         rpa1 = _i32_host(reads_per_allele1) if reads_per_allele1 is not None else None
@@ -166,23 +168,32 @@ class Engine:
         if on_device:
             import torch
             flags |= HELLO_IN_DEVICE | HELLO_OUT_DEVICE
+            post = None
             if out is not None:
-                logits, meta = out
+                logits, meta = out[0], out[1]
+                post = out[2] if len(out) > 2 else None
             else:
                 logits = torch.empty((self.n_experts, A), dtype=torch.float32, device=reads0.device)
                 meta = torch.empty((S, 3), dtype=torch.float32, device=reads0.device) if self.has_meta else None
+            if posteriors and post is None:
+                post = torch.empty((4, n_pairs(aps)), dtype=torch.float32, device=reads0.device)
             lp = logits.data_ptr()
             mp = meta.data_ptr() if meta is not None else None
+            pp = post.data_ptr() if posteriors else None
             if stream is None:
                 stream = torch.cuda.current_stream(reads0.device).cuda_stream
         else:
             logits = np.empty((self.n_experts, A), dtype=np.float32)
             meta = np.empty((S, 3), dtype=np.float32) if self.has_meta else None
+            post = np.empty((4, n_pairs(aps)), dtype=np.float32) if posteriors else None
             lp = logits.ctypes.data
             mp = meta.ctypes.data if meta is not None else None
+            pp = post.ctypes.data if posteriors else None
         _check(self.lib.hello_engine_forward(
             self.handle, p0, rpa0.ctypes.data, p1 or None, rpa1.ctypes.data if rpa1 is not None else None,
-            aps.ctypes.data, pf or None, S, A, n0, n1, lp, mp, flags, stream))
+            aps.ctypes.data, pf or None, S, A, n0, n1, lp, mp, pp, flags, stream))
+        if posteriors:
+            return logits, meta, post
         return logits, meta
 
     def posteriors(self, logits, meta, alleles_per_site, stream: Optional[int] = None):
@@ -216,15 +227,19 @@ class Engine:
         _check(self.lib.hello_engine_last_forward_ms(self.handle, C.byref(ms)))
         return float(ms.value)
 
-    def set_profiling(self, enabled: bool):
-        _check(self.lib.hello_engine_set_profiling(self.handle, int(enabled)))
+    def set_profiling(self, max_forwards: int):
+        """Arm per-op HIP-event timing for the next ``max_forwards`` forwards (0 disarms)."""
+        _check(self.lib.hello_engine_set_profiling(self.handle, int(max_forwards)))
 
     def op_times_ms(self):
+        """-> (list of (op kind, layer name, mean ms per forward), number of forwards averaged)."""
         n = len(self.program.ops)
         buf = (C.c_float * n)()
-        got = C.c_int32()
-        _check(self.lib.hello_engine_op_times_ms(self.handle, buf, n, C.byref(got)))
-        return [(compiler.OP_NAMES[o.kind], o.name, float(buf[i])) for i, o in enumerate(self.program.ops[:got.value])]
+        got, nf = C.c_int32(), C.c_int32()
+        _check(self.lib.hello_engine_op_times_ms(self.handle, buf, n, C.byref(got), C.byref(nf)))
+        rows = [(compiler.OP_NAMES[o.kind], o.name, float(buf[i]) / max(nf.value, 1))
+                for i, o in enumerate(self.program.ops[:got.value])]
+        return rows, int(nf.value)
 
     def forward_batch(self, batch, **kw):
         """Convenience over a hello_amd.synth.SiteBatch."""

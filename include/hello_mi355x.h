@@ -135,7 +135,9 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
  * MixtureOfExpertsDNNFast.py:128-134).
  *   reads0 [R0][L][C0], reads_per_allele0 [A] (host), reads1/reads_per_allele1 likewise or NULL,
  *   alleles_per_site [S] (host), ref_onehot [S][L][5] or NULL,
- *   logits out [n_experts][A], meta out [S][3] or NULL.
+ *   logits out [n_experts][A], meta out [S][3] or NULL,
+ *   posteriors out [4][sum_s A_s(A_s+1)/2] or NULL: the wrapper's pair posteriors (see
+ *   hello_engine_posteriors) computed in the same stream-ordered call.
  * Every allele must own >= 1 read (the featurizer inserts an all-zero dummy read,
  * AlleleSearcherLiteFiltered.cpp:1037-1043); violations are HELLO_ERR_SHAPE. */
 int hello_engine_forward(hello_engine* engine,
@@ -143,7 +145,7 @@ int hello_engine_forward(hello_engine* engine,
                          const uint8_t* reads1, const int32_t* reads_per_allele1,
                          const int32_t* alleles_per_site, const uint8_t* ref_onehot,
                          int32_t n_sites, int32_t n_alleles, int64_t n_reads0, int64_t n_reads1,
-                         float* logits, float* meta, int32_t flags, void* hip_stream);
+                         float* logits, float* meta, float* posteriors, int32_t flags, void* hip_stream);
 
 /* Stands in for: the posterior section of MoEMergedWrapperAdvanced.forward
  * (MixtureOfExpertsAdvanced.py:530-589): sigmoid, probability of every unordered allele pair in
@@ -162,9 +164,12 @@ int hello_engine_synchronize(hello_engine* engine);
  * call's stream); negative if unavailable.  Used by bench.py's roofline leg. */
 int hello_engine_last_forward_ms(hello_engine* engine, float* ms);
 
-/* Per-op device time of the most recent forward when profiling was enabled (see below). */
-int hello_engine_set_profiling(hello_engine* engine, int enabled);
-int hello_engine_op_times_ms(hello_engine* engine, float* ms, int32_t capacity, int32_t* n_ops);
+/* Per-op device time (HIP events on the call's stream around every op).  set_profiling(n > 0)
+ * arms recording for the next n forwards; op_times_ms returns, per op, the SUM over the forwards
+ * recorded since then and their number.  set_profiling(0) disarms. */
+int hello_engine_set_profiling(hello_engine* engine, int max_forwards);
+int hello_engine_op_times_ms(hello_engine* engine, float* ms_sum, int32_t capacity, int32_t* n_ops,
+                             int32_t* n_forwards);
 
 void hello_engine_destroy(hello_engine* engine);
 
