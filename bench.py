@@ -153,17 +153,22 @@ def main():
         print(f"  sum of ops {sum(r[2] for r in op_rows):.3f} ms over {n_fw} forwards", file=sys.stderr)
     flops_step = np.mean([site_flops(spec, pool[i % len(pool)]["batch"])[0] for i in range(args.steps)])
     reads_step = np.mean([pool[i % len(pool)]["batch"].reads0.shape[0] for i in range(args.steps)])
-    _, per_read, per_allele = site_flops(spec, pool[0]["batch"])
-    read_ops = [(k, n, ms) for (k, n, ms) in op_rows
-                if k == "readconv_fused" or (k in ("conv1d", "maxpool") and "read_convolver" in n) or k == "maxpool"]
+    alleles_step = np.mean([pool[i % len(pool)]["batch"].n_alleles for i in range(args.steps)])
+    rows_of = {0: reads_step, 1: 0.0, 2: alleles_step, 3: float(args.sites)}
     fused = eng.program.fused_read_convolver
-    if fused:
-        dom_ms = sum(ms for k, n, ms in op_rows if k == "readconv_fused")
-        dom_name = "readconv_fused_kernel"
-    else:
-        dom_ms = sum(ms for k, n, ms in read_ops)
-        dom_name = "conv1d_mfma_kernel (read-convolver layers, summed per step)"
-    dom_flops = per_read * reads_step
+    # group the per-op event times by the kernel that ran them; algorithmic FLOPs = 2 * MAC of the op
+    kernels = {}
+    for op, (k, n, ms) in zip(eng.program.ops, op_rows):
+        kname = {"conv1d": "conv1d_mfma_kernel", "readconv_fused": "readconv_trunk_kernel"}.get(k, k + "_kernel")
+        ent = kernels.setdefault(kname, dict(ms=0.0, flops=0.0, launches=0))
+        ent["ms"] += ms
+        rows = reads_step if k == "readconv_fused" else rows_of[op.domain]   # the trunk's MACs are per read
+        ent["flops"] += 2.0 * op.macs_per_row * rows
+        ent["launches"] += 1
+    dom_name = max(kernels, key=lambda kk: kernels[kk]["ms"])
+    dom = kernels[dom_name]
+    dom_ms = dom["ms"] / dom["launches"]                 # average launch duration
+    dom_flops = dom["flops"] / dom["launches"]           # algorithmic FLOPs per launch
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -175,7 +180,8 @@ def main():
     roofline = {
         "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-        "launch_ms": round(dom_ms, 4), "flop_per_launch": float(dom_flops),
+        "launch_ms": round(dom_ms, 4), "flop_per_launch": float(dom_flops), "launches_per_step": dom["launches"],
+        "kernels_ms_per_step": {kk: round(v["ms"], 4) for kk, v in sorted(kernels.items(), key=lambda x: -x[1]["ms"])},
         "whole_step_frac": round(flops_step / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
         "hbm_algorithmic_gbs": round((900.0 * reads_step) / (dt / args.steps) / 1e9, 3),
     }

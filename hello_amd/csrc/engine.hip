@@ -582,13 +582,14 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
             case HELLO_OP_READCONV_FUSED: {
                 const bool t1 = o.seg == HELLO_SEG_READS1_TO_ALLELES;
                 hello::ReadConvArgs a{};
-                a.reads = (const uint8_t*)ptr(o.src0);
+                a.pooled = (const float*)ptr(o.src0);
                 a.w = e->d_weights + o.w_off;
                 a.partial = (float*)e->d_partial.p;
                 a.allele_of_read = t1 ? e->allele_of_read1 : e->allele_of_read0;
                 a.slot_of_group = t1 ? e->group_slot1 : e->group_slot0;
                 a.n_reads = t1 ? R1 : R0;
-                a.channels = o.cin;
+                if ((size_t)o.w_off + hello::readconv_weight_floats() > e->n_weight_floats)
+                    return fail(HELLO_ERR_MODEL, "op %d: fused read-convolver weight block truncated", op_index);
                 HIP_TRY(hello::launch_readconv_fused(a, stream));
                 HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,
                                                         (float*)ptr(o.dst), A, stream));

@@ -54,15 +54,15 @@ hipError_t launch_posteriors(const float* logits, const float* meta, const int32
 
 // ---- fused read convolver (readconv_fused.hip) ------------------------------------------------
 struct ReadConvArgs {
-    const uint8_t* reads;      // [R][150][C]
-    const float* w;            // packed block, see compiler.pack_readconv
-    float* partial;            // [n_groups * reads_per_group][36][64] worst case; slot-compacted
+    const float* pooled;       // [R][71][32] output of the stem (3 valid convs + MaxPool1d(3,2))
+    const float* w;            // packed block, see hello_amd/readconv_pack.py
+    float* partial;            // [n_slots][36][64]: one slot per (read group, allele) incidence
     const int32_t* allele_of_read;   // [R]
     const int32_t* slot_of_group;    // [n_groups + 1] first partial slot of each read group
     long long n_reads;
-    int channels;
 };
 int readconv_reads_per_group();
+int readconv_weight_floats();
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
 // frames[a] = sum of the partial slots of allele a, in slot order
 hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames,

@@ -1,7 +1,302 @@
-// placeholder until the fused read convolver lands
+// Fused residual trunk of the read convolver + reads->alleles segment sum (gfx950).
+//
+// Reference semantics: architectures/read_convolver.py:58-143 (3 x ResidualBlock(32), the strided
+// 32->64 block with its 1x1 shortcut, 3 x ResidualBlock(64)) followed by reduceSlots over the reads of
+// each allele (MixtureOfExpertsAdvanced.py:23-34,163).  That is 92.6 % of the read convolver's
+// multiply-accumulates (4 700 160 of 5 076 096 per read) and 77 % of a 30x site's.
+//
+// One workgroup (512 threads = 8 waves = 2 per SIMD) carries G = 8 reads through all 15 convolutions
+// with every activation resident in LDS; nothing but the pooled stem output is read and nothing but
+// per-allele partial sums is written.
+//
+//   LDS     two ping-pong images (2 x 78 336 B of the CU's 160 KiB), float32 channels-last
+//           [row][channel]; the reads of the group are stacked along the row axis with ONE shared
+//           zero row between neighbours (row stride 72 at 71 positions, 37 at 36), so the k=3/pad=1
+//           convolutions need no edge handling: the pad row is written as zero by every epilogue.
+//           16-byte chunks of a row are XOR-swizzled with the row index, which keeps both the
+//           ds_read_b128 operand reads (16 rows x one chunk column) and the ds_write_b128 epilogue
+//           stores off each other's banks without padding the rows.
+//   MFMA    v_mfma_f32_16x16x4_f32 (exact fp32), D[channel][position] = W[channel][k] X[k][position]:
+//           a wave owns one 16-channel block and walks 16-position tiles, two tiles in flight so the
+//           40-cycle dependent latency of the 32-cycle instruction is covered.  Lane (j, q) of a tile
+//           ends with channels 4q..4q+3 of position j -> bias / ReLU / residual / store are float4.
+//           k is ordered so that lane-quarter q supplies channels 16m+4q+t at step (tap, m, t) for
+//           BOTH operands: one ds_read_b128 feeds four MFMAs.
+//   weights each wave keeps ONLY its own 16-channel slice of the layer in registers (<= 48 VGPRs),
+//           loaded straight from L2 in lane order (pre-packed by hello_amd/readconv_pack.py); the next
+//           layer's slice is requested before the current layer's MFMAs start.
+//   sum     reads of an allele are contiguous, so the group adds its reads per allele in order and
+//           writes one partial [36][64] slot per (group, allele) incidence; a tiny finalize kernel adds
+//           an allele's slots in order.  No atomics: results are bit-reproducible.
 #include "kernels.h"
+
 namespace hello {
-int readconv_reads_per_group() { return 8; }
-hipError_t launch_readconv_fused(const ReadConvArgs&, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_readconv_finalize(const float*, const int32_t*, float*, int, hipStream_t) { return hipErrorNotSupported; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace rc {
+constexpr int G = 8;                 // reads per workgroup
+constexpr int NW = 8;                // waves per workgroup
+constexpr int L1 = 71, RS1 = 72;     // positions / row stride per read at 32 channels
+constexpr int L2 = 36, RS2 = 37;     // ... at 64 channels
+constexpr int T1 = (RS1 * G + 15) / 16;   // 36 position tiles
+constexpr int T2 = (RS2 * G + 15) / 16;   // 19
+constexpr int BUF_FLOATS = (T2 * 16 + 2) * 64;   // 19 584 floats; the 32-channel image needs 18 496
+constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4 + 64;   // + allele ids of the group
+
+// packed weight block (floats): per conv [COUT/16][KT][CIN/16][64 lanes][4], then bias [COUT]
+constexpr int W3232 = 2 * 3 * 2 * 256, W3264 = 4 * 3 * 2 * 256, W3264S = 4 * 1 * 2 * 256, W6464 = 4 * 3 * 4 * 256;
+constexpr int OFF_B = 0;                                   // 6 convs 32->32
+constexpr int OFF_C1 = OFF_B + 6 * (W3232 + 32);           // 32->64 k3 s2
+constexpr int OFF_SC = OFF_C1 + W3264 + 64;                // 32->64 k1 s2
+constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3
+constexpr int OFF_D = OFF_C2 + W6464 + 64;                 // 6 convs 64->64
+constexpr int W_TOTAL = OFF_D + 6 * (W6464 + 64);
+}  // namespace rc
+
+int readconv_reads_per_group() { return rc::G; }
+int readconv_weight_floats() { return rc::W_TOTAL; }
+
+template <int C>
+__device__ __forceinline__ int swz(int row) {
+    return C == 64 ? (row & 15) : ((row >> 1) & 7);
 }
+
+template <int NV>
+__device__ __forceinline__ void load_weights(f32x4 (&w)[NV], const float* __restrict__ base, int cb, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) w[i] = *(const f32x4*)(base + ((cb * NV + i) * 64 + lane) * 4);
+}
+
+enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3 };
+
+// One convolution over the whole group.  `in`/`out` are LDS images with CIN / COUT floats per row.
+template <int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE>
+__device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* __restrict__ out,
+                                           const f32x4 (&w)[KT * CIN / 16], const float* __restrict__ bias,
+                                           f32x4 (&sreg)[(rc::T2 + 1) / 2], int wave, int lane) {
+    constexpr int M = CIN / 16, NCB = COUT / 16, NPG = rc::NW / NCB, ITER = (T + NPG - 1) / NPG;
+    const int cb = wave % NCB, pg = wave / NCB;
+    const int j = lane & 15, q = lane >> 4;
+    const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
+
+    auto in_row = [&](int t) {
+        const int r = t * 16 + j;
+        const int rd = r / RS_OUT;
+        return 1 + rd * RS_IN + (r - rd * RS_OUT) * STRIDE - PAD;
+    };
+    auto finish = [&](int t, f32x4 acc, f32x4& keep) {
+        const int r = t * 16 + j;
+        const int rd = r / RS_OUT;
+        const int p = r - rd * RS_OUT;
+        f32x4 v;
+        if (MODE == MODE_TO_REGS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[e] + b4[e];
+            keep = v;
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[e] + b4[e], 0.f);
+        const int row = r + 1;
+        float* dst = out + row * COUT + 4 * ((4 * cb + q) ^ swz<COUT>(row));
+        if (MODE == MODE_RESID_INPLACE) {
+            const f32x4 x = *(const f32x4*)dst;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += x[e];
+        }
+        if (MODE == MODE_ADD_REGS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += keep[e];
+        }
+        if (p >= LOUT) v = f32x4{0.f, 0.f, 0.f, 0.f};          // the shared zero row between reads
+        if (r < RS_OUT * rc::G) *(f32x4*)dst = v;
+    };
+
+#pragma unroll
+    for (int i = 0; i < ITER; i += 2) {
+        const int t0 = pg + NPG * i, t1 = pg + NPG * (i + 1);
+        if (t0 >= T) break;
+        const bool two = (i + 1 < ITER) && (t1 < T);
+        if (two) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            const int r0 = in_row(t0), r1 = in_row(t1);
+#pragma unroll
+            for (int tap = 0; tap < KT; ++tap) {
+                const float* p0 = in + (r0 + tap) * CIN;
+                const float* p1 = in + (r1 + tap) * CIN;
+                const int s0 = swz<CIN>(r0 + tap), s1 = swz<CIN>(r1 + tap);
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const f32x4 x0 = *(const f32x4*)(p0 + 4 * ((4 * m + q) ^ s0));
+                    const f32x4 x1 = *(const f32x4*)(p1 + 4 * ((4 * m + q) ^ s1));
+                    const f32x4 ww = w[tap * M + m];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[e], x0[e], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[e], x1[e], a1, 0, 0, 0);
+                    }
+                }
+            }
+            finish(t0, a0, sreg[i < (rc::T2 + 1) / 2 ? i : 0]);
+            finish(t1, a1, sreg[i + 1 < (rc::T2 + 1) / 2 ? i + 1 : 0]);
+        } else {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
+            const int r0 = in_row(t0);
+#pragma unroll
+            for (int tap = 0; tap < KT; ++tap) {
+                const float* p0 = in + (r0 + tap) * CIN;
+                const int s0 = swz<CIN>(r0 + tap);
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const f32x4 x0 = *(const f32x4*)(p0 + 4 * ((4 * m + q) ^ s0));
+                    const f32x4 ww = w[tap * M + m];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[e], x0[e], a0, 0, 0, 0);
+                }
+            }
+            finish(t0, a0, sreg[i < (rc::T2 + 1) / 2 ? i : 0]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
+    using namespace rc;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* bufA = smem;
+    float* bufB = smem + BUF_FLOATS;
+    int* s_allele = (int*)(smem + 2 * BUF_FLOATS);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const long long read0 = (long long)blockIdx.x * G;
+    const int n_here = (int)((a.n_reads - read0) < G ? (a.n_reads - read0) : G);
+    const float* __restrict__ W = a.w;
+
+    // ---- stage the group's pooled stem output [71][32] per read into bufA; everything else zero ----
+    for (int i = tid; i < BUF_FLOATS / 4; i += 512) ((f32x4*)bufA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
+    __syncthreads();
+    {
+        const f32x4* src = (const f32x4*)(a.pooled + read0 * (L1 * 32));
+        const int n4 = n_here * L1 * 8;
+        for (int f = tid; f < n4; f += 512) {
+            const int rd = f / (L1 * 8);
+            const int rem = f - rd * (L1 * 8);
+            const int p = rem >> 3, c = rem & 7;
+            const int row = 1 + rd * RS1 + p;
+            *(f32x4*)(bufA + row * 32 + 4 * (c ^ swz<32>(row))) = src[f];
+        }
+    }
+
+    f32x4 wa[6], wb[6];
+    f32x4 wc[12], wd[12];
+    f32x4 wsc[2];
+    f32x4 sreg[(T2 + 1) / 2];
+
+    // ---- 3 x ResidualBlock(32): x -> relu(conv) -> relu(conv) + x --------------------------------
+    load_weights<6>(wa, W + OFF_B, wave % 2, lane);
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+        const float* base = W + OFF_B + (2 * blk) * (W3232 + 32);
+        load_weights<6>(wb, base + (W3232 + 32), wave % 2, lane);
+        conv_layer<32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN>(bufA, bufB, wa, base + W3232, sreg, wave, lane);
+        __syncthreads();
+        if (blk < 2) load_weights<6>(wa, base + 2 * (W3232 + 32), wave % 2, lane);
+        conv_layer<32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_RESID_INPLACE>(bufB, bufA, wb, base + (W3232 + 32) + W3232,
+                                                                          sreg, wave, lane);
+        __syncthreads();
+    }
+
+    // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
+    load_weights<6>(wa, W + OFF_C1, wave % 4, lane);
+    load_weights<2>(wsc, W + OFF_SC, wave % 4, lane);
+    load_weights<12>(wc, W + OFF_C2, wave % 4, lane);
+    if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};     // zero row 0 of the 64-channel image
+    conv_layer<32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN>(bufA, bufB, wa, W + OFF_C1 + W3264, sreg, wave, lane);
+    conv_layer<32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS>(bufA, nullptr, wsc, W + OFF_SC + W3264S, sreg, wave, lane);
+    __syncthreads();
+    if (tid < 16) ((f32x4*)bufA)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_weights<12>(wd, W + OFF_D, wave % 4, lane);
+    conv_layer<64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS>(bufB, bufA, wc, W + OFF_C2 + W6464, sreg, wave, lane);
+    __syncthreads();
+
+    // ---- 3 x ResidualBlock(64) --------------------------------------------------------------------
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+        const float* base = W + OFF_D + (2 * blk) * (W6464 + 64);
+        load_weights<12>(wc, base + (W6464 + 64), wave % 4, lane);
+        conv_layer<64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN>(bufA, bufB, wd, base + W6464, sreg, wave, lane);
+        __syncthreads();
+        if (blk < 2) load_weights<12>(wd, base + 2 * (W6464 + 64), wave % 4, lane);
+        conv_layer<64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE>(bufB, bufA, wc, base + (W6464 + 64) + W6464,
+                                                                          sreg, wave, lane);
+        __syncthreads();
+    }
+
+    // ---- per-allele sums of the group's reads, in read order; one slot per (group, allele) ---------
+    {
+        const int slot0 = a.slot_of_group[blockIdx.x];
+        const int first_allele = s_allele[0];
+        for (int f = tid; f < L2 * 16; f += 512) {
+            const int p = f >> 4, c = f & 15;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            int cur = first_allele;
+            for (int rd = 0; rd < n_here; ++rd) {
+                const int al = s_allele[rd];
+                if (al != cur) {
+                    *(f32x4*)(a.partial + ((long long)(slot0 + cur - first_allele) * L2 + p) * 64 + 4 * c) = acc;
+                    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    cur = al;
+                }
+                const int row = 1 + rd * RS2 + p;
+                const f32x4 v = *(const f32x4*)(bufA + row * 64 + 4 * (c ^ swz<64>(row)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[e];
+            }
+            *(f32x4*)(a.partial + ((long long)(slot0 + cur - first_allele) * L2 + p) * 64 + 4 * c) = acc;
+        }
+    }
+}
+
+hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
+    if (a.n_reads <= 0) return hipSuccess;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)readconv_trunk_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, rc::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const unsigned groups = (unsigned)((a.n_reads + rc::G - 1) / rc::G);
+    hipLaunchKernelGGL(readconv_trunk_kernel, dim3(groups), dim3(512), rc::LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+// frames[a] = sum over the allele's partial slots, in slot (= read) order
+__global__ void readconv_finalize_kernel(const float* __restrict__ partial, const int32_t* __restrict__ slot_off,
+                                         float* __restrict__ frames) {
+    const int al = blockIdx.x;
+    const int lo = slot_off[al], hi = slot_off[al + 1];
+    for (int f = threadIdx.x; f < rc::L2 * 16; f += blockDim.x) {
+        f32x4 acc = *(const f32x4*)(partial + ((long long)lo * rc::L2 * 16 + f) * 4);
+        for (int s = lo + 1; s < hi; ++s) {
+            const f32x4 v = *(const f32x4*)(partial + ((long long)s * rc::L2 * 16 + f) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        }
+        *(f32x4*)(frames + ((long long)al * rc::L2 * 16 + f) * 4) = acc;
+    }
+}
+
+hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames, int n_alleles,
+                                    hipStream_t stream) {
+    if (n_alleles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(readconv_finalize_kernel, dim3(n_alleles), dim3(192), 0, stream, partial, slot_off, frames);
+    return hipGetLastError();
+}
+
+}  // namespace hello

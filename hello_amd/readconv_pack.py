@@ -1,6 +1,49 @@
-"""Weight packing for the fused read-convolver kernel (hello_amd/csrc/readconv_fused.hip)."""
-AVAILABLE = False
+"""Weight packing for the fused read-convolver trunk kernel (hello_amd/csrc/readconv_fused.hip).
+
+The kernel covers the residual part of the canonical read convolver (reference
+architectures/read_convolver.py:58-143): 3 x ResidualBlock(32), the strided 32->64 block with its 1x1
+shortcut, 3 x ResidualBlock(64).  Each wave owns one 16-channel output block and keeps that slice of a
+layer in registers as the A operand of v_mfma_f32_16x16x4_f32, so the blob is laid out in exactly the
+order the lanes load it:
+
+    per conv:  [cout/16 blocks][k taps][cin/16 groups][64 lanes][4 floats], then bias[cout]
+    lane l, float t  =  W[out = 16*block + (l & 15)][in = 16*group + 4*(l >> 4) + t][tap]
+"""
+import numpy as np
+
+from . import netspec as ns
+
+AVAILABLE = True
+TRUNK_FIRST_NODE = 4          # nodes[0:4] = the stem (3 valid convs + max pool), run layer by layer
 
 
-def pack(nodes, folded, cin):
-    raise NotImplementedError
+def _pack_conv(w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    cout, cin, k = w.shape
+    lanes = np.arange(64)
+    out_idx = (np.arange(cout // 16)[:, None] * 16 + (lanes & 15)[None, :])                    # [cb, lane]
+    in_idx = (np.arange(cin // 16)[:, None, None] * 16 + 4 * (lanes >> 4)[None, :, None]
+              + np.arange(4)[None, None, :])                                                  # [m, lane, t]
+    # result[cb, tap, m, lane, t]
+    packed = w[out_idx[:, None, None, :, None], in_idx[None, None, :, :, :], np.arange(k)[None, :, None, None, None]]
+    return np.concatenate([packed.astype(np.float32).ravel(), b.astype(np.float32).ravel()])
+
+
+def trunk_convs(nodes):
+    """The 15 convolutions in kernel order."""
+    blocks = nodes[TRUNK_FIRST_NODE:]
+    assert len(blocks) == 7 and all(isinstance(b, ns.Residual) for b in blocks)
+    order = []
+    for blk in blocks[:3]:
+        order += [blk.body[0], blk.body[1]]
+    strided = blocks[3]
+    order += [strided.body[0], strided.shortcut[0], strided.body[1]]
+    for blk in blocks[4:]:
+        order += [blk.body[0], blk.body[1]]
+    return order
+
+
+def pack(nodes, folded, cin=None) -> np.ndarray:
+    parts = [_pack_conv(*folded[c.key]) for c in trunk_convs(nodes)]
+    blob = np.concatenate(parts)
+    assert blob.size == 6 * (3072 + 32) + (6144 + 64) + (2048 + 64) + (12288 + 64) + 6 * (12288 + 64), blob.size
+    return blob
