@@ -1,0 +1,232 @@
+"""Model-loader surface: ``load(path)`` stands in for ``torch.load(args.network, map_location='cpu')``
+of the reference caller (reference python/caller_calling.py:863-868).
+
+Two on-disk formats are accepted:
+
+  * the reference's ``*.wrapper.dnn`` -- ``torch.save`` of a whole ``MoEMergedWrapperAdvanced`` module
+    (reference python/create_model_wrapper.py:7-10).  The pickle names classes from the reference's
+    ``MixtureOfExpertsAdvanced`` and ``NNTools`` modules; this loader supplies inert stand-in classes
+    under those module names while unpickling, so NO reference source has to be importable, then reads
+    the architecture off the module tree and the weights off ``state_dict()``;
+  * the build's native file -- an ``.npz`` holding the state dict and the name of one of
+    ``hello_amd.netspec.CONFIGS`` (``save_native``).
+
+Unpickling executes pickle opcodes: only load model files you trust (same caveat as the reference's
+own ``torch.load``; torch >= 2.6 needs ``weights_only=False`` for whole-module pickles).
+"""
+from __future__ import annotations
+
+import contextlib
+import json
+import sys
+import types
+import zipfile
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import netspec as ns
+
+_NATIVE_KEY = "__hello_config__"
+
+
+# --------------------------------------------------------------------------------------------
+# native format
+# --------------------------------------------------------------------------------------------
+def save_native(path: str, config: str, state: Dict[str, np.ndarray], **config_kwargs) -> None:
+    payload = {k: np.asarray(v) for k, v in state.items()}
+    payload[_NATIVE_KEY] = np.array(json.dumps({"config": config, "kwargs": config_kwargs}))
+    with open(path, "wb") as fh:
+        np.savez(fh, **payload)
+
+
+def _load_native(path: str) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:
+    with np.load(path, allow_pickle=False) as z:
+        meta = json.loads(str(z[_NATIVE_KEY]))
+        state = {k: z[k] for k in z.files if k != _NATIVE_KEY}
+    return ns.build(meta["config"], **meta.get("kwargs", {})), state
+
+
+def _is_native(path: str) -> bool:
+    try:
+        with zipfile.ZipFile(path) as zf:
+            return _NATIVE_KEY + ".npy" in zf.namelist()
+    except zipfile.BadZipFile:
+        return False
+
+
+# --------------------------------------------------------------------------------------------
+# reference pickles: inert stand-ins for the classes the pickle names
+# --------------------------------------------------------------------------------------------
+_NNTOOLS_CLASSES = ["Network", "ResidualBlock", "Noop", "Flatten", "GlobalPool", "Inception", "Pad1d",
+                    "Compressor", "DotProduct", "ConcatenateChannels", "AdditiveLayer", "SelectArgument",
+                    "Fork", "LinearCombination", "WeightNormedLinear", "WeightNormedConv1d",
+                    "LayerNormModule", "Transposer"]
+_MOE_CLASSES = ["MoEAttention", "MoEMergedAdvanced", "MoEMergedWrapperAdvanced", "ConvCombiner",
+                "DummyGraphNetwork"]
+
+
+@contextlib.contextmanager
+def _stand_in_modules():
+    import torch
+
+    def make(modname, names):
+        mod = types.ModuleType(modname)
+        for n in names:
+            setattr(mod, n, type(n, (torch.nn.Module,), {"__module__": modname}))
+        return mod
+
+    saved = {k: sys.modules.get(k) for k in ("NNTools", "MixtureOfExpertsAdvanced")}
+    sys.modules["NNTools"] = make("NNTools", _NNTOOLS_CLASSES)
+    sys.modules["MixtureOfExpertsAdvanced"] = make("MixtureOfExpertsAdvanced", _MOE_CLASSES)
+    try:
+        yield
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def _cls(m) -> str:
+    return type(m).__name__
+
+
+def _children(seq) -> List:
+    return list(seq._modules.values())
+
+
+def _conv_node(prefix, idx, layers, pos):
+    """layers[pos] is a conv (weight-normed wrapper or plain Conv1d); consume an optional norm and
+    activation that follow.  Returns (node, slots consumed)."""
+    layer = layers[pos]
+    wn = _cls(layer) == "WeightNormedConv1d"
+    conv = layer._modules["conv1d"] if wn else layer
+    key = f"{prefix}.{idx}.conv1d" if wn else f"{prefix}.{idx}"
+    used, norm, bn_key, act = 1, ("wn" if wn else "none"), None, "none"
+    while pos + used < len(layers):
+        nxt = _cls(layers[pos + used])
+        if nxt == "BatchNorm1d" and norm != "bn" and act == "none":
+            if wn:
+                raise NotImplementedError("BatchNorm after a weight-normed conv")
+            norm, bn_key = "bn", f"{prefix}.{idx + used}"
+        elif nxt == "Noop" and act == "none":
+            pass
+        elif nxt == "ReLU" and act == "none":
+            act = "relu"
+        elif nxt == "Softplus" and act == "none":
+            act = "softplus"
+        else:
+            break
+        used += 1
+        if act != "none":
+            break
+    (k,), (s,), (p,), (d,) = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+    return ns.Conv(key, conv.in_channels, conv.out_channels, k, s, p, d, conv.groups, norm, bn_key, act), used
+
+
+def _convert(network, prefix: str) -> List[ns.Node]:
+    """A pickled ``NNTools.Network`` (its ``.network`` Sequential) -> node list."""
+    layers = _children(network._modules["network"])
+    prefix = prefix + ".network"
+    nodes: List[ns.Node] = []
+    pos = 0
+    while pos < len(layers):
+        layer, name = layers[pos], _cls(layers[pos])
+        if name in ("WeightNormedConv1d", "Conv1d"):
+            node, used = _conv_node(prefix, pos, layers, pos)
+            nodes.append(node)
+            pos += used
+        elif name == "MaxPool1d":
+            k = layer.kernel_size if isinstance(layer.kernel_size, int) else layer.kernel_size[0]
+            s = layer.stride if isinstance(layer.stride, int) else layer.stride[0]
+            p = layer.padding if isinstance(layer.padding, int) else layer.padding[0]
+            nodes.append(ns.MaxPool(k, s, p))
+            pos += 1
+        elif name == "ResidualBlock":
+            body = _convert(layer._modules["ffNetwork"], f"{prefix}.{pos}.ffNetwork")
+            shortcut = _convert(layer._modules["shNetwork"], f"{prefix}.{pos}.shNetwork")
+            nodes.append(ns.Residual(body, shortcut))
+            pos += 1
+        elif name == "AdaptiveAvgPool1d":
+            # terminus: AdaptiveAvgPool1d(1), Flatten, norm|Noop|Dropout, Linear
+            if [_cls(x) for x in layers[pos:pos + 2]] != ["AdaptiveAvgPool1d", "Flatten"] or pos + 3 >= len(layers):
+                raise NotImplementedError("unsupported pooling head")
+            mid, lin = layers[pos + 2], layers[pos + 3]
+            wn = _cls(lin) == "WeightNormedLinear"
+            linear = lin._modules["linear"] if wn else lin
+            key = f"{prefix}.{pos + 3}.linear" if wn else f"{prefix}.{pos + 3}"
+            if _cls(mid) == "BatchNorm1d":
+                norm, bn_key = "bn", f"{prefix}.{pos + 2}"
+                if wn:
+                    raise NotImplementedError("BatchNorm before a weight-normed linear")
+            else:
+                norm, bn_key = ("wn" if wn else "none"), None
+            nodes.append(ns.Head(key, linear.in_features, linear.out_features, norm, bn_key))
+            pos += 4
+        elif name == "Fork":
+            nets = [m for n, m in layer._modules.items() if n.startswith("net")]
+            nxt = layers[pos + 1] if pos + 1 < len(layers) else None
+            sel = _children(nets[1]._modules["network"])[0] if len(nets) == 2 else None
+            if nxt is None or _cls(nxt) != "LinearCombination" or sel is None or _cls(sel) != "SelectArgument":
+                raise NotImplementedError("only the xattn_subtract Fork/LinearCombination front-end is supported")
+            nodes.append(ns.Mix(tuple(float(c) for c in nxt.coefficients), int(sel.select)))
+            pos += 2
+        elif name == "SelectArgument":
+            nodes.append(ns.Select(int(layer.select)))
+            pos += 1
+        elif name == "Transposer":
+            nodes.append(ns.Transpose(int(layer.dim0), int(layer.dim1)))
+            pos += 1
+        elif name == "ConcatenateChannels":
+            nodes.append(ns.Concat())
+            pos += 1
+        elif name in ("Noop", "Dropout"):
+            pos += 1
+        else:
+            raise NotImplementedError(f"layer type {name!r} at {prefix}.{pos} is not supported")
+    return nodes
+
+
+_MOE_ATTENTION_NETS = ["read_convolver0", "read_convolver1", "compressor0", "compressor1", "compressor2",
+                       "xattn0", "xattn1", "xattn2", "combiner0", "combiner1", "meta"]
+
+
+def spec_from_module(wrapper) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:
+    """Pickled ``MoEMergedWrapperAdvanced`` (stand-in instance) -> (ModelSpec, state dict)."""
+    moe = wrapper._modules.get("moeMerged")
+    if moe is None or _cls(moe) != "MoEAttention":
+        raise NotImplementedError(f"only MoEAttention models are supported (got {_cls(moe) if moe is not None else None})")
+    nets = {}
+    for name in _MOE_ATTENTION_NETS:
+        sub = moe._modules.get(name)
+        if sub is not None:
+            nets[name] = _convert(sub, f"moeMerged.{name}")
+    first0 = next(ns.walk(nets["read_convolver0"]))
+    c1 = next(ns.walk(nets["read_convolver1"])).cin if "read_convolver1" in nets else first0.cin
+    spec = ns.ModelSpec(nets, name="reference_pickle", channels=(first0.cin, c1))
+    state = {k: v.detach().cpu().numpy() for k, v in wrapper.state_dict().items()}
+    return spec, state
+
+
+def _load_reference_pickle(path: str):
+    import torch
+    import warnings
+    with _stand_in_modules(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+    return spec_from_module(obj)
+
+
+def load_spec(path: str) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:
+    """(ModelSpec, state dict) of a native file or a reference ``.wrapper.dnn`` pickle."""
+    return _load_native(path) if _is_native(path) else _load_reference_pickle(path)
+
+
+def load(path: str, device: int = 0, **kw):
+    """Drop-in for ``torch.load(path)`` in the reference caller: returns a network object with
+    ``.eval()``, ``.providePredictions`` and ``__call__(featureDict, ref_segment)``."""
+    from .wrapper import ScoringNetwork
+    spec, state = load_spec(path)
+    return ScoringNetwork(spec, state, device=device, **kw)

@@ -166,8 +166,53 @@ def sanity_known_answer():
     print("reference import sanity OK:", got)
 
 
+def make_pickle_fixture():
+    """A REAL reference pickle (torch.save of a whole MoEMergedWrapperAdvanced, exactly what
+    create_model_wrapper.py:7-10 writes), of a deliberately small architecture assembled from the
+    reference's own layer generators, plus the reference's outputs on a seeded batch.  It pins the
+    loader surface (hello_amd/loader.py) without needing a 6 MB model in the repository."""
+    wn = dict(use_weight_norm=True)
+    rb = dict(kernelSizes=[3, 3], paddings=[1, 1], dilations=[1, 1])
+    read_conv = NNTools.SingleConvLayer(6, 8, 3, 0, 1, 1, **wn)
+    read_conv.append({"type": "MaxPool1d", "kwargs": {"kernel_size": 3, "stride": 2, "padding": 0}})
+    read_conv += [NNTools.ResidualBlockFTShortcut(8, 8, strides=[1, 1], **rb, **wn),
+                  NNTools.ResidualBlockConvShortcut(8, 16, strides=[2, 1, 2], **rb, **wn)]
+    comp = NNTools.SingleConvLayer(16, 16, 1, 0, 1, 1, **wn)
+    comp += [NNTools.ResidualBlockConvShortcut(16, 32, strides=[2, 1, 2], **rb, **wn)]
+    xattn = [{"type": "Fork", "kwargs": {"net_args": [[{"type": "Noop", "kwargs": {}}],
+                                                       [{"type": "SelectArgument", "kwargs": {"select": 1}}]]}},
+             {"type": "LinearCombination", "kwargs": {"coefficients": [2, -1]}}]
+    xattn += NNTools.SingleConvLayer(32, 32, 1, 0, 1, 1, **wn)
+    xattn += [NNTools.ResidualBlockConvShortcut(32, 64, strides=[2, 1, 2], **rb, **wn)]
+    xattn += NNTools.terminus(64, 1, use_weight_norm=True)
+    torch.manual_seed(4321)
+    moe = REF.create_moe_attention_model({"read_conv0": read_conv, "compressor0": comp, "xattn0": xattn})
+    wrapper = REF.createMoEFullMergedAdvancedModelWrapper(moe)
+    wrapper.eval()
+    with torch.no_grad():      # make g != ||v|| and scale the raw-byte input layer down
+        for name, p in wrapper.named_parameters():
+            if name.endswith("weight_g"):
+                p.mul_(1.0 + 0.25 * torch.rand_like(p))
+            if name == "moeMerged.read_convolver0.network.0.conv1d.weight_g":
+                p.div_(128.0)
+    path = os.path.join(HERE, "mini_reference.wrapper.dnn")
+    torch.save(wrapper, path)
+    batch = synth.make_sites(5, seed=321, coverage=12)
+    res = run_batched(wrapper, batch)
+    res.pop("frames0")
+    res.update(run_wrapper(wrapper, batch, synth.allele_names(batch)))
+    wrapper.providePredictions = False
+    payload = dict(reads0=batch.reads0, reads_per_allele0=batch.reads_per_allele0,
+                   alleles_per_site=batch.alleles_per_site, ref_onehot=batch.ref_onehot)
+    payload.update({"exp_" + k: v for k, v in res.items()})
+    np.savez_compressed(os.path.join(HERE, "mini_reference.npz"), **payload)
+    print(f"mini_reference: pickle {os.path.getsize(path) / 1024:.0f} KB, logits "
+          f"[{res['logits'].min():.3f},{res['logits'].max():.3f}]")
+
+
 def main():
     sanity_known_answer()
+    make_pickle_fixture()
     for name, cfg, norm, n_sites, wseed, kw, with_wrapper, keep_frames, need in CASES:
         spec = ns.build(cfg, norm=norm) if norm != "wn" else ns.build(cfg)
         state = weights.synth_state(spec, seed=wseed)

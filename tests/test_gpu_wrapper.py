@@ -1,0 +1,116 @@
+"""GPU: the per-site plug-in surface (hello_amd.wrapper / hello_amd.loader) against what the reference's
+MoEMergedWrapperAdvanced returned for the same sites (golden vectors), through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from hello_amd import loader, synth
+from tests.util import GOLDEN, load_fixture
+
+pytestmark = pytest.mark.gpu
+PROB = dict(rtol=2e-4, atol=1e-4)
+
+
+def site_dicts(batch, as_float=True):
+    import torch
+    names = synth.allele_names(batch)
+    aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
+    r0 = np.concatenate([[0], np.cumsum(batch.reads_per_allele0)])
+    r1 = None if batch.reads1 is None else np.concatenate([[0], np.cumsum(batch.reads_per_allele1)])
+    out = []
+    for s in range(batch.n_sites):
+        fd = {}
+        for j, a in enumerate(range(aoff[s], aoff[s + 1])):
+            # exactly what caller_calling.scoreSite builds: torch.Tensor(uint8 ndarray) -> float32
+            t0 = torch.Tensor(batch.reads0[r0[a]:r0[a + 1]])
+            t1 = None if r1 is None else torch.Tensor(batch.reads1[r1[a]:r1[a + 1]])
+            fd[names[s][j]] = (t0, t1)
+        out.append((fd, torch.from_numpy(batch.ref_onehot[s:s + 1]).float()))
+    return out
+
+
+@pytest.mark.parametrize("name", ["single_tech_batched", "single_tech_hp", "hybrid_no_ensemble", "hybrid_full",
+                                  "hybrid_ensemble2"])
+def test_per_site_call_matches_reference_wrapper(name):
+    import torch
+    from hello_amd.wrapper import ScoringNetwork
+    spec, state, batch, exp = load_fixture(name)
+    net = ScoringNetwork(spec, state)
+    assert net.eval() is net
+    sites = site_dicts(batch)
+    # default: dict of pair -> 0-dim tensor
+    d = net(*sites[0])
+    assert list("|".join(k) for k in d) == list(exp["site0_pairs"])
+    assert all(isinstance(v, torch.Tensor) and v.dim() == 0 for v in d.values())
+    net.providePredictions = True
+    for s, (fd, seg) in enumerate(sites):
+        mix, e0, e1, e2, meta = net(fd, seg)
+        for got, key in ((mix, "mix"), (e0, "e0"), (e1, "e1"), (e2, "e2")):
+            np.testing.assert_allclose(np.array([float(v) for v in got.values()]), exp[f"site{s}_{key}"], **PROB)
+        np.testing.assert_allclose(meta.numpy(), exp[f"site{s}_meta"], **PROB)
+    # throughput form: all sites in one launch, same answers, same order
+    many = net.score_sites(sites)
+    for s, res in enumerate(many):
+        np.testing.assert_allclose(np.array([float(v) for v in res[0].values()]), exp[f"site{s}_mix"], **PROB)
+    net.close()
+
+
+def test_batched_operator_surface_matches_reference_layout():
+    """network.moeMerged(tensors [sumR, C, L], alleles/site, reads/allele, ref) -> logits [sumA, 1]."""
+    import torch
+    from hello_amd.wrapper import ScoringNetwork
+    spec, state, batch, exp = load_fixture("hybrid_full")
+    net = ScoringNetwork(spec, state)
+    t0 = torch.from_numpy(np.ascontiguousarray(np.transpose(batch.reads0, (0, 2, 1))))
+    t1 = torch.from_numpy(np.ascontiguousarray(np.transpose(batch.reads1, (0, 2, 1))))
+    experts, meta = net.moeMerged((t0, t1), batch.alleles_per_site.tolist(),
+                                  (batch.reads_per_allele0.tolist(), batch.reads_per_allele1.tolist()),
+                                  torch.from_numpy(batch.ref_onehot).float(), "ignored extra positional")
+    assert len(experts) == 3 and experts[0].shape == (batch.n_alleles, 1)
+    np.testing.assert_allclose(np.stack([e[:, 0].numpy() for e in experts]), exp["logits"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(meta.numpy(), exp["meta"], **PROB)
+    net.close()
+
+
+def test_loader_runs_a_real_reference_pickle():
+    net = loader.load(os.path.join(GOLDEN, "mini_reference.wrapper.dnn"))
+    net.eval()
+    net.providePredictions = True
+    z = np.load(os.path.join(GOLDEN, "mini_reference.npz"))
+    batch = synth.SiteBatch(z["reads0"], z["reads_per_allele0"], z["alleles_per_site"], z["ref_onehot"])
+    logits, _ = net.engine.forward_batch(batch)
+    np.testing.assert_allclose(logits, z["exp_logits"], rtol=2e-5, atol=2e-5)
+    for s, (fd, seg) in enumerate(site_dicts(batch)):
+        mix, e0, _, _, meta = net(fd, seg)
+        np.testing.assert_allclose(np.array([float(v) for v in mix.values()]), z[f"exp_site{s}_mix"], **PROB)
+        assert meta.tolist() == [1.0, 0.0, 0.0]
+    net.close()
+
+
+def test_site_batcher_preserves_order():
+    from hello_amd.wrapper import ScoringNetwork, SiteBatcher
+    spec, state, batch, exp = load_fixture("single_tech_batched")
+    net = ScoringNetwork(spec, state)
+    batcher = SiteBatcher(net, max_sites=4)
+    got = []
+    for s, (fd, seg) in enumerate(site_dicts(batch)):
+        got += batcher.submit(fd, seg, tag=s)
+    got += batcher.flush()
+    assert [t for t, _ in got] == list(range(batch.n_sites))
+    for s, res in got:
+        np.testing.assert_allclose(np.array([float(v) for v in res.values()]), exp[f"site{s}_mix"], **PROB)
+    net.close()
+
+
+def test_non_integer_pileups_are_rejected():
+    import torch
+    from hello_amd.wrapper import ScoringNetwork
+    spec, state, batch, _ = load_fixture("single_tech_batched")
+    net = ScoringNetwork(spec, state)
+    fd, seg = site_dicts(batch)[0]
+    k = next(iter(fd))
+    fd[k] = (fd[k][0] + 0.5, None)
+    with pytest.raises(ValueError, match="integers"):
+        net(fd, seg)
+    net.close()

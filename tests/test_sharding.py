@@ -1,0 +1,66 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes shard a batch by sites, score their shard and
+gather to rank 0 with the one collective of the path (hello_amd/shard.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from hello_amd import netspec as ns, shard, synth, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_is_contiguous_complete_and_balanced():
+    rng = np.random.default_rng(0)
+    reads = rng.poisson(30, size=1000) + 1
+    for parts in (1, 2, 3, 8):
+        ranges = shard.partition_sites(reads, parts)
+        assert ranges[0][0] == 0 and ranges[-1][1] == 1000
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        loads = [reads[lo:hi].sum() for lo, hi in ranges]
+        assert max(loads) - min(loads) <= 2 * reads.max()
+    assert shard.partition_sites([5, 5], 4)[-1][1] == 2           # fewer sites than ranks: empty ranges allowed
+    assert shard.partition_sites([1000, 1, 1, 1], 2)[0] == (0, 1)  # ragged
+
+
+def _worker(rank, world, port, out_path, use_oracle):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if use_oracle:
+        from oracle import moe_oracle as mo
+        spec = ns.build("hybrid_ensemble2")
+        oracle = mo.Oracle(spec, weights.synth_state(spec, seed=2))
+        batch = synth.make_sites(5, seed=8, coverage=6, hybrid_coverage=4)
+        fn = lambda sub: mo.forward_batch(oracle, sub, chunk_sites=1)        # noqa: E731
+    else:
+        batch = synth.make_sites(3 if world > 3 else 37, seed=5, coverage=20)
+        def fn(sub):     # a stand-in scorer: any per-allele function of the reads
+            off = np.concatenate([[0], np.cumsum(sub.reads_per_allele0)])
+            v = np.array([sub.reads0[off[i]:off[i + 1]].astype(np.float64).sum() for i in range(sub.n_alleles)])
+            return v[None, :].astype(np.float32), None
+    logits, meta = shard.score_sharded(fn, batch, rank, world)
+    if rank == 0:
+        full_logits, full_meta = fn(batch)
+        np.savez(out_path, got=logits.numpy(), want=np.asarray(full_logits),
+                 got_meta=np.zeros(0) if meta is None else meta.numpy(),
+                 want_meta=np.zeros(0) if full_meta is None else np.asarray(full_meta))
+    else:
+        assert logits is None and meta is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,use_oracle", [(2, False), (2, True), (4, False)])
+def test_sharded_scoring_equals_unsharded(tmp_path, world, use_oracle):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "out.npz")
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, out, use_oracle), nprocs=world, join=True)
+    z = np.load(out)
+    np.testing.assert_allclose(z["got"], z["want"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(z["got_meta"], z["want_meta"], rtol=1e-5, atol=1e-6)
