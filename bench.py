@@ -67,7 +67,9 @@ def main():
     ap.add_argument("--sites", type=int, default=8192, help="candidate sites per step per GPU")
     ap.add_argument("--pool", type=int, default=2, help="distinct resident batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fused", action="store_true", help="layer-by-layer read convolver")
+    ap.add_argument("--fused", choices=["full", "trunk", "none"], default="full",
+                    help="read convolver: one fused kernel from the bytes / layer-by-layer stem + fused trunk / "
+                         "layer by layer")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--op-times", action="store_true", help="print per-op device times to stderr")
     args = ap.parse_args()
@@ -92,7 +94,7 @@ def main():
 
     spec = ns.build("single_tech")
     state = weights.synth_state(spec, seed=args.seed)
-    eng = Engine(spec, state, device=local_rank, fused=not args.no_fused)
+    eng = Engine(spec, state, device=local_rank, fused={"full": True, "trunk": "trunk", "none": False}[args.fused])
 
     # resident pool of synthetic batches (every rank its own sites: shard = rank)
     pool = []

@@ -285,14 +285,20 @@ class _Lowering:
         from . import readconv_pack
         if (self.fused and readconv_pack.AVAILABLE and spec.window == 150
                 and _is_canonical_read_convolver(nodes, cin)):
-            # stem layer by layer (3 valid convs + max pool), then the fused residual trunk + segment sum
-            pooled = self.net(nodes[:readconv_pack.TRUNK_FIRST_NODE], x)
-            assert (pooled.length, pooled.channels) == (71, 32)
             y = self.new(ROWS_ALLELES, 36, 64)
             w_off = self.blob.add(readconv_pack.pack(nodes, self.folded, cin))
-            self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=pooled.vid, dst=y.vid, cin=32, cout=64,
-                               lin=71, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name + ".trunk",
-                               macs_per_row=ns.macs(nodes[readconv_pack.TRUNK_FIRST_NODE:], 71)))
+            if self.fused == "trunk":
+                # stem layer by layer (3 valid convs + max pool), fused residual trunk + segment sum
+                pooled = self.net(nodes[:readconv_pack.TRUNK_FIRST_NODE], x)
+                assert (pooled.length, pooled.channels) == (71, 32)
+                self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=pooled.vid, dst=y.vid, cin=32, cout=64,
+                                   lin=71, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name + ".trunk",
+                                   macs_per_row=ns.macs(nodes[readconv_pack.TRUNK_FIRST_NODE:], 71)))
+            else:
+                # the whole read convolver (stem included) + segment sum in one kernel, straight from the bytes
+                self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=buf, dst=y.vid, cin=cin, cout=64,
+                                   lin=150, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name,
+                                   flags=FLAG_SRC_U8, macs_per_row=ns.macs(nodes, 150)))
             self.used_fused = True
             return y
         return self.segsum(self.net(nodes, x), seg)

@@ -582,7 +582,13 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
             case HELLO_OP_READCONV_FUSED: {
                 const bool t1 = o.seg == HELLO_SEG_READS1_TO_ALLELES;
                 hello::ReadConvArgs a{};
-                a.pooled = (const float*)ptr(o.src0);
+                if (o.flags & HELLO_FLAG_SRC_U8) {
+                    a.reads = (const uint8_t*)ptr(o.src0);
+                    a.channels = o.cin;
+                } else {
+                    a.pooled = (const float*)ptr(o.src0);
+                }
+                if (!ptr(o.src0)) return fail(HELLO_ERR_ARG, "op %d reads an input the caller did not supply", op_index);
                 a.w = e->d_weights + o.w_off;
                 a.partial = (float*)e->d_partial.p;
                 a.allele_of_read = t1 ? e->allele_of_read1 : e->allele_of_read0;

@@ -54,7 +54,9 @@ hipError_t launch_posteriors(const float* logits, const float* meta, const int32
 
 // ---- fused read convolver (readconv_fused.hip) ------------------------------------------------
 struct ReadConvArgs {
-    const float* pooled;       // [R][71][32] output of the stem (3 valid convs + MaxPool1d(3,2))
+    const uint8_t* reads;      // [R][150][channels] pileups: the stem runs inside the kernel; or NULL and
+    const float* pooled;       // [R][71][32] output of a layer-by-layer stem (3 valid convs + MaxPool1d(3,2))
+    int channels;              // 6 | 7 (only with `reads`)
     const float* w;            // packed block, see hello_amd/readconv_pack.py
     float* partial;            // [n_slots][36][64]: one slot per (read group, allele) incidence
     const int32_t* allele_of_read;   // [R]

@@ -51,7 +51,22 @@ constexpr int OFF_C1 = OFF_B + 6 * (W3232 + 32);           // 32->64 k3 s2
 constexpr int OFF_SC = OFF_C1 + W3264 + 64;                // 32->64 k1 s2
 constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3
 constexpr int OFF_D = OFF_C2 + W6464 + 64;                 // 6 convs 64->64
-constexpr int W_TOTAL = OFF_D + 6 * (W6464 + 64);
+constexpr int W_TRUNK = OFF_D + 6 * (W6464 + 64);
+
+// ---- stem (3 valid convs + MaxPool1d(3,2)), run in sub-batches of SB reads inside the same kernel ----
+constexpr int SB = 4;                        // reads per stem sub-batch
+constexpr int SROWS = 150 * SB;              // rows of a sub-batch (reads stacked at their natural stride)
+constexpr int ST12 = (SROWS + 15) / 16;      // 38 position tiles for conv1 / conv2
+constexpr int ST3 = (SROWS + 13) / 14;       // 43 tiles of conv3: 16 positions, stride 14 -> 7 pooled outputs each
+constexpr int C12_ROWS = 612;                // rows of the 16-channel conv1 / conv2 images (2 x 39 168 B = bufB)
+constexpr int U8_BYTES = 4384;               // (SROWS + 24) * 7 rounded up to 16
+constexpr int S1_STEPS = 6;                  // K = 3*C <= 21 -> 6 MFMA steps of 4
+constexpr int OFF_S1 = W_TRUNK;                          // [6 steps][64 lanes], bias[16]
+constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;      // [3 taps][64 lanes][4], bias[16]
+constexpr int OFF_S3 = OFF_S2 + 3 * 256 + 16;            // [2 blocks][3 taps][64 lanes][4], bias[32]
+constexpr int W_TOTAL = OFF_S3 + 2 * 3 * 256 + 32;
+constexpr int LDS_BYTES_STEM = LDS_BYTES + U8_BYTES;
+static_assert(2 * C12_ROWS * 16 <= BUF_FLOATS, "conv1/conv2 images must fit the second LDS image");
 }  // namespace rc
 
 int readconv_reads_per_group() { return rc::G; }
@@ -160,6 +175,128 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     }
 }
 
+
+// ---- stem ----------------------------------------------------------------------------------------
+// Reference: architectures/read_convolver.py:13-56 (6|7 -> 16 -> 16 -> 32, kernel 3, no padding, ReLU
+// each, then MaxPool1d(3, 2)).  Reads of a sub-batch are stacked at their natural stride of 150 rows, so
+// the three valid convolutions run over the stacked rows as if they were one sequence; rows whose window
+// straddles two reads are garbage that nothing valid ever consumes (a read's pooled outputs only look at
+// its own first 143 conv3 rows).  conv1 reads the bytes themselves: with channels-last bytes the im2col
+// index k = tap*C + c is simply the byte offset from the row start.  conv3 tiles overlap by two rows
+// (stride 14) so each 16-position tile max-pools 7 outputs entirely inside one DPP row.
+__device__ __forceinline__ int sw16(int row) { return (row >> 2) & 3; }
+
+__device__ __forceinline__ void stem_subbatch(const unsigned char* __restrict__ s_u8, float* __restrict__ c1,
+                                              float* __restrict__ c2, float* __restrict__ bufA,
+                                              const float* __restrict__ W, int ch, int sb, int n_here, int wave,
+                                              int lane) {
+    using namespace rc;
+    const int j = lane & 15, q = lane >> 4;
+    // conv1: bytes -> 16 channels
+    {
+        float w1[S1_STEPS];
+#pragma unroll
+        for (int s = 0; s < S1_STEPS; ++s) w1[s] = W[OFF_S1 + s * 64 + lane];
+        const f32x4 b4 = *(const f32x4*)(W + OFF_S1 + S1_STEPS * 64 + 4 * q);
+        for (int t = wave; t < ST12; t += 2 * NW) {
+            const int t1 = (t + NW < ST12) ? t + NW : t;
+            const int r0 = 16 * t + j, r1 = 16 * t1 + j;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < S1_STEPS; ++s) {
+                const float x0 = (float)s_u8[r0 * ch + 4 * s + q];
+                const float x1 = (float)s_u8[r1 * ch + 4 * s + q];
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], x0, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], x1, a1, 0, 0, 0);
+            }
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = fmaxf(a0[e] + b4[e], 0.f);
+                v1[e] = fmaxf(a1[e] + b4[e], 0.f);
+            }
+            *(f32x4*)(c1 + r0 * 16 + 4 * (q ^ sw16(r0))) = v0;
+            if (t1 != t) *(f32x4*)(c1 + r1 * 16 + 4 * (q ^ sw16(r1))) = v1;
+        }
+    }
+    __syncthreads();
+    // conv2: 16 -> 16
+    {
+        f32x4 w2[3];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) w2[tap] = *(const f32x4*)(W + OFF_S2 + (tap * 64 + lane) * 4);
+        const f32x4 b4 = *(const f32x4*)(W + OFF_S2 + 3 * 256 + 4 * q);
+        for (int t = wave; t < ST12; t += 2 * NW) {
+            const int t1 = (t + NW < ST12) ? t + NW : t;
+            const int r0 = 16 * t + j, r1 = 16 * t1 + j;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const f32x4 x0 = *(const f32x4*)(c1 + (r0 + tap) * 16 + 4 * (q ^ sw16(r0 + tap)));
+                const f32x4 x1 = *(const f32x4*)(c1 + (r1 + tap) * 16 + 4 * (q ^ sw16(r1 + tap)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[tap][e], x0[e], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[tap][e], x1[e], a1, 0, 0, 0);
+                }
+            }
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = fmaxf(a0[e] + b4[e], 0.f);
+                v1[e] = fmaxf(a1[e] + b4[e], 0.f);
+            }
+            *(f32x4*)(c2 + r0 * 16 + 4 * (q ^ sw16(r0))) = v0;
+            if (t1 != t) *(f32x4*)(c2 + r1 * 16 + 4 * (q ^ sw16(r1))) = v1;
+        }
+    }
+    __syncthreads();
+    // conv3: 16 -> 32, ReLU, MaxPool1d(3, 2) in registers, scatter into the trunk's 32-channel image
+    {
+        const int cb = wave & 1, pg = wave >> 1;
+        f32x4 w3[3];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) w3[tap] = *(const f32x4*)(W + OFF_S3 + ((cb * 3 + tap) * 64 + lane) * 4);
+        const f32x4 b4 = *(const f32x4*)(W + OFF_S3 + 2 * 3 * 256 + cb * 16 + 4 * q);
+        for (int t = pg; t < ST3; t += 8) {
+            const int t1 = (t + 4 < ST3) ? t + 4 : t;
+            const int r0 = 14 * t + j, r1 = 14 * t1 + j;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const f32x4 x0 = *(const f32x4*)(c2 + (r0 + tap) * 16 + 4 * (q ^ sw16(r0 + tap)));
+                const f32x4 x1 = *(const f32x4*)(c2 + (r1 + tap) * 16 + 4 * (q ^ sw16(r1 + tap)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[tap][e], x0[e], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[tap][e], x1[e], a1, 0, 0, 0);
+                }
+            }
+            auto pool_store = [&](f32x4 acc, int r) {
+                f32x4 v, m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[e] + b4[e], 0.f);
+                    const float n1 = __shfl_down(v[e], 1, 16);
+                    const float n2 = __shfl_down(v[e], 2, 16);
+                    m[e] = fmaxf(fmaxf(v[e], n1), n2);
+                }
+                const int rdl = r / 150;
+                const int i = r - rdl * 150;
+                const int p = i >> 1;
+                const int rd = SB * sb + rdl;
+                if (((j & 1) == 0) && j <= 12 && p < L1 && rd < n_here && rdl < SB) {
+                    const int row = 1 + rd * RS1 + p;
+                    *(f32x4*)(bufA + row * 32 + 4 * ((4 * cb + q) ^ swz<32>(row))) = m;
+                }
+            };
+            pool_store(a0, r0);
+            if (t1 != t) pool_store(a1, r1);
+        }
+    }
+}
+
+template <bool STEM>
 __global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
     using namespace rc;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -174,12 +311,27 @@ __global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
     const int n_here = (int)((a.n_reads - read0) < G ? (a.n_reads - read0) : G);
     const float* __restrict__ W = a.w;
 
-    // ---- stage the group's pooled stem output [71][32] per read into bufA; everything else zero ----
+    // ---- the trunk's input image [71][32] per read in bufA (pad rows and row 0 zero) ------------------
     for (int i = tid; i < BUF_FLOATS / 4; i += 512) ((f32x4*)bufA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!STEM && tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
     __syncthreads();
-    {
+    if (STEM) {
+        // computed here from the uint8 pileups, SB reads at a time, temporaries in bufB
+        unsigned char* s_u8 = (unsigned char*)(smem + 2 * BUF_FLOATS + 16);
+        const int ch = a.channels;
+        const int per_read = 150 * ch;
+        for (int sb = 0; sb < G / SB; ++sb) {
+            const int have = n_here - SB * sb;                       // reads of this sub-batch that exist
+            const int n_bytes = (have < 0 ? 0 : (have > SB ? SB : have)) * per_read;
+            const unsigned char* src = a.reads + (read0 + SB * sb) * per_read;
+            for (int i = tid; i < U8_BYTES; i += 512) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
+            __syncthreads();
+            stem_subbatch(s_u8, bufB, bufB + C12_ROWS * 16, bufA, W, ch, sb, n_here, wave, lane);
+            __syncthreads();
+        }
+        if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};   // row 0 of the 32-channel image
+    } else {
         const f32x4* src = (const f32x4*)(a.pooled + read0 * (L1 * 32));
         const int n4 = n_here * L1 * 8;
         for (int f = tid; f < n4; f += 512) {
@@ -266,13 +418,21 @@ hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
     if (a.n_reads <= 0) return hipSuccess;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)readconv_trunk_kernel,
+        hipError_t e = hipFuncSetAttribute((const void*)readconv_trunk_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, rc::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)readconv_trunk_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, rc::LDS_BYTES_STEM);
         if (e != hipSuccess) return e;
         configured = true;
     }
     const unsigned groups = (unsigned)((a.n_reads + rc::G - 1) / rc::G);
-    hipLaunchKernelGGL(readconv_trunk_kernel, dim3(groups), dim3(512), rc::LDS_BYTES, stream, a);
+    if (a.reads) {
+        if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(readconv_trunk_kernel<true>, dim3(groups), dim3(512), rc::LDS_BYTES_STEM, stream, a);
+    } else {
+        hipLaunchKernelGGL(readconv_trunk_kernel<false>, dim3(groups), dim3(512), rc::LDS_BYTES, stream, a);
+    }
     return hipGetLastError();
 }
 

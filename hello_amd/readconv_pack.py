@@ -42,8 +42,26 @@ def trunk_convs(nodes):
     return order
 
 
+def _pack_first_conv(w: np.ndarray, b: np.ndarray, steps: int = 6) -> np.ndarray:
+    """conv1 of the stem reads the pileup bytes directly: k = tap*C + c is the byte offset from the row
+    start, walked 4 per MFMA step; lane l holds W[out = l & 15][k = 4*step + (l >> 4)] (zero past 3*C)."""
+    cout, cin, k = w.shape
+    assert cout == 16 and k == 3 and 3 * cin <= 4 * steps
+    flat = np.zeros((cout, 4 * steps), np.float32)
+    flat[:, :3 * cin] = w.transpose(0, 2, 1).reshape(cout, 3 * cin)          # [out][tap*C + c]
+    lanes = np.arange(64)
+    packed = flat[(lanes & 15)[None, :], 4 * np.arange(steps)[:, None] + (lanes >> 4)[None, :]]   # [step][lane]
+    return np.concatenate([packed.ravel(), b.astype(np.float32).ravel()])
+
+
 def pack(nodes, folded, cin=None) -> np.ndarray:
+    """trunk block followed by the stem block (conv1 bytes form, conv2, conv3)."""
     parts = [_pack_conv(*folded[c.key]) for c in trunk_convs(nodes)]
+    stem = nodes[:3]
+    parts.append(_pack_first_conv(*folded[stem[0].key]))
+    parts.append(_pack_conv(*folded[stem[1].key]))
+    parts.append(_pack_conv(*folded[stem[2].key]))
     blob = np.concatenate(parts)
-    assert blob.size == 6 * (3072 + 32) + (6144 + 64) + (2048 + 64) + (12288 + 64) + 6 * (12288 + 64), blob.size
+    trunk = 6 * (3072 + 32) + (6144 + 64) + (2048 + 64) + (12288 + 64) + 6 * (12288 + 64)
+    assert blob.size == trunk + (384 + 16) + (768 + 16) + (1536 + 32), blob.size
     return blob

@@ -34,7 +34,7 @@ def get_engine(cache, name, spec, state, fused):
     return cache[key]
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, "trunk", True])
 @pytest.mark.parametrize("name", FIXTURES)
 def test_golden_logits(engines, name, fused):
     spec, state, batch, exp = load_fixture(name)
