@@ -1,33 +1,43 @@
-// Fused residual trunk of the read convolver + reads->alleles segment sum (gfx950).
+// Fused read convolver + reads->alleles segment sum (gfx950): pileup bytes in, per-allele sums out.
 //
-// Reference semantics: architectures/read_convolver.py:58-143 (3 x ResidualBlock(32), the strided
-// 32->64 block with its 1x1 shortcut, 3 x ResidualBlock(64)) followed by reduceSlots over the reads of
-// each allele (MixtureOfExpertsAdvanced.py:23-34,163).  That is 92.6 % of the read convolver's
-// multiply-accumulates (4 700 160 of 5 076 096 per read) and 77 % of a 30x site's.
+// Reference semantics: architectures/read_convolver.py:9-144 -- the stem (6|7 -> 16 -> 16 -> 32, kernel 3,
+// no padding, ReLU each, MaxPool1d(3,2)), 3 x ResidualBlock(32), the strided 32->64 block with its 1x1
+// shortcut, 3 x ResidualBlock(64) -- followed by reduceSlots over the reads of each allele
+// (MixtureOfExpertsAdvanced.py:23-34,163).  That is 5 076 096 MAC per read, 83 % of a 30x site.
 //
-// One workgroup (512 threads = 8 waves = 2 per SIMD) carries G = 8 reads through all 15 convolutions
-// with every activation resident in LDS; nothing but the pooled stem output is read and nothing but
-// per-allele partial sums is written.
+// One workgroup carries G reads through all 18 convolutions with every activation resident in LDS;
+// nothing but the bytes is read and nothing but per-allele partial sums is written.  Two geometries are
+// compiled: <G=4, 4 waves> (two workgroups per CU: one workgroup's barriers and prologue hide behind the
+// other's MFMAs) and <G=8, 8 waves> (one workgroup per CU, less tile padding).
 //
-//   LDS     two ping-pong images (2 x 78 336 B of the CU's 160 KiB), float32 channels-last
-//           [row][channel]; the reads of the group are stacked along the row axis with ONE shared
-//           zero row between neighbours (row stride 72 at 71 positions, 37 at 36), so the k=3/pad=1
-//           convolutions need no edge handling: the pad row is written as zero by every epilogue.
-//           16-byte chunks of a row are XOR-swizzled with the row index, which keeps both the
-//           ds_read_b128 operand reads (16 rows x one chunk column) and the ds_write_b128 epilogue
-//           stores off each other's banks without padding the rows.
+//   LDS     two ping-pong images, float32 channels-last [row][channel]; the reads of the group are
+//           stacked along the row axis with ONE shared zero row between neighbours (row stride 72 at 71
+//           positions, 37 at 36), so the k=3/pad=1 convolutions need no edge handling: the pad row is
+//           written as zero by every epilogue.  16-byte chunks of a row are XOR-swizzled with the row
+//           index (chunk ^ 2*(row&7) at 64 channels) so that the ds_read_b128 operand reads of 16
+//           consecutive rows, issued by lanes of two different channel quarters, hit 16 distinct bank
+//           groups whatever the tile's first row is.
 //   MFMA    v_mfma_f32_16x16x4_f32 (exact fp32), D[channel][position] = W[channel][k] X[k][position]:
-//           a wave owns one 16-channel block and walks 16-position tiles, two tiles in flight so the
-//           40-cycle dependent latency of the 32-cycle instruction is covered.  Lane (j, q) of a tile
-//           ends with channels 4q..4q+3 of position j -> bias / ReLU / residual / store are float4.
-//           k is ordered so that lane-quarter q supplies channels 16m+4q+t at step (tap, m, t) for
-//           BOTH operands: one ds_read_b128 feeds four MFMAs.
+//           a wave owns one 16-channel block and walks 16-position tiles, two accumulation chains in
+//           flight so the 40-cycle dependent latency of the 32-cycle instruction is covered.  Lane (j, q)
+//           of a tile ends with channels 4q..4q+3 of position j -> bias / ReLU / residual / store are
+//           float4.  k is ordered so that lane-quarter q supplies channels 16m+4q+t at step (tap, m, t)
+//           for BOTH operands: one ds_read_b128 feeds four MFMAs.
 //   weights each wave keeps ONLY its own 16-channel slice of the layer in registers (<= 48 VGPRs),
 //           loaded straight from L2 in lane order (pre-packed by hello_amd/readconv_pack.py); the next
 //           layer's slice is requested before the current layer's MFMAs start.
+//   stem    runs in sub-batches inside the same kernel with its temporaries in the second image.  Reads
+//           of a sub-batch are stacked at their natural stride of 150 rows, so the three valid
+//           convolutions run over the stacked rows as one sequence; rows whose window straddles two
+//           reads are garbage nothing valid consumes.  conv1 reads the bytes themselves: with
+//           channels-last bytes the im2col index k = tap*C + c is the byte offset from the row start.
+//           conv3 tiles overlap by two rows (stride 14) so each tile max-pools 7 outputs inside one
+//           16-lane row with two lane shifts, and only the pooled values ever reach LDS.
 //   sum     reads of an allele are contiguous, so the group adds its reads per allele in order and
 //           writes one partial [36][64] slot per (group, allele) incidence; a tiny finalize kernel adds
 //           an allele's slots in order.  No atomics: results are bit-reproducible.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace hello {
@@ -35,14 +45,8 @@ namespace hello {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace rc {
-constexpr int G = 8;                 // reads per workgroup
-constexpr int NW = 8;                // waves per workgroup
 constexpr int L1 = 71, RS1 = 72;     // positions / row stride per read at 32 channels
 constexpr int L2 = 36, RS2 = 37;     // ... at 64 channels
-constexpr int T1 = (RS1 * G + 15) / 16;   // 36 position tiles
-constexpr int T2 = (RS2 * G + 15) / 16;   // 19
-constexpr int BUF_FLOATS = (T2 * 16 + 2) * 64;   // 19 584 floats; the 32-channel image needs 18 496
-constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4 + 64;   // + allele ids of the group
 
 // packed weight block (floats): per conv [COUT/16][KT][CIN/16][64 lanes][4], then bias [COUT]
 constexpr int W3232 = 2 * 3 * 2 * 256, W3264 = 4 * 3 * 2 * 256, W3264S = 4 * 1 * 2 * 256, W6464 = 4 * 3 * 4 * 256;
@@ -52,29 +56,54 @@ constexpr int OFF_SC = OFF_C1 + W3264 + 64;                // 32->64 k1 s2
 constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3
 constexpr int OFF_D = OFF_C2 + W6464 + 64;                 // 6 convs 64->64
 constexpr int W_TRUNK = OFF_D + 6 * (W6464 + 64);
-
-// ---- stem (3 valid convs + MaxPool1d(3,2)), run in sub-batches of SB reads inside the same kernel ----
-constexpr int SB = 4;                        // reads per stem sub-batch
-constexpr int SROWS = 150 * SB;              // rows of a sub-batch (reads stacked at their natural stride)
-constexpr int ST12 = (SROWS + 15) / 16;      // 38 position tiles for conv1 / conv2
-constexpr int ST3 = (SROWS + 13) / 14;       // 43 tiles of conv3: 16 positions, stride 14 -> 7 pooled outputs each
-constexpr int C12_ROWS = 612;                // rows of the 16-channel conv1 / conv2 images (2 x 39 168 B = bufB)
-constexpr int U8_BYTES = 4384;               // (SROWS + 24) * 7 rounded up to 16
-constexpr int S1_STEPS = 6;                  // K = 3*C <= 21 -> 6 MFMA steps of 4
-constexpr int OFF_S1 = W_TRUNK;                          // [6 steps][64 lanes], bias[16]
-constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;      // [3 taps][64 lanes][4], bias[16]
-constexpr int OFF_S3 = OFF_S2 + 3 * 256 + 16;            // [2 blocks][3 taps][64 lanes][4], bias[32]
+constexpr int S1_STEPS = 6;                                // stem conv1: K = 3*C <= 21 -> 6 MFMA steps of 4
+constexpr int OFF_S1 = W_TRUNK;                            // [6 steps][64 lanes], bias[16]
+constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps][64 lanes][4], bias[16]
+constexpr int OFF_S3 = OFF_S2 + 3 * 256 + 16;              // [2 blocks][3 taps][64 lanes][4], bias[32]
 constexpr int W_TOTAL = OFF_S3 + 2 * 3 * 256 + 32;
-constexpr int LDS_BYTES_STEM = LDS_BYTES + U8_BYTES;
-static_assert(2 * C12_ROWS * 16 <= BUF_FLOATS, "conv1/conv2 images must fit the second LDS image");
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int G_, int NW_>
+struct Cfg {
+    static constexpr int G = G_;                       // reads per workgroup
+    static constexpr int NW = NW_;                     // waves per workgroup
+    static constexpr int THREADS = 64 * NW_;
+    static constexpr int T1 = (RS1 * G_ + 15) / 16;    // position tiles at 32 channels
+    static constexpr int T2 = (RS2 * G_ + 15) / 16;    // ... at 64 channels
+    static constexpr int ROWS1 = RS1 * G_ + 1;         // rows of the 32-channel image (row 0 = leading zero row)
+    static constexpr int ROWS2 = RS2 * G_ + 1;
+    static constexpr int SB = G_ / 2;                  // reads per stem sub-batch
+    static constexpr int SROWS = 150 * SB;
+    static constexpr int ST12 = (SROWS + 15) / 16;     // tiles of stem conv1 / conv2
+    static constexpr int ST3 = (SROWS + 13) / 14;      // tiles of stem conv3 (16 positions, stride 14)
+    static constexpr int BUF_FLOATS = cmax(cmax(ROWS2 * 64, ROWS1 * 32), 2 * SROWS * 16);
+    static constexpr int U8_BYTES = ((SROWS + 24) * 7 + 15) / 16 * 16;
+    static constexpr int NSREG = (T2 * 4 + NW_ - 1) / NW_;   // shortcut tiles a wave keeps in registers
+    // Tiles past the last read of the group are computed and discarded; their operand reads run up to
+    // (T2*16 + 2) rows of 64 floats past the start of the SECOND image, so the allocation covers that
+    // extent (the bytes read there are never consumed by a stored result).
+    static constexpr int LDS_BYTES = cmax(2 * BUF_FLOATS * 4 + 64 + U8_BYTES,
+                                          BUF_FLOATS * 4 + (T2 * 16 + 2) * 256 + 64);
+};
 }  // namespace rc
 
-int readconv_reads_per_group() { return rc::G; }
 int readconv_weight_floats() { return rc::W_TOTAL; }
 
+static int g_cfg = -1;   // 0: <8,8>, 1: <4,4>
+static int readconv_cfg() {
+    if (g_cfg < 0) {
+        const char* e = std::getenv("HELLO_READCONV_GROUP");
+        g_cfg = (e && std::atoi(e) == 8) ? 0 : 1;
+    }
+    return g_cfg;
+}
+int readconv_reads_per_group() { return readconv_cfg() == 0 ? 8 : 4; }
+
+// chunk swizzles: 16-byte chunk index of a row XORed with a function of the row
 template <int C>
 __device__ __forceinline__ int swz(int row) {
-    return C == 64 ? (row & 15) : ((row >> 1) & 7);
+    return C == 64 ? 2 * (row & 7) : (C == 32 ? 2 * ((row >> 1) & 3) : 2 * ((row >> 2) & 1));
 }
 
 template <int NV>
@@ -86,11 +115,12 @@ __device__ __forceinline__ void load_weights(f32x4 (&w)[NV], const float* __rest
 enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3 };
 
 // One convolution over the whole group.  `in`/`out` are LDS images with CIN / COUT floats per row.
-template <int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE>
+template <class CF, int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* __restrict__ out,
                                            const f32x4 (&w)[KT * CIN / 16], const float* __restrict__ bias,
-                                           f32x4 (&sreg)[(rc::T2 + 1) / 2], int wave, int lane) {
-    constexpr int M = CIN / 16, NCB = COUT / 16, NPG = rc::NW / NCB, ITER = (T + NPG - 1) / NPG;
+                                           f32x4 (&sreg)[CF::NSREG], int wave, int lane) {
+    constexpr int M = CIN / 16, NCB = COUT / 16, NPG = CF::NW / NCB, ITER = (T + NPG - 1) / NPG;
+    static_assert(NPG >= 1 && NCB * NPG == CF::NW, "waves must tile channel blocks x position groups");
     const int cb = wave % NCB, pg = wave / NCB;
     const int j = lane & 15, q = lane >> 4;
     const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
@@ -99,6 +129,9 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
         const int r = t * 16 + j;
         const int rd = r / RS_OUT;
         return 1 + rd * RS_IN + (r - rd * RS_OUT) * STRIDE - PAD;
+    };
+    auto operand = [&](int row, int m) -> f32x4 {
+        return *(const f32x4*)(in + row * CIN + 4 * ((4 * m + q) ^ swz<CIN>(row)));
     };
     auto finish = [&](int t, f32x4 acc, f32x4& keep) {
         const int r = t * 16 + j;
@@ -115,17 +148,19 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[e] + b4[e], 0.f);
         const int row = r + 1;
         float* dst = out + row * COUT + 4 * ((4 * cb + q) ^ swz<COUT>(row));
-        if (MODE == MODE_RESID_INPLACE) {
-            const f32x4 x = *(const f32x4*)dst;
+        if (r < RS_OUT * CF::G) {
+            if (MODE == MODE_RESID_INPLACE) {
+                const f32x4 x = *(const f32x4*)dst;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += x[e];
-        }
-        if (MODE == MODE_ADD_REGS) {
+                for (int e = 0; e < 4; ++e) v[e] += x[e];
+            }
+            if (MODE == MODE_ADD_REGS) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += keep[e];
+                for (int e = 0; e < 4; ++e) v[e] += keep[e];
+            }
+            if (p >= LOUT) v = f32x4{0.f, 0.f, 0.f, 0.f};          // the shared zero row between reads
+            *(f32x4*)dst = v;
         }
-        if (p >= LOUT) v = f32x4{0.f, 0.f, 0.f, 0.f};          // the shared zero row between reads
-        if (r < RS_OUT * rc::G) *(f32x4*)dst = v;
     };
 
 #pragma unroll
@@ -133,18 +168,15 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
         const int t0 = pg + NPG * i, t1 = pg + NPG * (i + 1);
         if (t0 >= T) break;
         const bool two = (i + 1 < ITER) && (t1 < T);
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
         if (two) {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
             const int r0 = in_row(t0), r1 = in_row(t1);
 #pragma unroll
             for (int tap = 0; tap < KT; ++tap) {
-                const float* p0 = in + (r0 + tap) * CIN;
-                const float* p1 = in + (r1 + tap) * CIN;
-                const int s0 = swz<CIN>(r0 + tap), s1 = swz<CIN>(r1 + tap);
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const f32x4 x0 = *(const f32x4*)(p0 + 4 * ((4 * m + q) ^ s0));
-                    const f32x4 x1 = *(const f32x4*)(p1 + 4 * ((4 * m + q) ^ s1));
+                    const f32x4 x0 = operand(r0 + tap, m);
+                    const f32x4 x1 = operand(r1 + tap, m);
                     const f32x4 ww = w[tap * M + m];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -153,45 +185,42 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
                     }
                 }
             }
-            finish(t0, a0, sreg[i < (rc::T2 + 1) / 2 ? i : 0]);
-            finish(t1, a1, sreg[i + 1 < (rc::T2 + 1) / 2 ? i + 1 : 0]);
+            finish(t0, a0, sreg[i < CF::NSREG ? i : 0]);
+            finish(t1, a1, sreg[i + 1 < CF::NSREG ? i + 1 : 0]);
         } else {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
+            // a lone tile: split its k range over the two chains (keeps the MFMA pipe full), add at the end
             const int r0 = in_row(t0);
 #pragma unroll
             for (int tap = 0; tap < KT; ++tap) {
-                const float* p0 = in + (r0 + tap) * CIN;
-                const int s0 = swz<CIN>(r0 + tap);
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const f32x4 x0 = *(const f32x4*)(p0 + 4 * ((4 * m + q) ^ s0));
+                    const f32x4 x0 = operand(r0 + tap, m);
                     const f32x4 ww = w[tap * M + m];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[e], x0[e], a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x0[0], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x0[1], a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x0[2], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x0[3], a1, 0, 0, 0);
                 }
             }
-            finish(t0, a0, sreg[i < (rc::T2 + 1) / 2 ? i : 0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a0[e] += a1[e];
+            finish(t0, a0, sreg[i < CF::NSREG ? i : 0]);
         }
     }
 }
 
-
-// ---- stem ----------------------------------------------------------------------------------------
-// Reference: architectures/read_convolver.py:13-56 (6|7 -> 16 -> 16 -> 32, kernel 3, no padding, ReLU
-// each, then MaxPool1d(3, 2)).  Reads of a sub-batch are stacked at their natural stride of 150 rows, so
-// the three valid convolutions run over the stacked rows as if they were one sequence; rows whose window
-// straddles two reads are garbage that nothing valid ever consumes (a read's pooled outputs only look at
-// its own first 143 conv3 rows).  conv1 reads the bytes themselves: with channels-last bytes the im2col
-// index k = tap*C + c is simply the byte offset from the row start.  conv3 tiles overlap by two rows
-// (stride 14) so each 16-position tile max-pools 7 outputs entirely inside one DPP row.
-__device__ __forceinline__ int sw16(int row) { return (row >> 2) & 3; }
-
+// ---- stem: one sub-batch of CF::SB reads, bytes -> pooled [71][32] rows of the trunk's input image ----
+template <class CF>
 __device__ __forceinline__ void stem_subbatch(const unsigned char* __restrict__ s_u8, float* __restrict__ c1,
                                               float* __restrict__ c2, float* __restrict__ bufA,
                                               const float* __restrict__ W, int ch, int sb, int n_here, int wave,
                                               int lane) {
     using namespace rc;
+    constexpr int NW = CF::NW, SROWS = CF::SROWS, ST12 = CF::ST12, ST3 = CF::ST3, SB = CF::SB;
     const int j = lane & 15, q = lane >> 4;
+    auto row16 = [&](const float* img, int row) -> f32x4 {
+        return *(const f32x4*)(img + row * 16 + 4 * (q ^ swz<16>(row)));
+    };
     // conv1: bytes -> 16 channels
     {
         float w1[S1_STEPS];
@@ -215,8 +244,8 @@ __device__ __forceinline__ void stem_subbatch(const unsigned char* __restrict__ 
                 v0[e] = fmaxf(a0[e] + b4[e], 0.f);
                 v1[e] = fmaxf(a1[e] + b4[e], 0.f);
             }
-            *(f32x4*)(c1 + r0 * 16 + 4 * (q ^ sw16(r0))) = v0;
-            if (t1 != t) *(f32x4*)(c1 + r1 * 16 + 4 * (q ^ sw16(r1))) = v1;
+            if (r0 < SROWS) *(f32x4*)(c1 + r0 * 16 + 4 * (q ^ swz<16>(r0))) = v0;
+            if (t1 != t && r1 < SROWS) *(f32x4*)(c1 + r1 * 16 + 4 * (q ^ swz<16>(r1))) = v1;
         }
     }
     __syncthreads();
@@ -232,8 +261,8 @@ __device__ __forceinline__ void stem_subbatch(const unsigned char* __restrict__ 
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
-                const f32x4 x0 = *(const f32x4*)(c1 + (r0 + tap) * 16 + 4 * (q ^ sw16(r0 + tap)));
-                const f32x4 x1 = *(const f32x4*)(c1 + (r1 + tap) * 16 + 4 * (q ^ sw16(r1 + tap)));
+                const f32x4 x0 = row16(c1, r0 + tap);
+                const f32x4 x1 = row16(c1, r1 + tap);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[tap][e], x0[e], a0, 0, 0, 0);
@@ -246,26 +275,27 @@ __device__ __forceinline__ void stem_subbatch(const unsigned char* __restrict__ 
                 v0[e] = fmaxf(a0[e] + b4[e], 0.f);
                 v1[e] = fmaxf(a1[e] + b4[e], 0.f);
             }
-            *(f32x4*)(c2 + r0 * 16 + 4 * (q ^ sw16(r0))) = v0;
-            if (t1 != t) *(f32x4*)(c2 + r1 * 16 + 4 * (q ^ sw16(r1))) = v1;
+            if (r0 < SROWS) *(f32x4*)(c2 + r0 * 16 + 4 * (q ^ swz<16>(r0))) = v0;
+            if (t1 != t && r1 < SROWS) *(f32x4*)(c2 + r1 * 16 + 4 * (q ^ swz<16>(r1))) = v1;
         }
     }
     __syncthreads();
     // conv3: 16 -> 32, ReLU, MaxPool1d(3, 2) in registers, scatter into the trunk's 32-channel image
     {
+        constexpr int NPG = NW / 2;
         const int cb = wave & 1, pg = wave >> 1;
         f32x4 w3[3];
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) w3[tap] = *(const f32x4*)(W + OFF_S3 + ((cb * 3 + tap) * 64 + lane) * 4);
         const f32x4 b4 = *(const f32x4*)(W + OFF_S3 + 2 * 3 * 256 + cb * 16 + 4 * q);
-        for (int t = pg; t < ST3; t += 8) {
-            const int t1 = (t + 4 < ST3) ? t + 4 : t;
+        for (int t = pg; t < ST3; t += 2 * NPG) {
+            const int t1 = (t + NPG < ST3) ? t + NPG : t;
             const int r0 = 14 * t + j, r1 = 14 * t1 + j;
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
-                const f32x4 x0 = *(const f32x4*)(c2 + (r0 + tap) * 16 + 4 * (q ^ sw16(r0 + tap)));
-                const f32x4 x1 = *(const f32x4*)(c2 + (r1 + tap) * 16 + 4 * (q ^ sw16(r1 + tap)));
+                const f32x4 x0 = row16(c2, r0 + tap);
+                const f32x4 x1 = row16(c2, r1 + tap);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[tap][e], x0[e], a0, 0, 0, 0);
@@ -273,13 +303,13 @@ __device__ __forceinline__ void stem_subbatch(const unsigned char* __restrict__ 
                 }
             }
             auto pool_store = [&](f32x4 acc, int r) {
-                f32x4 v, m;
+                f32x4 m;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaxf(acc[e] + b4[e], 0.f);
-                    const float n1 = __shfl_down(v[e], 1, 16);
-                    const float n2 = __shfl_down(v[e], 2, 16);
-                    m[e] = fmaxf(fmaxf(v[e], n1), n2);
+                    const float v = fmaxf(acc[e] + b4[e], 0.f);
+                    const float n1 = __shfl_down(v, 1, 16);
+                    const float n2 = __shfl_down(v, 2, 16);
+                    m[e] = fmaxf(fmaxf(v, n1), n2);
                 }
                 const int rdl = r / 150;
                 const int i = r - rdl * 150;
@@ -296,13 +326,15 @@ __device__ __forceinline__ void stem_subbatch(const unsigned char* __restrict__ 
     }
 }
 
-template <bool STEM>
-__global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
+template <class CF, bool STEM>
+__global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
+    constexpr int G = CF::G, T1 = CF::T1, T2 = CF::T2, BUF_FLOATS = CF::BUF_FLOATS, THREADS = CF::THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bufA = smem;
     float* bufB = smem + BUF_FLOATS;
     int* s_allele = (int*)(smem + 2 * BUF_FLOATS);
+    unsigned char* s_u8 = (unsigned char*)(smem + 2 * BUF_FLOATS + 16);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -312,29 +344,28 @@ __global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
     const float* __restrict__ W = a.w;
 
     // ---- the trunk's input image [71][32] per read in bufA (pad rows and row 0 zero) ------------------
-    for (int i = tid; i < BUF_FLOATS / 4; i += 512) ((f32x4*)bufA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < BUF_FLOATS / 4; i += THREADS) ((f32x4*)bufA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!STEM && tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
     __syncthreads();
     if (STEM) {
         // computed here from the uint8 pileups, SB reads at a time, temporaries in bufB
-        unsigned char* s_u8 = (unsigned char*)(smem + 2 * BUF_FLOATS + 16);
         const int ch = a.channels;
         const int per_read = 150 * ch;
-        for (int sb = 0; sb < G / SB; ++sb) {
-            const int have = n_here - SB * sb;                       // reads of this sub-batch that exist
-            const int n_bytes = (have < 0 ? 0 : (have > SB ? SB : have)) * per_read;
-            const unsigned char* src = a.reads + (read0 + SB * sb) * per_read;
-            for (int i = tid; i < U8_BYTES; i += 512) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
+        for (int sb = 0; sb < G / CF::SB; ++sb) {
+            const int have = n_here - CF::SB * sb;                    // reads of this sub-batch that exist
+            const int n_bytes = (have < 0 ? 0 : (have > CF::SB ? CF::SB : have)) * per_read;
+            const unsigned char* src = a.reads + (read0 + CF::SB * sb) * per_read;
+            for (int i = tid; i < CF::U8_BYTES; i += THREADS) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
             __syncthreads();
-            stem_subbatch(s_u8, bufB, bufB + C12_ROWS * 16, bufA, W, ch, sb, n_here, wave, lane);
+            stem_subbatch<CF>(s_u8, bufB, bufB + CF::SROWS * 16, bufA, W, ch, sb, n_here, wave, lane);
             __syncthreads();
         }
         if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};   // row 0 of the 32-channel image
     } else {
         const f32x4* src = (const f32x4*)(a.pooled + read0 * (L1 * 32));
         const int n4 = n_here * L1 * 8;
-        for (int f = tid; f < n4; f += 512) {
+        for (int f = tid; f < n4; f += THREADS) {
             const int rd = f / (L1 * 8);
             const int rem = f - rd * (L1 * 8);
             const int p = rem >> 3, c = rem & 7;
@@ -346,7 +377,7 @@ __global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
     f32x4 wa[6], wb[6];
     f32x4 wc[12], wd[12];
     f32x4 wsc[2];
-    f32x4 sreg[(T2 + 1) / 2];
+    f32x4 sreg[CF::NSREG];
 
     // ---- 3 x ResidualBlock(32): x -> relu(conv) -> relu(conv) + x --------------------------------
     load_weights<6>(wa, W + OFF_B, wave % 2, lane);
@@ -355,11 +386,11 @@ __global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
     for (int blk = 0; blk < 3; ++blk) {
         const float* base = W + OFF_B + (2 * blk) * (W3232 + 32);
         load_weights<6>(wb, base + (W3232 + 32), wave % 2, lane);
-        conv_layer<32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN>(bufA, bufB, wa, base + W3232, sreg, wave, lane);
+        conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN>(bufA, bufB, wa, base + W3232, sreg, wave, lane);
         __syncthreads();
         if (blk < 2) load_weights<6>(wa, base + 2 * (W3232 + 32), wave % 2, lane);
-        conv_layer<32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_RESID_INPLACE>(bufB, bufA, wb, base + (W3232 + 32) + W3232,
-                                                                          sreg, wave, lane);
+        conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_RESID_INPLACE>(bufB, bufA, wb, base + (W3232 + 32) + W3232,
+                                                                              sreg, wave, lane);
         __syncthreads();
     }
 
@@ -368,12 +399,12 @@ __global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
     load_weights<2>(wsc, W + OFF_SC, wave % 4, lane);
     load_weights<12>(wc, W + OFF_C2, wave % 4, lane);
     if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};     // zero row 0 of the 64-channel image
-    conv_layer<32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN>(bufA, bufB, wa, W + OFF_C1 + W3264, sreg, wave, lane);
-    conv_layer<32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS>(bufA, nullptr, wsc, W + OFF_SC + W3264S, sreg, wave, lane);
+    conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN>(bufA, bufB, wa, W + OFF_C1 + W3264, sreg, wave, lane);
+    conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS>(bufA, nullptr, wsc, W + OFF_SC + W3264S, sreg, wave, lane);
     __syncthreads();
     if (tid < 16) ((f32x4*)bufA)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_weights<12>(wd, W + OFF_D, wave % 4, lane);
-    conv_layer<64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS>(bufB, bufA, wc, W + OFF_C2 + W6464, sreg, wave, lane);
+    conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS>(bufB, bufA, wc, W + OFF_C2 + W6464, sreg, wave, lane);
     __syncthreads();
 
     // ---- 3 x ResidualBlock(64) --------------------------------------------------------------------
@@ -381,11 +412,11 @@ __global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
     for (int blk = 0; blk < 3; ++blk) {
         const float* base = W + OFF_D + (2 * blk) * (W6464 + 64);
         load_weights<12>(wc, base + (W6464 + 64), wave % 4, lane);
-        conv_layer<64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN>(bufA, bufB, wd, base + W6464, sreg, wave, lane);
+        conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN>(bufA, bufB, wd, base + W6464, sreg, wave, lane);
         __syncthreads();
         if (blk < 2) load_weights<12>(wd, base + 2 * (W6464 + 64), wave % 4, lane);
-        conv_layer<64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE>(bufB, bufA, wc, base + (W6464 + 64) + W6464,
-                                                                          sreg, wave, lane);
+        conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE>(bufB, bufA, wc, base + (W6464 + 64) + W6464,
+                                                                              sreg, wave, lane);
         __syncthreads();
     }
 
@@ -393,7 +424,7 @@ __global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
     {
         const int slot0 = a.slot_of_group[blockIdx.x];
         const int first_allele = s_allele[0];
-        for (int f = tid; f < L2 * 16; f += 512) {
+        for (int f = tid; f < L2 * 16; f += THREADS) {
             const int p = f >> 4, c = f & 15;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             int cur = first_allele;
@@ -414,26 +445,31 @@ __global__ __launch_bounds__(512) void readconv_trunk_kernel(ReadConvArgs a) {
     }
 }
 
-hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
-    if (a.n_reads <= 0) return hipSuccess;
+template <class CF>
+static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)readconv_trunk_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, rc::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)readconv_trunk_kernel<true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, rc::LDS_BYTES_STEM);
+            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    const unsigned groups = (unsigned)((a.n_reads + rc::G - 1) / rc::G);
+    const unsigned groups = (unsigned)((a.n_reads + CF::G - 1) / CF::G);
     if (a.reads) {
         if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(readconv_trunk_kernel<true>, dim3(groups), dim3(512), rc::LDS_BYTES_STEM, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, true>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     } else {
-        hipLaunchKernelGGL(readconv_trunk_kernel<false>, dim3(groups), dim3(512), rc::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, false>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
+    if (a.n_reads <= 0) return hipSuccess;
+    return readconv_cfg() == 0 ? launch_cfg<rc::Cfg<8, 8>>(a, stream) : launch_cfg<rc::Cfg<4, 4>>(a, stream);
 }
 
 // frames[a] = sum over the allele's partial slots, in slot (= read) order
