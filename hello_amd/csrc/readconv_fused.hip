@@ -125,13 +125,31 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     const int j = lane & 15, q = lane >> 4;
     const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
 
+    // Stride-1 layers keep the image geometry: output row r reads input rows r + tap (+1 for the leading
+    // zero row, -PAD).  Then a tile only adds a compile-time constant to the lane's address, the swizzle
+    // term (row & 7 ...) does not depend on the tile, and one address register per (tap, m) serves them all.
+    constexpr bool IDENT = (RS_IN == RS_OUT) && (STRIDE == 1);
     auto in_row = [&](int t) {
         const int r = t * 16 + j;
+        if (IDENT) return r + 1 - PAD;
         const int rd = r / RS_OUT;
         return 1 + rd * RS_IN + (r - rd * RS_OUT) * STRIDE - PAD;
     };
     auto operand = [&](int row, int m) -> f32x4 {
         return *(const f32x4*)(in + row * CIN + 4 * ((4 * m + q) ^ swz<CIN>(row)));
+    };
+    // IDENT layers: one pointer per (tap, m) for the wave's first tile; tile k adds the constant k*NPG*16*CIN,
+    // which the compiler folds into the ds_read offset field (16 t + x keeps x's low bits, so the swizzle
+    // of row 16 t + x is the swizzle of x)
+    const float* opbase[KT * M];
+#pragma unroll
+    for (int s = 0; s < KT * M; ++s) {
+        const int x = j + 1 - PAD + s / M;
+        opbase[s] = in + (16 * pg + x) * CIN + 4 * ((4 * (s % M) + q) ^ swz<CIN>(x));
+    }
+    auto tile_operand = [&](int k, int s) -> f32x4 {     // k-th tile of this wave, step s = tap*M + m
+        if (IDENT) return *(const f32x4*)(opbase[s] + k * NPG * 16 * CIN);
+        return operand(in_row(pg + NPG * k) + s / M, s % M);
     };
     auto finish = [&](int t, f32x4 acc, f32x4& keep) {
         const int r = t * 16 + j;
@@ -163,48 +181,74 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
         }
     };
 
+    // ---- tile pairs, software pipelined over the whole layer --------------------------------------
+    // A step = one (tap, m) of a tile pair = 2 ds_read_b128 + 8 MFMAs.  The two waves of a SIMD run the
+    // same program and fall into lockstep (they reach their LDS waits together), so a wave must hide its
+    // own LDS latency: the operands of step u+DEPTH are requested before the MFMAs of step u are issued,
+    // across tile-pair boundaries, and the order is pinned with sched_barrier.  Each tile accumulates in
+    // two chains (even / odd k steps): with four chains in flight a chain is revisited every 128 cycles,
+    // far beyond the 40-cycle dependent latency of the 32-cycle instruction.
+    constexpr int S = KT * M, NFULL = T / NPG, NP = NFULL / 2, NU = NP * S, DEPTH = 2;
+    f32x4 ring0[DEPTH + 1], ring1[DEPTH + 1];
+    auto issue = [&](int u) {
+        const int i = u / S, s = u % S;
+        ring0[u % (DEPTH + 1)] = tile_operand(2 * i, s);
+        ring1[u % (DEPTH + 1)] = tile_operand(2 * i + 1, s);
+    };
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < ITER; i += 2) {
-        const int t0 = pg + NPG * i, t1 = pg + NPG * (i + 1);
-        if (t0 >= T) break;
-        const bool two = (i + 1 < ITER) && (t1 < T);
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        if (two) {
-            const int r0 = in_row(t0), r1 = in_row(t1);
+    for (int u = 0; u < DEPTH && u < NU; ++u) issue(u);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        if (u + DEPTH < NU) issue(u + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 ww = w[u % S];
+        const f32x4 x0 = ring0[u % (DEPTH + 1)], x1 = ring1[u % (DEPTH + 1)];
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x0[0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x1[0], a1, 0, 0, 0);
+        b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x0[1], b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x1[1], b1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x0[2], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x1[2], a1, 0, 0, 0);
+        b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x0[3], b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x1[3], b1, 0, 0, 0);
+        if (u % S == S - 1) {
+            const int i = u / S;
+            const int tA = pg + NPG * (2 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[e] += b0[e];
+                a1[e] += b1[e];
+            }
+            finish(tA, a0, sreg[2 * i < CF::NSREG ? 2 * i : 0]);
+            finish(tA + NPG, a1, sreg[2 * i + 1 < CF::NSREG ? 2 * i + 1 : 0]);
+            a0 = a1 = b0 = b1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // ---- the wave's remaining tile(s): one if its share is odd, one more if T does not divide ----------
+#pragma unroll
+    for (int i = 2 * NP; i < ITER; ++i) {
+        const int t0 = pg + NPG * i;
+        if (t0 < T) {
+            // a lone tile: its k range is split over two chains, added at the end
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tap = 0; tap < KT; ++tap) {
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const f32x4 x0 = operand(r0 + tap, m);
-                    const f32x4 x1 = operand(r1 + tap, m);
+                    const f32x4 x0 = tile_operand(i, tap * M + m);
                     const f32x4 ww = w[tap * M + m];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[e], x0[e], a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[e], x1[e], a1, 0, 0, 0);
-                    }
-                }
-            }
-            finish(t0, a0, sreg[i < CF::NSREG ? i : 0]);
-            finish(t1, a1, sreg[i + 1 < CF::NSREG ? i + 1 : 0]);
-        } else {
-            // a lone tile: split its k range over the two chains (keeps the MFMA pipe full), add at the end
-            const int r0 = in_row(t0);
-#pragma unroll
-            for (int tap = 0; tap < KT; ++tap) {
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const f32x4 x0 = operand(r0 + tap, m);
-                    const f32x4 ww = w[tap * M + m];
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x0[0], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x0[1], a1, 0, 0, 0);
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x0[2], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x0[3], a1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x0[0], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x0[1], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x0[2], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x0[3], c1, 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a0[e] += a1[e];
-            finish(t0, a0, sreg[i < CF::NSREG ? i : 0]);
+            for (int e = 0; e < 4; ++e) c0[e] += c1[e];
+            finish(t0, c0, sreg[i < CF::NSREG ? i : 0]);
         }
     }
 }

@@ -16,7 +16,9 @@ import numpy as np
 from . import compiler
 from . import netspec as ns
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhello_mi355x.so")
+# HELLO_LIB overrides the library path (kernel experiments); the default is the in-tree build
+_LIB_PATH = os.environ.get("HELLO_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                        "libhello_mi355x.so")
 HELLO_IN_DEVICE, HELLO_OUT_DEVICE, HELLO_LAYOUT_RCL = 1, 2, 4
 
 
