@@ -88,7 +88,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at world size 1)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
