@@ -90,15 +90,8 @@ struct Cfg {
 
 int readconv_weight_floats() { return rc::W_TOTAL; }
 
-static int g_cfg = -1;   // 0: <8,8>, 1: <4,4>
-static int readconv_cfg() {
-    if (g_cfg < 0) {
-        const char* e = std::getenv("HELLO_READCONV_GROUP");
-        g_cfg = (e && std::atoi(e) == 8) ? 0 : 1;
-    }
-    return g_cfg;
-}
-int readconv_reads_per_group() { return readconv_cfg() == 0 ? 8 : 4; }
+using Geometry = rc::Cfg<4, 4>;    // 4 reads x 4 waves per workgroup, two workgroups per CU
+int readconv_reads_per_group() { return Geometry::G; }
 
 // chunk swizzles: 16-byte chunk index of a row XORed with a function of the row
 template <int C>
@@ -115,32 +108,28 @@ __device__ __forceinline__ void load_weights(f32x4 (&w)[NV], const float* __rest
 enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3 };
 
 // One convolution over the whole group.  `in`/`out` are LDS images with CIN / COUT floats per row.
-template <class CF, int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE>
+//   w        this wave's 16-channel weight slice; with ROLL its registers are refilled in place with the
+//            NEXT layer's slice (`next_w`, already offset to this wave's block and lane) right after their
+//            last use, so only one slice is ever resident
+//   padmask  bit k set: row j of the wave's k-th tile is a shared zero row (must be stored as zero)
+//   dump     16 spare LDS bytes: stores of rows past the group are redirected there instead of branching
+template <class CF, int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE,
+          bool ROLL>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* __restrict__ out,
-                                           const f32x4 (&w)[KT * CIN / 16], const float* __restrict__ bias,
-                                           f32x4 (&sreg)[CF::NSREG], int wave, int lane) {
-    constexpr int M = CIN / 16, NCB = COUT / 16, NPG = CF::NW / NCB, ITER = (T + NPG - 1) / NPG;
-    static_assert(NPG >= 1 && NCB * NPG == CF::NW, "waves must tile channel blocks x position groups");
+                                           f32x4 (&w)[KT * CIN / 16], const float* __restrict__ next_w,
+                                           const float* __restrict__ bias, f32x4 (&sreg)[CF::NSREG],
+                                           unsigned padmask, float* __restrict__ dump, int wave, int lane) {
+    constexpr int M = CIN / 16, NCB = COUT / 16, NPG = CF::NW / NCB, ITER = T / NPG;
+    static_assert(NPG >= 1 && NCB * NPG == CF::NW && T % NPG == 0, "waves must tile channel blocks x position groups");
     const int cb = wave % NCB, pg = wave / NCB;
     const int j = lane & 15, q = lane >> 4;
     const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
 
     // Stride-1 layers keep the image geometry: output row r reads input rows r + tap (+1 for the leading
-    // zero row, -PAD).  Then a tile only adds a compile-time constant to the lane's address, the swizzle
-    // term (row & 7 ...) does not depend on the tile, and one address register per (tap, m) serves them all.
+    // zero row, -PAD).  A tile then only adds a compile-time constant to the lane's address (16 t + x keeps
+    // x's low bits, so the swizzle of row 16 t + x is the swizzle of x): one pointer per (tap, m) serves
+    // every tile through the ds_read offset field.
     constexpr bool IDENT = (RS_IN == RS_OUT) && (STRIDE == 1);
-    auto in_row = [&](int t) {
-        const int r = t * 16 + j;
-        if (IDENT) return r + 1 - PAD;
-        const int rd = r / RS_OUT;
-        return 1 + rd * RS_IN + (r - rd * RS_OUT) * STRIDE - PAD;
-    };
-    auto operand = [&](int row, int m) -> f32x4 {
-        return *(const f32x4*)(in + row * CIN + 4 * ((4 * m + q) ^ swz<CIN>(row)));
-    };
-    // IDENT layers: one pointer per (tap, m) for the wave's first tile; tile k adds the constant k*NPG*16*CIN,
-    // which the compiler folds into the ds_read offset field (16 t + x keeps x's low bits, so the swizzle
-    // of row 16 t + x is the swizzle of x)
     const float* opbase[KT * M];
 #pragma unroll
     for (int s = 0; s < KT * M; ++s) {
@@ -149,60 +138,76 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     }
     auto tile_operand = [&](int k, int s) -> f32x4 {     // k-th tile of this wave, step s = tap*M + m
         if (IDENT) return *(const f32x4*)(opbase[s] + k * NPG * 16 * CIN);
-        return operand(in_row(pg + NPG * k) + s / M, s % M);
-    };
-    auto finish = [&](int t, f32x4 acc, f32x4& keep) {
-        const int r = t * 16 + j;
+        const int r = (pg + NPG * k) * 16 + j;
         const int rd = r / RS_OUT;
-        const int p = r - rd * RS_OUT;
+        const int row = 1 + rd * RS_IN + (r - rd * RS_OUT) * STRIDE - PAD + s / M;
+        return *(const f32x4*)(in + row * CIN + 4 * ((4 * (s % M) + q) ^ swz<CIN>(row)));
+    };
+    // output pointer of the k-th tile: base + constant; rows past the group go to the dump slot
+    float* const outbase = out + (16 * pg + j + 1) * COUT + 4 * ((4 * cb + q) ^ swz<COUT>(j + 1));
+    auto out_ptr = [&](int k) -> float* {
+        float* ptr = outbase + k * NPG * 16 * COUT;
+        if ((NPG - 1 + NPG * k) * 16 + 15 >= RS_OUT * CF::G)          // only the last tile(s) can overrun
+            ptr = ((pg + NPG * k) * 16 + j < RS_OUT * CF::G) ? ptr : dump;
+        return ptr;
+    };
+    auto epilogue = [&](int k, f32x4 acc, f32x4 res) {
         f32x4 v;
         if (MODE == MODE_TO_REGS) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[e] + b4[e];
-            keep = v;
+            sreg[k < CF::NSREG ? k : 0] = v;
             return;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[e] + b4[e], 0.f);
-        const int row = r + 1;
-        float* dst = out + row * COUT + 4 * ((4 * cb + q) ^ swz<COUT>(row));
-        if (r < RS_OUT * CF::G) {
-            if (MODE == MODE_RESID_INPLACE) {
-                const f32x4 x = *(const f32x4*)dst;
+        if (MODE == MODE_RESID_INPLACE) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += x[e];
-            }
-            if (MODE == MODE_ADD_REGS) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += keep[e];
-            }
-            if (p >= LOUT) v = f32x4{0.f, 0.f, 0.f, 0.f};          // the shared zero row between reads
-            *(f32x4*)dst = v;
+            for (int e = 0; e < 4; ++e) v[e] += res[e];
         }
+        if (MODE == MODE_ADD_REGS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += sreg[k < CF::NSREG ? k : 0][e];
+        }
+        if ((padmask >> k) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};      // the shared zero row between reads
+        *(f32x4*)out_ptr(k) = v;
+    };
+    auto residual = [&](int k) -> f32x4 {
+        if (MODE == MODE_RESID_INPLACE) return *(const f32x4*)out_ptr(k);
+        return f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
     // ---- tile pairs, software pipelined over the whole layer --------------------------------------
     // A step = one (tap, m) of a tile pair = 2 ds_read_b128 + 8 MFMAs.  The two waves of a SIMD run the
-    // same program and fall into lockstep (they reach their LDS waits together), so a wave must hide its
-    // own LDS latency: the operands of step u+DEPTH are requested before the MFMAs of step u are issued,
-    // across tile-pair boundaries, and the order is pinned with sched_barrier.  Each tile accumulates in
-    // two chains (even / odd k steps): with four chains in flight a chain is revisited every 128 cycles,
-    // far beyond the 40-cycle dependent latency of the 32-cycle instruction.
-    constexpr int S = KT * M, NFULL = T / NPG, NP = NFULL / 2, NU = NP * S, DEPTH = 2;
+    // same program and fall into lockstep (they reach their LDS waits together), so a wave hides its own
+    // latencies: operands of step u+DEPTH are requested before the MFMAs of step u are issued, across pair
+    // boundaries; the finished pair's epilogue (bias, ReLU, residual, store) is deferred into steps 1 and 2
+    // of the next pair, where it fills MFMA issue gaps; its residual input is requested at step 0.  The
+    // order is pinned with sched_barrier.  Each tile accumulates in two chains (even / odd k steps): with
+    // four chains in flight a chain is revisited every 128 cycles, far beyond the 40-cycle dependent latency.
+    constexpr int S = KT * M, NP = ITER / 2, NU = NP * S, DEPTH = 2;
+    constexpr bool DEFER = (MODE != MODE_TO_REGS) && (S >= 3);
+    constexpr bool LONE = (ITER % 2) != 0;
     f32x4 ring0[DEPTH + 1], ring1[DEPTH + 1];
     auto issue = [&](int u) {
-        const int i = u / S, s = u % S;
-        ring0[u % (DEPTH + 1)] = tile_operand(2 * i, s);
-        ring1[u % (DEPTH + 1)] = tile_operand(2 * i + 1, s);
+        ring0[u % (DEPTH + 1)] = tile_operand(2 * (u / S), u % S);
+        ring1[u % (DEPTH + 1)] = tile_operand(2 * (u / S) + 1, u % S);
     };
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a0 = zero4, a1 = zero4, b0 = zero4, b1 = zero4;
+    f32x4 pend0 = zero4, pend1 = zero4, res0 = zero4, res1 = zero4;
 #pragma unroll
     for (int u = 0; u < DEPTH && u < NU; ++u) issue(u);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         if (u + DEPTH < NU) issue(u + DEPTH);
+        if (DEFER && u >= S && u % S == 0) {
+            res0 = residual(2 * (u / S - 1));
+            res1 = residual(2 * (u / S - 1) + 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if (DEFER && u >= S && u % S == 1) epilogue(2 * (u / S - 1), pend0, res0);
+        if (DEFER && u >= S && u % S == 2) epilogue(2 * (u / S - 1) + 1, pend1, res1);
         const f32x4 ww = w[u % S];
         const f32x4 x0 = ring0[u % (DEPTH + 1)], x1 = ring1[u % (DEPTH + 1)];
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x0[0], a0, 0, 0, 0);
@@ -213,43 +218,42 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
         a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x1[2], a1, 0, 0, 0);
         b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x0[3], b0, 0, 0, 0);
         b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x1[3], b1, 0, 0, 0);
+        if (ROLL && !LONE && u >= NU - S) w[u % S] = *(const f32x4*)(next_w + (u % S) * 256);
         if (u % S == S - 1) {
-            const int i = u / S;
-            const int tA = pg + NPG * (2 * i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 a0[e] += b0[e];
                 a1[e] += b1[e];
             }
-            finish(tA, a0, sreg[2 * i < CF::NSREG ? 2 * i : 0]);
-            finish(tA + NPG, a1, sreg[2 * i + 1 < CF::NSREG ? 2 * i + 1 : 0]);
-            a0 = a1 = b0 = b1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (DEFER && u + 1 < NU) {
+                pend0 = a0;
+                pend1 = a1;
+            } else {
+                const int k = 2 * (u / S);
+                epilogue(k, a0, residual(k));
+                epilogue(k + 1, a1, residual(k + 1));
+            }
+            a0 = a1 = b0 = b1 = zero4;
         }
     }
 
-    // ---- the wave's remaining tile(s): one if its share is odd, one more if T does not divide ----------
+    // ---- an odd share leaves one lone tile: its k range is split over two chains ---------------------
+    if (LONE) {
+        constexpr int k = ITER - 1;
+        f32x4 c0 = zero4, c1 = zero4;
 #pragma unroll
-    for (int i = 2 * NP; i < ITER; ++i) {
-        const int t0 = pg + NPG * i;
-        if (t0 < T) {
-            // a lone tile: its k range is split over two chains, added at the end
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tap = 0; tap < KT; ++tap) {
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const f32x4 x0 = tile_operand(i, tap * M + m);
-                    const f32x4 ww = w[tap * M + m];
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x0[0], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x0[1], c1, 0, 0, 0);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x0[2], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x0[3], c1, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c0[e] += c1[e];
-            finish(t0, c0, sreg[i < CF::NSREG ? i : 0]);
+        for (int s = 0; s < S; ++s) {
+            const f32x4 x0 = tile_operand(k, s);
+            const f32x4 ww = w[s];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x0[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x0[1], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x0[2], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x0[3], c1, 0, 0, 0);
+            if (ROLL) w[s] = *(const f32x4*)(next_w + s * 256);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c0[e] += c1[e];
+        epilogue(k, c0, residual(k));
     }
 }
 
@@ -374,18 +378,31 @@ template <class CF, bool STEM>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
     constexpr int G = CF::G, T1 = CF::T1, T2 = CF::T2, BUF_FLOATS = CF::BUF_FLOATS, THREADS = CF::THREADS;
+    static_assert(CF::NW == 4, "the layer schedule below maps 4 waves to (2 blocks x 2 groups) / (4 blocks)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bufA = smem;
     float* bufB = smem + BUF_FLOATS;
-    int* s_allele = (int*)(smem + 2 * BUF_FLOATS);
+    int* s_allele = (int*)(smem + 2 * BUF_FLOATS);           // G ints
+    float* dump = smem + 2 * BUF_FLOATS + 12;                 // 16 spare bytes of the same 64-byte block
     unsigned char* s_u8 = (unsigned char*)(smem + 2 * BUF_FLOATS + 16);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    const int j = lane & 15;
     const long long read0 = (long long)blockIdx.x * G;
     const int n_here = (int)((a.n_reads - read0) < G ? (a.n_reads - read0) : G);
     const float* __restrict__ W = a.w;
+
+    // which of a lane's rows are shared zero rows: bit k = the wave's k-th tile, per image geometry
+    unsigned pad1 = 0, pad2 = 0;
+    {
+        const int pg1 = wave / 2;                              // 32-channel layers: 2 blocks x 2 position groups
+#pragma unroll
+        for (int k = 0; k < T1 / 2; ++k) pad1 |= ((((pg1 + 2 * k) * 16 + j) % RS1) >= L1 ? 1u : 0u) << k;
+#pragma unroll
+        for (int k = 0; k < T2; ++k) pad2 |= (((k * 16 + j) % RS2) >= L2 ? 1u : 0u) << k;
+    }
 
     // ---- the trunk's input image [71][32] per read in bufA (pad rows and row 0 zero) ------------------
     for (int i = tid; i < BUF_FLOATS / 4; i += THREADS) ((f32x4*)bufA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -418,49 +435,54 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         }
     }
 
-    f32x4 wa[6], wb[6];
-    f32x4 wc[12], wd[12];
-    f32x4 wsc[2];
+    f32x4 w6[6], w12[12], w2[2];
     f32x4 sreg[CF::NSREG];
+    const int cb2 = wave % 2, cb4 = wave;
+    auto slice = [&](int off, int cb, int nv) { return W + off + cb * nv * 256 + lane * 4; };   // this wave's block, this lane
 
     // ---- 3 x ResidualBlock(32): x -> relu(conv) -> relu(conv) + x --------------------------------
-    load_weights<6>(wa, W + OFF_B, wave % 2, lane);
+    load_weights<6>(w6, W + OFF_B, cb2, lane);
     __syncthreads();
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
-        const float* base = W + OFF_B + (2 * blk) * (W3232 + 32);
-        load_weights<6>(wb, base + (W3232 + 32), wave % 2, lane);
-        conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN>(bufA, bufB, wa, base + W3232, sreg, wave, lane);
+        const int off_a = OFF_B + (2 * blk) * (W3232 + 32), off_b = off_a + (W3232 + 32);
+        conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN, true>(
+            bufA, bufB, w6, slice(off_b, cb2, 6), W + off_a + W3232, sreg, pad1, dump, wave, lane);
         __syncthreads();
-        if (blk < 2) load_weights<6>(wa, base + 2 * (W3232 + 32), wave % 2, lane);
-        conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_RESID_INPLACE>(bufB, bufA, wb, base + (W3232 + 32) + W3232,
-                                                                              sreg, wave, lane);
+        // the block's second conv rolls in the next block's first conv, or the strided conv (4 channel blocks)
+        const float* nxt = (blk < 2) ? slice(off_b + (W3232 + 32), cb2, 6) : slice(OFF_C1, cb4, 6);
+        conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_RESID_INPLACE, true>(
+            bufB, bufA, w6, nxt, W + off_b + W3232, sreg, pad1, dump, wave, lane);
         __syncthreads();
     }
 
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
-    load_weights<6>(wa, W + OFF_C1, wave % 4, lane);
-    load_weights<2>(wsc, W + OFF_SC, wave % 4, lane);
-    load_weights<12>(wc, W + OFF_C2, wave % 4, lane);
+    load_weights<2>(w2, W + OFF_SC, cb4, lane);
+    load_weights<12>(w12, W + OFF_C2, cb4, lane);
     if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};     // zero row 0 of the 64-channel image
-    conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN>(bufA, bufB, wa, W + OFF_C1 + W3264, sreg, wave, lane);
-    conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS>(bufA, nullptr, wsc, W + OFF_SC + W3264S, sreg, wave, lane);
+    conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false>(
+        bufA, bufB, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
+    conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS, false>(
+        bufA, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
     __syncthreads();
     if (tid < 16) ((f32x4*)bufA)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load_weights<12>(wd, W + OFF_D, wave % 4, lane);
-    conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS>(bufB, bufA, wc, W + OFF_C2 + W6464, sreg, wave, lane);
+    conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true>(
+        bufB, bufA, w12, slice(OFF_D, cb4, 12), W + OFF_C2 + W6464, sreg, pad2, dump, wave, lane);
     __syncthreads();
 
     // ---- 3 x ResidualBlock(64) --------------------------------------------------------------------
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
-        const float* base = W + OFF_D + (2 * blk) * (W6464 + 64);
-        load_weights<12>(wc, base + (W6464 + 64), wave % 4, lane);
-        conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN>(bufA, bufB, wd, base + W6464, sreg, wave, lane);
+        const int off_a = OFF_D + (2 * blk) * (W6464 + 64), off_b = off_a + (W6464 + 64);
+        conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN, true>(
+            bufA, bufB, w12, slice(off_b, cb4, 12), W + off_a + W6464, sreg, pad2, dump, wave, lane);
         __syncthreads();
-        if (blk < 2) load_weights<12>(wd, base + 2 * (W6464 + 64), wave % 4, lane);
-        conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE>(bufB, bufA, wc, base + (W6464 + 64) + W6464,
-                                                                              sreg, wave, lane);
+        if (blk < 2)
+            conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, true>(
+                bufB, bufA, w12, slice(off_b + (W6464 + 64), cb4, 12), W + off_b + W6464, sreg, pad2, dump, wave, lane);
+        else
+            conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, false>(
+                bufB, bufA, w12, nullptr, W + off_b + W6464, sreg, pad2, dump, wave, lane);
         __syncthreads();
     }
 
@@ -513,7 +535,7 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
 
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
     if (a.n_reads <= 0) return hipSuccess;
-    return readconv_cfg() == 0 ? launch_cfg<rc::Cfg<8, 8>>(a, stream) : launch_cfg<rc::Cfg<4, 4>>(a, stream);
+    return launch_cfg<Geometry>(a, stream);
 }
 
 // frames[a] = sum over the allele's partial slots, in slot (= read) order
