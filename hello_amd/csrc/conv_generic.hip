@@ -6,14 +6,13 @@
 // combiner, meta) and as the layer-by-layer path for read convolvers the fused kernel does not cover.
 //
 // Tiling (wave64, v_mfma_f32_32x32x2_f32, exact fp32 == k-ordered fmaf chain):
-//   workgroup = 256 threads = 4 waves, output tile 128 positions x (32*NCB) channels;
+//   workgroup = 256 threads = 4 waves, output tile 128 positions x (32*NCB) channels, NCB = 1, 2 or 4;
 //   GEMM orientation D[channel][position] = W[channel][k] * X[k][position]  (A = weights, B = activations)
 //   so that each lane ends up with 4 consecutive channels of ONE position per accumulator quad ->
 //   bias/ReLU/residual/store are 16-byte vector ops on the channels-last tensors.
-//   K is walked in chunks of 32 through LDS; rows are padded to 36 floats, which makes the
-//   ds_read_b128 operand reads (16 lanes x 16 B, row stride 144 B) bank-conflict free.
-//   Within an 8-wide k group lane-half h supplies k = 8g + 4h + t at MFMA step t for BOTH operands, so
-//   one ds_read_b128 per operand feeds four MFMAs.
+//   K is walked in chunks of KC = 32 through LDS; rows are padded by 4 floats, which makes the
+//   ds_read_b128 operand reads (16 lanes x 16 B, row stride 144 B) bank-conflict free.  Within an 8-wide k group lane-half h supplies k = 8g + 4h + t at MFMA step t for BOTH operands,
+//   so one ds_read_b128 per operand feeds four MFMAs.
 //   The next chunk is prefetched global->registers while the current one is multiplied.
 #include "kernels.h"
 
@@ -23,31 +22,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int BM = 128;   // positions per workgroup
-static constexpr int KC = 32;    // K chunk
-static constexpr int LDS_LD = 36;
 
 template <typename SrcT>
 __device__ __forceinline__ float load_scalar(const SrcT* p) { return (float)(*p); }
 
-template <int NCB, typename SrcT, bool VEC>
+template <int NCB, typename SrcT, bool VEC, int KC>
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_act[BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float s_w[NCB * 32 * LDS_LD];
+    constexpr int LD = KC + 4;                // LDS row stride (floats)
+    constexpr int QPR = KC / 4;               // float4 per row of a chunk
+    constexpr int RPP = 256 / QPR;            // rows covered per pass of the 256 threads
+    constexpr int NA = BM / RPP;              // activation float4 per thread per chunk
+    constexpr int NWV = (NCB * 32) / RPP;     // weight float4 per thread per chunk
+    __shared__ __attribute__((aligned(16))) float s_act[BM * LD];
+    __shared__ __attribute__((aligned(16))) float s_w[NCB * 32 * LD];
 
     const int t = threadIdx.x;
-    const int kq = t & 7;            // which float4 of the 32-wide chunk
-    const int lrow = t >> 3;         // 0..31
+    const int kq = t % QPR;          // which float4 of the chunk
+    const int lrow = t / QPR;
     const long long m0 = (long long)blockIdx.x * BM;
     const int cb0 = blockIdx.y * (32 * NCB);
     const SrcT* src = (const SrcT*)a.src;
     const int kreal = a.k * a.cin;
 
-    // per-thread gather rows: m = lrow + 32*j
-    long long row_base[4];   // item * lin
-    int pos_base[4];         // p*stride - pad, or a large negative number for rows past the end
+    // per-thread gather rows: m = lrow + RPP*j
+    long long row_base[NA];  // item * lin
+    int pos_base[NA];        // p*stride - pad, or a large negative number for rows past the end
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        long long mg = m0 + lrow + 32 * j;
+    for (int j = 0; j < NA; ++j) {
+        long long mg = m0 + lrow + RPP * j;
         if (mg < a.m_total) {
             long long item = mg / a.lout;
             int p = (int)(mg - item * a.lout);
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
         }
     }
 
-    f32x4 ra[4];
-    f32x4 rw[NCB];
+    f32x4 ra[NA];
+    f32x4 rw[NWV];
 
     auto prefetch = [&](int kbase) {
         const int kk = kbase + kq * 4;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
             const int tap = kk / a.cin;
             const int c = kk - tap * a.cin;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NA; ++j) {
                 const int pos = pos_base[j] + tap;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (kk < kreal && pos >= 0 && pos < a.lin)
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NA; ++j) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -93,41 +95,50 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < NCB; ++j)
-            rw[j] = *(const f32x4*)(a.w + (long long)(cb0 + lrow + 32 * j) * a.kpad + kk);
+        for (int j = 0; j < NWV; ++j)
+            rw[j] = *(const f32x4*)(a.w + (long long)(cb0 + lrow + RPP * j) * a.kpad + kk);
     };
 
+    // wave grid: NCB = 1: 1 channel block x 4 position tiles; NCB = 2: 2 x 2 waves, each 1 block x 2 tiles;
+    // NCB = 4: 2 x 2 waves, each 2 blocks x 2 tiles (every operand fragment feeds two MFMA tiles)
     const int wave = t >> 6, lane = t & 63;
     const int lj = lane & 31, lh = lane >> 5;
-    constexpr int TP = (NCB == 2) ? 2 : 1;
-    const int wn = (NCB == 2) ? (wave & 1) : 0;
-    const int ptile0 = (NCB == 2) ? (wave >> 1) * 64 : wave * 32;
+    constexpr int TP = (NCB >= 2) ? 2 : 1;
+    constexpr int CBW = (NCB == 4) ? 2 : 1;
+    const int wn = (NCB >= 2) ? (wave & 1) * CBW : 0;          // first channel block of this wave
+    const int ptile0 = (NCB >= 2) ? (wave >> 1) * 64 : wave * 32;
 
-    f32x16 acc[TP];
+    f32x16 acc[CBW][TP];
 #pragma unroll
-    for (int tp = 0; tp < TP; ++tp)
+    for (int cw = 0; cw < CBW; ++cw)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+        for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cw][tp][r] = 0.f;
 
     prefetch(0);
     for (int kbase = 0; kbase < a.kpad; kbase += KC) {
         __syncthreads();   // previous chunk's MFMA reads are done
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(f32x4*)&s_act[(lrow + 32 * j) * LDS_LD + kq * 4] = ra[j];
+        for (int j = 0; j < NA; ++j) *(f32x4*)&s_act[(lrow + RPP * j) * LD + kq * 4] = ra[j];
 #pragma unroll
-        for (int j = 0; j < NCB; ++j) *(f32x4*)&s_w[(lrow + 32 * j) * LDS_LD + kq * 4] = rw[j];
+        for (int j = 0; j < NWV; ++j) *(f32x4*)&s_w[(lrow + RPP * j) * LD + kq * 4] = rw[j];
         __syncthreads();
         if (kbase + KC < a.kpad) prefetch(kbase + KC);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 wa = *(const f32x4*)&s_w[(wn * 32 + lj) * LDS_LD + g * 8 + lh * 4];
+        for (int g = 0; g < KC / 8; ++g) {
+            f32x4 wa[CBW], xb[TP];
 #pragma unroll
-            for (int tp = 0; tp < TP; ++tp) {
-                const f32x4 xb = *(const f32x4*)&s_act[(ptile0 + tp * 32 + lj) * LDS_LD + g * 8 + lh * 4];
+            for (int cw = 0; cw < CBW; ++cw) wa[cw] = *(const f32x4*)&s_w[((wn + cw) * 32 + lj) * LD + g * 8 + lh * 4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[e], xb[e], acc[tp], 0, 0, 0);
-            }
+            for (int tp = 0; tp < TP; ++tp) xb[tp] = *(const f32x4*)&s_act[(ptile0 + tp * 32 + lj) * LD + g * 8 + lh * 4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int cw = 0; cw < CBW; ++cw)
+#pragma unroll
+                    for (int tp = 0; tp < TP; ++tp)
+                        acc[cw][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cw][e], xb[tp][e], acc[cw][tp], 0, 0, 0);
         }
     }
 
@@ -137,43 +148,57 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
         const long long mg = m0 + ptile0 + tp * 32 + lj;
         if (mg >= a.m_total) continue;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ch = cb0 + wn * 32 + 8 * q + 4 * lh;
-            if (ch >= a.cout) continue;
-            const f32x4 b4 = *(const f32x4*)(a.bias + ch);
-            f32x4 v;
+        for (int cw = 0; cw < CBW; ++cw) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = acc[tp][4 * q + e] + b4[e];
-                v[e] = a.relu ? fmaxf(x, 0.f) : x;
-            }
-            const long long o = mg * a.cout + ch;
-            if (a.res) {
-                const f32x4 r4 = *(const f32x4*)(a.res + o);
+            for (int q = 0; q < 4; ++q) {
+                const int ch = cb0 + (wn + cw) * 32 + 8 * q + 4 * lh;
+                if (ch >= a.cout) continue;
+                const f32x4 b4 = *(const f32x4*)(a.bias + ch);
+                f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[cw][tp][4 * q + e] + b4[e];
+                    v[e] = a.relu ? fmaxf(x, 0.f) : x;
+                }
+                const long long o = mg * a.cout + ch;
+                if (a.res) {
+                    const f32x4 r4 = *(const f32x4*)(a.res + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                }
+                *(f32x4*)(a.dst + o) = v;
             }
-            *(f32x4*)(a.dst + o) = v;
         }
     }
+}
+
+template <int NCB, typename SrcT, bool VEC>
+static void launch_kc(const ConvArgs& a, dim3 grid, hipStream_t stream) {
+    // KC = 64 was measured 3-12 % slower on the allele-stage layers (52 KB of LDS per workgroup costs
+    // two resident workgroups per CU); 32 it is
+    hipLaunchKernelGGL((conv1d_mfma_kernel<NCB, SrcT, VEC, 32>), grid, dim3(256), 0, stream, a);
 }
 
 hipError_t launch_conv1d(const ConvArgs& a, hipStream_t stream) {
     if (a.m_total <= 0) return hipSuccess;
     const unsigned gx = (unsigned)((a.m_total + BM - 1) / BM);
     const bool two = (a.cout_pad % 64) == 0;
-    const dim3 grid(gx, two ? a.cout_pad / 64 : a.cout_pad / 32);
-    const dim3 block(256);
     const bool vec = !a.src_u8 && (a.cin % 4 == 0);
+    if (vec && (a.cout_pad % 128) == 0) {
+        // 128 channels per workgroup: the activation tile is gathered once for four channel blocks
+        launch_kc<4, float, true>(a, dim3(gx, a.cout_pad / 128), stream);
+        return hipGetLastError();
+    }
+    const dim3 grid(gx, two ? a.cout_pad / 64 : a.cout_pad / 32);
     if (a.src_u8) {
-        if (two) hipLaunchKernelGGL((conv1d_mfma_kernel<2, uint8_t, false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((conv1d_mfma_kernel<1, uint8_t, false>), grid, block, 0, stream, a);
+        if (two) launch_kc<2, uint8_t, false>(a, grid, stream);
+        else launch_kc<1, uint8_t, false>(a, grid, stream);
     } else if (vec) {
-        if (two) hipLaunchKernelGGL((conv1d_mfma_kernel<2, float, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((conv1d_mfma_kernel<1, float, true>), grid, block, 0, stream, a);
+        if (two) launch_kc<2, float, true>(a, grid, stream);
+        else launch_kc<1, float, true>(a, grid, stream);
     } else {
-        if (two) hipLaunchKernelGGL((conv1d_mfma_kernel<2, float, false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((conv1d_mfma_kernel<1, float, false>), grid, block, 0, stream, a);
+        if (two) launch_kc<2, float, false>(a, grid, stream);
+        else launch_kc<1, float, false>(a, grid, stream);
     }
     return hipGetLastError();
 }
