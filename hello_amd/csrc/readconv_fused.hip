@@ -73,12 +73,13 @@ struct Cfg {
     static constexpr int T2 = (RS2 * G_ + 15) / 16;    // ... at 64 channels
     static constexpr int ROWS1 = RS1 * G_ + 1;         // rows of the 32-channel image (row 0 = leading zero row)
     static constexpr int ROWS2 = RS2 * G_ + 1;
-    static constexpr int SB = G_ / 2;                  // reads per stem sub-batch
+    static constexpr int SB = G_;                      // the stem runs over all reads of the group at once
     static constexpr int SROWS = 150 * SB;
-    static constexpr int ST12 = (SROWS + 15) / 16;     // tiles of stem conv1 / conv2
-    static constexpr int ST3 = (SROWS + 13) / 14;      // tiles of stem conv3 (16 positions, stride 14)
-    static constexpr int BUF_FLOATS = cmax(cmax(ROWS2 * 64, ROWS1 * 32), 2 * SROWS * 16);
-    static constexpr int U8_BYTES = ((SROWS + 24) * 7 + 15) / 16 * 16;
+    static constexpr int ST12 = ((SROWS + 15) / 16 + 3) / 4 * 4;   // tiles of stem conv1 / conv2 (4 position groups)
+    static constexpr int ST3 = ((SROWS + 13) / 14 + 3) / 4 * 4;    // tiles of stem conv3: 16 positions, stride 14
+    static constexpr int BUF_FLOATS = cmax(cmax(ROWS2 * 64, ROWS1 * 32), SROWS * 16);
+    static constexpr int U8_BYTES = ((ST12 * 16 + 8) * 7 + 15) / 16 * 16;   // every conv1 tile reads in bounds
+
     static constexpr int NSREG = (T2 * 4 + NW_ - 1) / NW_;   // shortcut tiles a wave keeps in registers
     // Tiles past the last read of the group are computed and discarded; their operand reads run up to
     // (T2*16 + 2) rows of 64 floats past the start of the SECOND image, so the allocation covers that
@@ -105,7 +106,15 @@ __device__ __forceinline__ void load_weights(f32x4 (&w)[NV], const float* __rest
     for (int i = 0; i < NV; ++i) w[i] = *(const f32x4*)(base + ((cb * NV + i) * 64 + lane) * 4);
 }
 
-enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3 };
+enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3, MODE_POOL = 4 };
+enum { GEOM_TRUNK = 0, GEOM_STEM = 1 };
+
+// value of lane+n of the same 16-lane row (DPP row_shl); lanes shifted in from outside keep their own value
+__device__ __forceinline__ float row_shl(float v, int n) {
+    const int vi = __float_as_int(v);
+    return __int_as_float(n == 1 ? __builtin_amdgcn_update_dpp(vi, vi, 0x101, 0xf, 0xf, false)
+                                 : __builtin_amdgcn_update_dpp(vi, vi, 0x102, 0xf, 0xf, false));
+}
 
 // One convolution over the whole group.  `in`/`out` are LDS images with CIN / COUT floats per row.
 //   w        this wave's 16-channel weight slice; with ROLL its registers are refilled in place with the
@@ -113,12 +122,16 @@ enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS =
 //            last use, so only one slice is ever resident
 //   padmask  bit k set: row j of the wave's k-th tile is a shared zero row (must be stored as zero)
 //   dump     16 spare LDS bytes: stores of rows past the group are redirected there instead of branching
+//   GEOM     GEOM_TRUNK: images with a leading zero row and RS_IN / RS_OUT rows per read;  GEOM_STEM: the stem's
+//            flat stacks (150 rows per read, no leading row): tile t starts at row TS*t, valid convolution
+//   VROWS    output rows >= VROWS are discarded;  `aux` = reads present in the group (MODE_POOL only)
 template <class CF, int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE,
-          bool ROLL>
+          bool ROLL, int GEOM = GEOM_TRUNK, int TS = 16, int VROWS = RS_OUT * CF::G>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* __restrict__ out,
                                            f32x4 (&w)[KT * CIN / 16], const float* __restrict__ next_w,
                                            const float* __restrict__ bias, f32x4 (&sreg)[CF::NSREG],
-                                           unsigned padmask, float* __restrict__ dump, int wave, int lane) {
+                                           unsigned padmask, float* __restrict__ dump, int wave, int lane,
+                                           int aux = 0) {
     constexpr int M = CIN / 16, NCB = COUT / 16, NPG = CF::NW / NCB, ITER = T / NPG;
     static_assert(NPG >= 1 && NCB * NPG == CF::NW && T % NPG == 0, "waves must tile channel blocks x position groups");
     const int cb = wave % NCB, pg = wave / NCB;
@@ -129,30 +142,54 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     // zero row, -PAD).  A tile then only adds a compile-time constant to the lane's address (16 t + x keeps
     // x's low bits, so the swizzle of row 16 t + x is the swizzle of x): one pointer per (tap, m) serves
     // every tile through the ds_read offset field.
-    constexpr bool IDENT = (RS_IN == RS_OUT) && (STRIDE == 1);
+    constexpr bool IDENT = (GEOM == GEOM_STEM) ? (TS == 16) : ((RS_IN == RS_OUT) && (STRIDE == 1));
+    constexpr int LEAD = (GEOM == GEOM_STEM) ? 0 : 1;
     const float* opbase[KT * M];
 #pragma unroll
     for (int s = 0; s < KT * M; ++s) {
-        const int x = j + 1 - PAD + s / M;
+        const int x = j + LEAD - PAD + s / M;
         opbase[s] = in + (16 * pg + x) * CIN + 4 * ((4 * (s % M) + q) ^ swz<CIN>(x));
     }
     auto tile_operand = [&](int k, int s) -> f32x4 {     // k-th tile of this wave, step s = tap*M + m
         if (IDENT) return *(const f32x4*)(opbase[s] + k * NPG * 16 * CIN);
-        const int r = (pg + NPG * k) * 16 + j;
-        const int rd = r / RS_OUT;
-        const int row = 1 + rd * RS_IN + (r - rd * RS_OUT) * STRIDE - PAD + s / M;
+        int row;
+        if (GEOM == GEOM_STEM) {
+            row = TS * (pg + NPG * k) + j + s / M;
+        } else {
+            const int r = (pg + NPG * k) * 16 + j;
+            const int rd = r / RS_OUT;
+            row = 1 + rd * RS_IN + (r - rd * RS_OUT) * STRIDE - PAD + s / M;
+        }
         return *(const f32x4*)(in + row * CIN + 4 * ((4 * (s % M) + q) ^ swz<CIN>(row)));
     };
     // output pointer of the k-th tile: base + constant; rows past the group go to the dump slot
-    float* const outbase = out + (16 * pg + j + 1) * COUT + 4 * ((4 * cb + q) ^ swz<COUT>(j + 1));
+    float* const outbase = out + (16 * pg + j + LEAD) * COUT + 4 * ((4 * cb + q) ^ swz<COUT>(j + LEAD));
     auto out_ptr = [&](int k) -> float* {
         float* ptr = outbase + k * NPG * 16 * COUT;
-        if ((NPG - 1 + NPG * k) * 16 + 15 >= RS_OUT * CF::G)          // only the last tile(s) can overrun
-            ptr = ((pg + NPG * k) * 16 + j < RS_OUT * CF::G) ? ptr : dump;
+        if ((NPG - 1 + NPG * k) * 16 + 15 >= VROWS)                   // only the last tile(s) can overrun
+            ptr = ((pg + NPG * k) * 16 + j < VROWS) ? ptr : dump;
         return ptr;
     };
     auto epilogue = [&](int k, f32x4 acc, f32x4 res) {
         f32x4 v;
+        if (MODE == MODE_POOL) {
+            // stem conv3: ReLU, MaxPool1d(3, 2) over positions j, j+1, j+2 of the lane row, then scatter the
+            // even lanes' result into the trunk's 32-channel image (row 1 + read*72 + p)
+            f32x4 m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = fmaxf(acc[e] + b4[e], 0.f);
+                m[e] = fmaxf(fmaxf(x0, row_shl(x0, 1)), row_shl(x0, 2));
+            }
+            const int r = TS * (pg + NPG * k) + j;
+            const int rd = r / 150;
+            const int p = (r - rd * 150) >> 1;
+            const int row = 1 + rd * rc::RS1 + p;
+            float* ptr = out + row * 32 + 4 * ((4 * cb + q) ^ swz<32>(row));
+            const bool ok = ((j & 1) == 0) && (j <= 12) && (p < rc::L1) && (rd < aux);
+            *(f32x4*)(ok ? ptr : dump) = m;
+            return;
+        }
         if (MODE == MODE_TO_REGS) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[e] + b4[e];
@@ -257,119 +294,59 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     }
 }
 
-// ---- stem: one sub-batch of CF::SB reads, bytes -> pooled [71][32] rows of the trunk's input image ----
+// ---- stem conv1: pileup bytes -> 16 channels (valid convolution over the stacked reads) ---------------
+// The bytes are read as they are (no float copy): lane (j, q) of a tile needs k = 4*step + q of row j, and
+// k = tap*C + c is the byte offset from the row start.  Tiles of a wave: t = wave + 4*i; pairs of tiles in
+// flight; the bytes of the next pair are requested before the MFMAs of the current one.
 template <class CF>
-__device__ __forceinline__ void stem_subbatch(const unsigned char* __restrict__ s_u8, float* __restrict__ c1,
-                                              float* __restrict__ c2, float* __restrict__ bufA,
-                                              const float* __restrict__ W, int ch, int sb, int n_here, int wave,
-                                              int lane) {
+__device__ __forceinline__ void stem_conv1(const unsigned char* __restrict__ s_u8, float* __restrict__ c1,
+                                           const float* __restrict__ W, int ch, float* __restrict__ dump, int wave,
+                                           int lane) {
     using namespace rc;
-    constexpr int NW = CF::NW, SROWS = CF::SROWS, ST12 = CF::ST12, ST3 = CF::ST3, SB = CF::SB;
+    constexpr int NPAIR = CF::ST12 / 8;          // 4 waves x 2 tiles per pair
+    static_assert(CF::ST12 % 8 == 0, "stem tiles must split into pairs over 4 waves");
     const int j = lane & 15, q = lane >> 4;
-    auto row16 = [&](const float* img, int row) -> f32x4 {
-        return *(const f32x4*)(img + row * 16 + 4 * (q ^ swz<16>(row)));
-    };
-    // conv1: bytes -> 16 channels
-    {
-        float w1[S1_STEPS];
+    float w1[S1_STEPS];
 #pragma unroll
-        for (int s = 0; s < S1_STEPS; ++s) w1[s] = W[OFF_S1 + s * 64 + lane];
-        const f32x4 b4 = *(const f32x4*)(W + OFF_S1 + S1_STEPS * 64 + 4 * q);
-        for (int t = wave; t < ST12; t += 2 * NW) {
-            const int t1 = (t + NW < ST12) ? t + NW : t;
-            const int r0 = 16 * t + j, r1 = 16 * t1 + j;
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S1_STEPS; ++s) w1[s] = W[OFF_S1 + s * 64 + lane];
+    const f32x4 b4 = *(const f32x4*)(W + OFF_S1 + S1_STEPS * 64 + 4 * q);
+    const unsigned char* base = s_u8 + (16 * wave + j) * ch + q;       // tile `wave`, row j, byte q
+    const int tile_bytes = 16 * ch;
+    unsigned char cur0[S1_STEPS], cur1[S1_STEPS], nxt0[S1_STEPS], nxt1[S1_STEPS];
+#pragma unroll
+    for (int s = 0; s < S1_STEPS; ++s) {
+        cur0[s] = base[4 * s];
+        cur1[s] = base[4 * tile_bytes + 4 * s];
+    }
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+        if (i + 1 < NPAIR) {
 #pragma unroll
             for (int s = 0; s < S1_STEPS; ++s) {
-                const float x0 = (float)s_u8[r0 * ch + 4 * s + q];
-                const float x1 = (float)s_u8[r1 * ch + 4 * s + q];
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], x0, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], x1, a1, 0, 0, 0);
+                nxt0[s] = base[(8 * (i + 1)) * tile_bytes + 4 * s];
+                nxt1[s] = base[(8 * (i + 1) + 4) * tile_bytes + 4 * s];
             }
-            f32x4 v0, v1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v0[e] = fmaxf(a0[e] + b4[e], 0.f);
-                v1[e] = fmaxf(a1[e] + b4[e], 0.f);
-            }
-            if (r0 < SROWS) *(f32x4*)(c1 + r0 * 16 + 4 * (q ^ swz<16>(r0))) = v0;
-            if (t1 != t && r1 < SROWS) *(f32x4*)(c1 + r1 * 16 + 4 * (q ^ swz<16>(r1))) = v1;
         }
-    }
-    __syncthreads();
-    // conv2: 16 -> 16
-    {
-        f32x4 w2[3];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) w2[tap] = *(const f32x4*)(W + OFF_S2 + (tap * 64 + lane) * 4);
-        const f32x4 b4 = *(const f32x4*)(W + OFF_S2 + 3 * 256 + 4 * q);
-        for (int t = wave; t < ST12; t += 2 * NW) {
-            const int t1 = (t + NW < ST12) ? t + NW : t;
-            const int r0 = 16 * t + j, r1 = 16 * t1 + j;
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap) {
-                const f32x4 x0 = row16(c1, r0 + tap);
-                const f32x4 x1 = row16(c1, r1 + tap);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[tap][e], x0[e], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[tap][e], x1[e], a1, 0, 0, 0);
-                }
-            }
-            f32x4 v0, v1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v0[e] = fmaxf(a0[e] + b4[e], 0.f);
-                v1[e] = fmaxf(a1[e] + b4[e], 0.f);
-            }
-            if (r0 < SROWS) *(f32x4*)(c2 + r0 * 16 + 4 * (q ^ swz<16>(r0))) = v0;
-            if (t1 != t && r1 < SROWS) *(f32x4*)(c2 + r1 * 16 + 4 * (q ^ swz<16>(r1))) = v1;
+        for (int s = 0; s < S1_STEPS; ++s) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], (float)cur0[s], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], (float)cur1[s], a1, 0, 0, 0);
         }
-    }
-    __syncthreads();
-    // conv3: 16 -> 32, ReLU, MaxPool1d(3, 2) in registers, scatter into the trunk's 32-channel image
-    {
-        constexpr int NPG = NW / 2;
-        const int cb = wave & 1, pg = wave >> 1;
-        f32x4 w3[3];
+        const int r0 = 16 * (wave + 8 * i) + j, r1 = r0 + 64;
+        f32x4 v0, v1;
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) w3[tap] = *(const f32x4*)(W + OFF_S3 + ((cb * 3 + tap) * 64 + lane) * 4);
-        const f32x4 b4 = *(const f32x4*)(W + OFF_S3 + 2 * 3 * 256 + cb * 16 + 4 * q);
-        for (int t = pg; t < ST3; t += 2 * NPG) {
-            const int t1 = (t + NPG < ST3) ? t + NPG : t;
-            const int r0 = 14 * t + j, r1 = 14 * t1 + j;
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = fmaxf(a0[e] + b4[e], 0.f);
+            v1[e] = fmaxf(a1[e] + b4[e], 0.f);
+        }
+        *(f32x4*)(r0 < CF::SROWS ? c1 + r0 * 16 + 4 * (q ^ swz<16>(r0)) : dump) = v0;
+        *(f32x4*)(r1 < CF::SROWS ? c1 + r1 * 16 + 4 * (q ^ swz<16>(r1)) : dump) = v1;
 #pragma unroll
-            for (int tap = 0; tap < 3; ++tap) {
-                const f32x4 x0 = row16(c2, r0 + tap);
-                const f32x4 x1 = row16(c2, r1 + tap);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[tap][e], x0[e], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[tap][e], x1[e], a1, 0, 0, 0);
-                }
-            }
-            auto pool_store = [&](f32x4 acc, int r) {
-                f32x4 m;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = fmaxf(acc[e] + b4[e], 0.f);
-                    const float n1 = __shfl_down(v, 1, 16);
-                    const float n2 = __shfl_down(v, 2, 16);
-                    m[e] = fmaxf(fmaxf(v, n1), n2);
-                }
-                const int rdl = r / 150;
-                const int i = r - rdl * 150;
-                const int p = i >> 1;
-                const int rd = SB * sb + rdl;
-                if (((j & 1) == 0) && j <= 12 && p < L1 && rd < n_here && rdl < SB) {
-                    const int row = 1 + rd * RS1 + p;
-                    *(f32x4*)(bufA + row * 32 + 4 * ((4 * cb + q) ^ swz<32>(row))) = m;
-                }
-            };
-            pool_store(a0, r0);
-            if (t1 != t) pool_store(a1, r1);
+        for (int s = 0; s < S1_STEPS; ++s) {
+            cur0[s] = nxt0[s];
+            cur1[s] = nxt1[s];
         }
     }
 }
@@ -404,26 +381,39 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         for (int k = 0; k < T2; ++k) pad2 |= (((k * 16 + j) % RS2) >= L2 ? 1u : 0u) << k;
     }
 
-    // ---- the trunk's input image [71][32] per read in bufA (pad rows and row 0 zero) ------------------
-    for (int i = tid; i < BUF_FLOATS / 4; i += THREADS) ((f32x4*)bufA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!STEM && tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // X = the trunk's input image [71][32] per read (shared zero rows and row 0 zero), H = the other image
+    float* const X = STEM ? bufB : bufA;
+    float* const H = STEM ? bufA : bufB;
+    f32x4 sreg[CF::NSREG];
     if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
-    __syncthreads();
     if (STEM) {
-        // computed here from the uint8 pileups, SB reads at a time, temporaries in bufB
+        // the stem, from the uint8 pileups: conv1 bytes -> bufB, conv2 bufB -> bufA, conv3 + max pool
+        // bufA -> X (= bufB again, now as the 32-channel image)
         const int ch = a.channels;
-        const int per_read = 150 * ch;
-        for (int sb = 0; sb < G / CF::SB; ++sb) {
-            const int have = n_here - CF::SB * sb;                    // reads of this sub-batch that exist
-            const int n_bytes = (have < 0 ? 0 : (have > CF::SB ? CF::SB : have)) * per_read;
-            const unsigned char* src = a.reads + (read0 + CF::SB * sb) * per_read;
-            for (int i = tid; i < CF::U8_BYTES; i += THREADS) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
-            __syncthreads();
-            stem_subbatch<CF>(s_u8, bufB, bufB + CF::SROWS * 16, bufA, W, ch, sb, n_here, wave, lane);
-            __syncthreads();
+        const int n_bytes = n_here * 150 * ch;
+        const unsigned char* src = a.reads + read0 * 150 * ch;
+        for (int i = tid; i < CF::U8_BYTES; i += THREADS) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
+        f32x4 ws2[3], ws3[3];
+        load_weights<3>(ws2, W + OFF_S2, 0, lane);
+        load_weights<3>(ws3, W + OFF_S3, wave % 2, lane);
+        __syncthreads();
+        stem_conv1<CF>(s_u8, bufB, W, ch, dump, wave, lane);
+        __syncthreads();
+        conv_layer<CF, 16, 16, 3, 1, 0, 1, 1, 0, CF::ST12, MODE_PLAIN, false, GEOM_STEM, 16, CF::SROWS>(
+            bufB, bufA, ws2, nullptr, W + OFF_S2 + 3 * 256, sreg, 0u, dump, wave, lane);
+        __syncthreads();
+        if (tid < 8 * (G + 1)) {                      // the image's shared zero rows: 0, 72, 144, ...
+            const int row = (tid >> 3) * RS1;
+            *(f32x4*)(X + row * 32 + 4 * (tid & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};   // row 0 of the 32-channel image
+        conv_layer<CF, 16, 32, 3, 1, 0, 1, 1, 0, CF::ST3, MODE_POOL, false, GEOM_STEM, 14>(
+            bufA, X, ws3, nullptr, W + OFF_S3 + 2 * 3 * 256, sreg, 0u, dump, wave, lane, n_here);
+        __syncthreads();
+        if (tid < 8) ((f32x4*)H)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};        // row 0 of the 32-channel image
     } else {
+        for (int i = tid; i < BUF_FLOATS / 4; i += THREADS) ((f32x4*)bufA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
         const f32x4* src = (const f32x4*)(a.pooled + read0 * (L1 * 32));
         const int n4 = n_here * L1 * 8;
         for (int f = tid; f < n4; f += THREADS) {
@@ -436,7 +426,6 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
 
     f32x4 w6[6], w12[12], w2[2];
-    f32x4 sreg[CF::NSREG];
     const int cb2 = wave % 2, cb4 = wave;
     auto slice = [&](int off, int cb, int nv) { return W + off + cb * nv * 256 + lane * 4; };   // this wave's block, this lane
 
@@ -447,27 +436,27 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     for (int blk = 0; blk < 3; ++blk) {
         const int off_a = OFF_B + (2 * blk) * (W3232 + 32), off_b = off_a + (W3232 + 32);
         conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN, true>(
-            bufA, bufB, w6, slice(off_b, cb2, 6), W + off_a + W3232, sreg, pad1, dump, wave, lane);
+            X, H, w6, slice(off_b, cb2, 6), W + off_a + W3232, sreg, pad1, dump, wave, lane);
         __syncthreads();
         // the block's second conv rolls in the next block's first conv, or the strided conv (4 channel blocks)
         const float* nxt = (blk < 2) ? slice(off_b + (W3232 + 32), cb2, 6) : slice(OFF_C1, cb4, 6);
         conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_RESID_INPLACE, true>(
-            bufB, bufA, w6, nxt, W + off_b + W3232, sreg, pad1, dump, wave, lane);
+            H, X, w6, nxt, W + off_b + W3232, sreg, pad1, dump, wave, lane);
         __syncthreads();
     }
 
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
     load_weights<2>(w2, W + OFF_SC, cb4, lane);
     load_weights<12>(w12, W + OFF_C2, cb4, lane);
-    if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};     // zero row 0 of the 64-channel image
+    if (tid < 16) ((f32x4*)H)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};     // zero row 0 of the 64-channel image
     conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false>(
-        bufA, bufB, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
+        X, H, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
     conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS, false>(
-        bufA, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
+        X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
     __syncthreads();
-    if (tid < 16) ((f32x4*)bufA)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 16) ((f32x4*)X)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true>(
-        bufB, bufA, w12, slice(OFF_D, cb4, 12), W + OFF_C2 + W6464, sreg, pad2, dump, wave, lane);
+        H, X, w12, slice(OFF_D, cb4, 12), W + OFF_C2 + W6464, sreg, pad2, dump, wave, lane);
     __syncthreads();
 
     // ---- 3 x ResidualBlock(64) --------------------------------------------------------------------
@@ -475,14 +464,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     for (int blk = 0; blk < 3; ++blk) {
         const int off_a = OFF_D + (2 * blk) * (W6464 + 64), off_b = off_a + (W6464 + 64);
         conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN, true>(
-            bufA, bufB, w12, slice(off_b, cb4, 12), W + off_a + W6464, sreg, pad2, dump, wave, lane);
+            X, H, w12, slice(off_b, cb4, 12), W + off_a + W6464, sreg, pad2, dump, wave, lane);
         __syncthreads();
         if (blk < 2)
             conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, true>(
-                bufB, bufA, w12, slice(off_b + (W6464 + 64), cb4, 12), W + off_b + W6464, sreg, pad2, dump, wave, lane);
+                H, X, w12, slice(off_b + (W6464 + 64), cb4, 12), W + off_b + W6464, sreg, pad2, dump, wave, lane);
         else
             conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, false>(
-                bufB, bufA, w12, nullptr, W + off_b + W6464, sreg, pad2, dump, wave, lane);
+                H, X, w12, nullptr, W + off_b + W6464, sreg, pad2, dump, wave, lane);
         __syncthreads();
     }
 
@@ -502,7 +491,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
                     cur = al;
                 }
                 const int row = 1 + rd * RS2 + p;
-                const f32x4 v = *(const f32x4*)(bufA + row * 64 + 4 * (c ^ swz<64>(row)));
+                const f32x4 v = *(const f32x4*)(X + row * 64 + 4 * (c ^ swz<64>(row)));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += v[e];
             }
