@@ -1,0 +1,74 @@
+"""GPU, end to end: pileups -> HIP engine -> pair posteriors -> genotype calls, against the CPU oracle driven
+through the same steps.  "Identical calls" is the north star's acceptance criterion; identity is defined as
+in SURVEY.md section 7: equal (CHROM, POS, REF, ALT set, genotype alleles); posteriors within 1e-4; QUAL
+compared only where 1-p is large enough for -10 log10(1-p) to be well conditioned."""
+import numpy as np
+import pytest
+
+from hello_amd import netspec as ns, synth, vcf, weights
+from oracle import moe_oracle as mo
+from oracle import vcf_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def genome_for(n_sites, spacing=40):
+    """A synthetic chromosome with an 'A' (the reference allele of synth.allele_names) at every site start."""
+    rng = np.random.default_rng(5)
+    g = rng.choice(list("CG"), size=n_sites * spacing + 50)
+    pos = 20 + spacing * np.arange(n_sites)
+    g[pos] = "A"
+    return "".join(g), pos
+
+
+@pytest.mark.parametrize("cfg,kw", [
+    ("single_tech", dict(coverage=30)),
+    ("hybrid_ensemble2", dict(coverage=20, hybrid_coverage=10)),
+])
+def test_calls_identical_to_oracle(cfg, kw):
+    import torch
+    from hello_amd.wrapper import ScoringNetwork
+    spec = ns.build(cfg)
+    state = weights.synth_state(spec, seed=31)
+    batch = synth.make_sites(48, seed=90, **kw)
+    names = synth.allele_names(batch)
+    genome, pos = genome_for(batch.n_sites)
+    net = ScoringNetwork(spec, state, providePredictions=True)
+    ref = mo.WrapperOracle(spec, state, provide_predictions=True)
+    aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
+    r0 = np.concatenate([[0], np.cumsum(batch.reads_per_allele0)])
+    r1 = None if batch.reads1 is None else np.concatenate([[0], np.cumsum(batch.reads_per_allele1)])
+    sites = []
+    for s in range(batch.n_sites):
+        fd = {}
+        for j, a in enumerate(range(aoff[s], aoff[s + 1])):
+            second = None if r1 is None else torch.Tensor(batch.reads1[r1[a]:r1[a + 1]])
+            fd[names[s][j]] = (torch.Tensor(batch.reads0[r0[a]:r0[a + 1]]), second)
+        sites.append((fd, torch.from_numpy(batch.ref_onehot[s:s + 1]).float()))
+    got_all = net.score_sites(sites)
+    n_calls = 0
+    for s, (fd, seg) in enumerate(sites):
+        fd_np = {k: (v[0].numpy(), None if v[1] is None else v[1].numpy()) for k, v in fd.items()}
+        want = ref(fd_np, seg.numpy())
+        got = got_all[s]
+        for k in want[0]:
+            assert abs(float(got[0][k]) - float(want[0][k])) < 1e-4
+        got_call = vcf.call_from_prediction(got, "chrS", int(pos[s]), 1, genome)
+        mean = vo.mean_of_experts(want[1:4], want[4])
+        want_line = vo.call_alleles(mean, "chrS", int(pos[s]), 1, genome)
+        assert (got_call is None) == (want_line is None)
+        if got_call is None:
+            continue
+        n_calls += 1
+        chrom, p1, _, r, alt, qual, _, _, _, gt = want_line.split("\t")
+        # a genuinely ambiguous site (two pairs within 1e-4) may legitimately flip: skip those
+        ps = sorted((float(v) for v in mean.values()), reverse=True)
+        if len(ps) > 1 and ps[0] - ps[1] < 2e-4:
+            continue
+        alleles = [r] + alt.split(",")
+        want_id = (chrom, int(p1) - 1, r, frozenset(alt.split(",")), tuple(sorted(alleles[int(g)] for g in gt.split("/"))))
+        assert got_call.identity() == want_id
+        if 1.0 - ps[0] > 1e-2:
+            assert abs(got_call.qual - float(qual)) < 0.05
+    assert n_calls >= 40
+    net.close()

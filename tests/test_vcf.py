@@ -1,0 +1,112 @@
+"""Posterior -> genotype -> VCF record: hand-worked cases of every normalisation rule of
+the reference (vcfFromContigs.py:139-227, prepareVcf.py:36-105), and the product (hello_amd/vcf.py) against
+the literal oracle restatement (oracle/vcf_oracle.py) on random sites."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+from hello_amd import vcf
+from oracle import vcf_oracle as vo
+
+GENOME = "ACGTACGTTTGACCATGCA"
+
+
+def fields(line):
+    chrom, pos, _, ref, alt, qual, flt, info, fmt, gt = line.split("\t")
+    return chrom, int(pos), ref, alt, float(qual), flt, info, fmt, gt
+
+
+def test_snv_het():
+    post = {("G", "G"): 0.1, ("G", "T"): 0.8, ("T", "T"): 0.1}
+    line = vo.call_alleles(post, "chr1", 2, 1, GENOME)
+    assert fields(line) == ("chr1", 3, "G", "T", pytest.approx(-10 * math.log10(0.2), abs=1e-6), "PASS", "HELLO", "GT", "0/1")
+    call = vcf.call_site(post, "chr1", 2, 1, GENOME)
+    assert call.line() == line
+
+
+def test_quality_is_capped_at_80():
+    post = {("G", "G"): 0.0, ("G", "T"): 1.0, ("T", "T"): 0.0}
+    assert fields(vo.call_alleles(post, "c", 2, 1, GENOME))[4] == pytest.approx(80.0, abs=1e-4)
+    assert vcf.call_site(post, "c", 2, 1, GENOME).qual == pytest.approx(80.0, abs=1e-4)
+
+
+@pytest.mark.parametrize("start,ref,alts,want", [
+    (3, "T", ["-"], (2, "GT", ["G"])),                 # empty allele: anchor on the previous base
+    (3, "TAC", ["TC"], (3, "TA", ["T"])),              # shared suffix trimmed, stops when an allele has 1 base
+    (12, "CAT", ["CAG"], (14, "T", ["G"])),            # shared prefix trimmed
+    (2, "G", ["GA"], (2, "G", ["GA"])),                # insertion outside a repeat: nothing to trim
+    (8, "T", ["TTT"], (6, "G", ["GTT"])),              # insertion in a T run: trimmed and re-anchored until left-aligned
+    (8, "TT", ["T"], (6, "GT", ["G"])),                # deletion in a T run: likewise
+])
+def test_normalisation_rules(start, ref, alts, want):
+    got = vcf.normalise(start, ref, alts, GENOME)
+    assert (got[0], got[1], list(got[2])) == want
+    line = vo.create_vcf_record("c", start, GENOME, ref, alts, [0, 1])
+    f = fields(line)
+    assert (f[1] - 1, f[2], f[3].split(",")) == want
+
+
+def test_hom_ref_lists_every_site_allele_and_gt_00():
+    post = {("A", "A"): 0.9, ("A", "AT"): 0.05, ("A", "ATT"): 0.01, ("AT", "AT"): 0.02, ("AT", "ATT"): 0.01, ("ATT", "ATT"): 0.01}
+    genome = "CCAGG"
+    call = vcf.call_site(post, "c", 2, 1, genome)
+    assert call.genotype == (0, 0) and call.alts == ("AT", "ATT") and call.ref == "A"
+    assert call.line() == vo.call_alleles(post, "c", 2, 1, genome)
+
+
+def test_site_without_alternative_allele_gives_no_record():
+    assert vcf.call_site({("A", "A"): 1.0}, "c", 0, 1, GENOME) is None
+    assert vo.call_alleles({("A", "A"): 1.0}, "c", 0, 1, GENOME) is None
+
+
+def test_two_alt_genotype_indices_follow_sorted_alts():
+    post = {("A", "A"): 0.0, ("A", "AT"): 0.1, ("A", "ATT"): 0.1, ("AT", "AT"): 0.1, ("ATT", "AT"): 0.6, ("ATT", "ATT"): 0.1}
+    call = vcf.call_site(post, "c", 2, 1, "CCAGG")
+    assert call.alts == ("AT", "ATT") and call.genotype == (2, 1)
+    assert call.line() == vo.call_alleles(post, "c", 2, 1, "CCAGG")
+
+
+def test_product_matches_oracle_on_random_sites():
+    rng = random.Random(7)
+    genome = "".join(rng.choice("ACGT") for _ in range(400))
+    n_records = 0
+    for _ in range(300):
+        start = rng.randrange(5, 380)
+        length = rng.choice([1, 1, 2, 3])
+        ref = genome[start:start + length]
+        alleles = [ref]
+        while len(alleles) < rng.choice([2, 2, 3, 4]):
+            kind = rng.random()
+            if kind < 0.4:
+                cand = "".join(rng.choice("ACGT") for _ in range(length))
+            elif kind < 0.7:
+                cand = ref + "".join(rng.choice("ACGT") for _ in range(rng.choice([1, 2])))
+            else:
+                cand = ref[:max(0, length - rng.choice([1, 2]))] or "-"
+            if cand not in alleles:
+                alleles.append(cand)
+        rng.shuffle(alleles)
+        pairs = [(alleles[i], alleles[j]) for i in range(len(alleles)) for j in range(i, len(alleles))]
+        p = np.random.default_rng(rng.randrange(1 << 30)).dirichlet(np.ones(len(pairs)) * 0.3)
+        post = dict(zip(pairs, p.tolist()))
+        want = vo.call_alleles(post, "chr7", start, length, genome)
+        got = vcf.call_site(post, "chr7", start, length, genome)
+        assert (got is None) == (want is None)
+        if got is not None:
+            assert got.line() == want
+            n_records += 1
+    assert n_records > 200
+
+
+def test_ensemble_mean_rule():
+    e = [{("A", "A"): 0.2, ("A", "T"): 0.7, ("T", "T"): 0.1},
+         {("A", "A"): 0.6, ("A", "T"): 0.3, ("T", "T"): 0.1},
+         {("A", "A"): 0.1, ("A", "T"): 0.1, ("T", "T"): 0.8}]
+    meta = [0.5, 0.3, 0.2]
+    mean = vcf.mean_posteriors(e, meta)
+    assert mean == vo.mean_of_experts(e, meta)
+    assert mean[("A", "T")] == pytest.approx(0.46)
+    call = vcf.call_from_prediction((None, e[0], e[1], e[2], meta), "c", 0, 1, "ACGT")
+    assert call.genotype == (0, 1) and call.line() == vo.call_alleles(mean, "c", 0, 1, "ACGT")
