@@ -85,16 +85,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HELLO_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("HELLO_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at world size 1)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     spec = ns.build("single_tech")
     state = weights.synth_state(spec, seed=args.seed)
-    eng = Engine(spec, state, device=local_rank, fused={"full": True, "trunk": "trunk", "none": False}[args.fused])
+    eng = Engine(spec, state, device=dev_index, fused={"full": True, "trunk": "trunk", "none": False}[args.fused])
 
     # resident pool of synthetic batches (every rank its own sites: shard = rank)
     pool = []
@@ -105,6 +111,11 @@ def main():
             aps=b.alleles_per_site, pairs=n_pairs(b.alleles_per_site)))
     max_a = max(p["batch"].n_alleles for p in pool)
     max_p = max(p["pairs"] for p in pool)
+    if dist is not None:
+        # ranks hold different random shards: agree on one row width so the final gather is a plain gather
+        width = torch.tensor([max_a], dtype=torch.int64, device=dev)
+        dist.all_reduce(width, op=dist.ReduceOp.MAX)
+        max_a = int(width.item())
     # outputs of every timed step stay on the device until the single gather at the end
     out_logits = torch.zeros((args.steps, max_a), dtype=torch.float32, device=dev)
     out_post = torch.zeros((4, max_p), dtype=torch.float32, device=dev)

@@ -137,3 +137,37 @@ def test_error_paths(engines):
     with pytest.raises(RuntimeError, match="alleles_per_site"):
         eng.forward(batch.reads0, batch.reads_per_allele0, aps)
     eng.forward_batch(batch)      # the engine stays usable after a rejected call
+
+
+def test_wide_model_runs_layer_by_layer_and_matches_oracle(engines):
+    """The *_wide configuration (2x channels) is outside the fused kernel's shape: it must take the generic
+    conv path (including the 128-channel workgroup tile) and still agree with the oracle."""
+    from oracle import moe_oracle as mo
+    spec = ns.build("hybrid_no_ensemble_wide")
+    state = weights.synth_state(spec, seed=23)
+    batch = synth.make_sites(6, seed=12, coverage=12, hybrid_coverage=8)
+    eng = get_engine(engines, "wide", spec, state, True)
+    assert not eng.program.fused_read_convolver
+    logits, _ = eng.forward_batch(batch)
+    want, _ = mo.forward_batch(mo.Oracle(spec, state), batch, chunk_sites=6)
+    np.testing.assert_allclose(logits, want, **LOGIT_TOL)
+
+
+def test_ragged_extremes(engines):
+    """1-read alleles next to 1000-read alleles, many alleles per site, a single-site batch of one read."""
+    from oracle import moe_oracle as mo
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=21)
+    eng = get_engine(engines, "fresh_single_tech", spec, state, True)
+    rng = np.random.default_rng(3)
+    rpa = np.array([1, 1000, 1, 3, 2, 1, 1, 257, 5, 1, 1, 1], dtype=np.int32)
+    aps = np.array([2, 1, 6, 3], dtype=np.int32)
+    reads = rng.integers(0, 255, size=(int(rpa.sum()), 150, 6), dtype=np.uint8)
+    reads[0] = 0                                         # an all-zero dummy read
+    logits, _ = eng.forward(reads, rpa, aps)
+    oracle = mo.Oracle(spec, state)
+    want = oracle.forward((np.transpose(reads, (0, 2, 1)), None), aps, (rpa, None))[:, 0]
+    np.testing.assert_allclose(logits[0], want, rtol=5e-5, atol=5e-4)     # sums over 1000 reads: looser
+    one, _ = eng.forward(reads[:1], np.array([1], np.int32), np.array([1], np.int32))
+    want1 = oracle.forward((np.transpose(reads[:1], (0, 2, 1)), None), [1], ([1], None))[:, 0]
+    np.testing.assert_allclose(one[0], want1, **LOGIT_TOL)
