@@ -172,7 +172,7 @@ def main():
     # group the per-op event times by the kernel that ran them; algorithmic FLOPs = 2 * MAC of the op
     kernels = {}
     for op, (k, n, ms) in zip(eng.program.ops, op_rows):
-        kname = {"conv1d": "conv1d_mfma_kernel", "readconv_fused": "readconv_trunk_kernel"}.get(k, k + "_kernel")
+        kname = {"conv1d": "conv1d_mfma_kernel", "readconv_fused": "readconv_kernel"}.get(k, k + "_kernel")
         ent = kernels.setdefault(kname, dict(ms=0.0, flops=0.0, launches=0))
         ent["ms"] += ms
         rows = reads_step if k == "readconv_fused" else rows_of[op.domain]   # the trunk's MACs are per read
