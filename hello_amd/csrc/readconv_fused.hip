@@ -37,6 +37,7 @@
 //           writes one partial [36][64] slot per (group, allele) incidence; a tiny finalize kernel adds
 //           an allele's slots in order.  No atomics: results are bit-reproducible.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -46,7 +47,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace rc {
 constexpr int L1 = 71, RS1 = 72;     // positions / row stride per read at 32 channels
-constexpr int L2 = 36, RS2 = 37;     // ... at 64 channels
+constexpr int L2 = 36, RS2 = 36;     // ... at 64 channels: reads stacked WITHOUT zero rows between them, so the
+                                     // 36*G rows tile exactly; the taps that would cross a read boundary are
+                                     // zeroed in registers instead (BMASK)
 
 // packed weight block (floats): per conv [COUT/16][KT][CIN/16][64 lanes][4], then bias [COUT]
 constexpr int W3232 = 2 * 3 * 2 * 256, W3264 = 4 * 3 * 2 * 256, W3264S = 4 * 1 * 2 * 256, W6464 = 4 * 3 * 4 * 256;
@@ -72,7 +75,7 @@ struct Cfg {
     static constexpr int T1 = (RS1 * G_ + 15) / 16;    // position tiles at 32 channels
     static constexpr int T2 = (RS2 * G_ + 15) / 16;    // ... at 64 channels
     static constexpr int ROWS1 = RS1 * G_ + 1;         // rows of the 32-channel image (row 0 = leading zero row)
-    static constexpr int ROWS2 = RS2 * G_ + 1;
+    static constexpr int ROWS2 = RS2 * G_ + 2;         // leading and trailing zero row
     static constexpr int SB = G_;                      // the stem runs over all reads of the group at once
     static constexpr int SROWS = 150 * SB;
     static constexpr int ST12 = ((SROWS + 15) / 16 + 3) / 4 * 4;   // tiles of stem conv1 / conv2 (4 position groups)
@@ -106,6 +109,15 @@ __device__ __forceinline__ void load_weights(f32x4 (&w)[NV], const float* __rest
     for (int i = 0; i < NV; ++i) w[i] = *(const f32x4*)(base + ((cb * NV + i) * 64 + lane) * 4);
 }
 
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3, MODE_POOL = 4 };
 enum { GEOM_TRUNK = 0, GEOM_STEM = 1 };
 
@@ -126,7 +138,7 @@ __device__ __forceinline__ float row_shl(float v, int n) {
 //            flat stacks (150 rows per read, no leading row): tile t starts at row TS*t, valid convolution
 //   VROWS    output rows >= VROWS are discarded;  `aux` = reads present in the group (MODE_POOL only)
 template <class CF, int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE,
-          bool ROLL, int GEOM = GEOM_TRUNK, int TS = 16, int VROWS = RS_OUT * CF::G>
+          bool ROLL, int GEOM = GEOM_TRUNK, int TS = 16, int VROWS = RS_OUT * CF::G, bool BMASK = false>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* __restrict__ out,
                                            f32x4 (&w)[KT * CIN / 16], const float* __restrict__ next_w,
                                            const float* __restrict__ bias, f32x4 (&sreg)[CF::NSREG],
@@ -224,74 +236,92 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     // four chains in flight a chain is revisited every 128 cycles, far beyond the 40-cycle dependent latency.
     constexpr int S = KT * M, NP = ITER / 2, NU = NP * S, DEPTH = 2;
     constexpr bool DEFER = (MODE != MODE_TO_REGS) && (S >= 3);
+    // An odd share leaves one lone tile.  It runs in the same pipeline as a pseudo-pair: its k steps are
+    // split in two halves that play the roles of the two tiles (each with its own weight registers).
     constexpr bool LONE = (ITER % 2) != 0;
+    static_assert(!LONE || (S % 2 == 0), "a lone tile needs an even number of k steps");
+    constexpr int HS = S / 2, NUT = NU + (LONE ? HS : 0);
+    static_assert(!BMASK || NPG == 1, "boundary masks assume one position group (tile index = wave's tile index)");
+    // BMASK (64-channel images without zero rows between reads): lane j of tile t must see zero instead of
+    // the previous read's last row at tap 0 when 16 t + j is a read's first row, and instead of the next
+    // read's first row at the last tap when it is a read's last row.
     f32x4 ring0[DEPTH + 1], ring1[DEPTH + 1];
-    auto issue = [&](int u) {
-        ring0[u % (DEPTH + 1)] = tile_operand(2 * (u / S), u % S);
-        ring1[u % (DEPTH + 1)] = tile_operand(2 * (u / S) + 1, u % S);
-    };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 a0 = zero4, a1 = zero4, b0 = zero4, b1 = zero4;
     f32x4 pend0 = zero4, pend1 = zero4, res0 = zero4, res1 = zero4;
-#pragma unroll
-    for (int u = 0; u < DEPTH && u < NU; ++u) issue(u);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        if (u + DEPTH < NU) issue(u + DEPTH);
-        if (DEFER && u >= S && u % S == 0) {
-            res0 = residual(2 * (u / S - 1));
-            res1 = residual(2 * (u / S - 1) + 1);
+
+    // every index below is a compile-time constant (static_for hands the step number over as a type)
+    auto issue = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int t0 = u < NU ? 2 * (u / S) : ITER - 1, t1 = u < NU ? 2 * (u / S) + 1 : ITER - 1;
+        constexpr int s0 = u < NU ? u % S : u - NU, s1 = u < NU ? u % S : u - NU + HS;
+        ring0[u % (DEPTH + 1)] = tile_operand(t0, s0);
+        ring1[u % (DEPTH + 1)] = tile_operand(t1, s1);
+    };
+    static_for<0, (DEPTH < NUT ? DEPTH : NUT)>(issue);
+    static_for<0, NUT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int t0 = u < NU ? 2 * (u / S) : ITER - 1, t1 = u < NU ? 2 * (u / S) + 1 : ITER - 1;
+        constexpr int s0 = u < NU ? u % S : u - NU, s1 = u < NU ? u % S : u - NU + HS;
+        constexpr int ls = u < NU ? u % S : u - NU;                 // step within the current (pseudo-)pair
+        constexpr int ip = (u < NU ? u / S : NP) - 1;              // the pair whose epilogue may be pending
+        constexpr bool pending = DEFER && ip >= 0 && (u < NU || HS >= 3);
+        if constexpr (u + DEPTH < NUT) issue(std::integral_constant<int, u + DEPTH>{});
+        if constexpr (pending && ls == 0) {
+            res0 = residual(2 * ip);
+            res1 = residual(2 * ip + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (DEFER && u >= S && u % S == 1) epilogue(2 * (u / S - 1), pend0, res0);
-        if (DEFER && u >= S && u % S == 2) epilogue(2 * (u / S - 1) + 1, pend1, res1);
-        const f32x4 ww = w[u % S];
-        const f32x4 x0 = ring0[u % (DEPTH + 1)], x1 = ring1[u % (DEPTH + 1)];
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x0[0], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x1[0], a1, 0, 0, 0);
-        b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x0[1], b0, 0, 0, 0);
-        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x1[1], b1, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x0[2], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x1[2], a1, 0, 0, 0);
-        b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x0[3], b0, 0, 0, 0);
-        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x1[3], b1, 0, 0, 0);
-        if (ROLL && !LONE && u >= NU - S) w[u % S] = *(const f32x4*)(next_w + (u % S) * 256);
-        if (u % S == S - 1) {
+        if constexpr (pending && ls == 1) epilogue(2 * ip, pend0, res0);
+        if constexpr (pending && ls == 2) epilogue(2 * ip + 1, pend1, res1);
+        const f32x4 w0 = w[s0], w1 = w[s1];
+        f32x4 x0 = ring0[u % (DEPTH + 1)], x1 = ring1[u % (DEPTH + 1)];
+        if constexpr (BMASK) {
+            constexpr int tap0 = s0 / M, tap1 = s1 / M;
+            constexpr int first0 = ((16 * t0 + RS_OUT - 1) / RS_OUT) * RS_OUT, last0 = ((16 * t0 + RS_OUT) / RS_OUT) * RS_OUT - 1;
+            constexpr int first1 = ((16 * t1 + RS_OUT - 1) / RS_OUT) * RS_OUT, last1 = ((16 * t1 + RS_OUT) / RS_OUT) * RS_OUT - 1;
+            if constexpr (tap0 == 0 && first0 > 0 && first0 <= 16 * t0 + 15) x0 = (j == first0 - 16 * t0) ? zero4 : x0;
+            if constexpr (tap0 == KT - 1 && last0 <= 16 * t0 + 15 && last0 < RS_OUT * CF::G - 1) x0 = (j == last0 - 16 * t0) ? zero4 : x0;
+            if constexpr (tap1 == 0 && first1 > 0 && first1 <= 16 * t1 + 15) x1 = (j == first1 - 16 * t1) ? zero4 : x1;
+            if constexpr (tap1 == KT - 1 && last1 <= 16 * t1 + 15 && last1 < RS_OUT * CF::G - 1) x1 = (j == last1 - 16 * t1) ? zero4 : x1;
+        }
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[0], x0[0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0], x1[0], a1, 0, 0, 0);
+        b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[1], x0[1], b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[1], x1[1], b1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[2], x0[2], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[2], x1[2], a1, 0, 0, 0);
+        b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[3], x0[3], b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[3], x1[3], b1, 0, 0, 0);
+        if constexpr (ROLL) {
+            // refill a weight register with the next layer's value right after its last use
+            if constexpr (LONE && u >= NU) {
+                w[s0] = *(const f32x4*)(next_w + s0 * 256);
+                w[s1] = *(const f32x4*)(next_w + s1 * 256);
+            }
+            if constexpr (!LONE && u >= NU - S) w[s0] = *(const f32x4*)(next_w + s0 * 256);
+        }
+        if constexpr (u < NU && u % S == S - 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 a0[e] += b0[e];
                 a1[e] += b1[e];
             }
-            if (DEFER && u + 1 < NU) {
+            if constexpr (DEFER && (u + 1 < NU || (LONE && HS >= 3))) {
                 pend0 = a0;
                 pend1 = a1;
             } else {
-                const int k = 2 * (u / S);
-                epilogue(k, a0, residual(k));
-                epilogue(k + 1, a1, residual(k + 1));
+                epilogue(t0, a0, residual(t0));
+                epilogue(t1, a1, residual(t1));
             }
             a0 = a1 = b0 = b1 = zero4;
         }
-    }
-
-    // ---- an odd share leaves one lone tile: its k range is split over two chains ---------------------
-    if (LONE) {
-        constexpr int k = ITER - 1;
-        f32x4 c0 = zero4, c1 = zero4;
+        if constexpr (LONE && u == NUT - 1) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const f32x4 x0 = tile_operand(k, s);
-            const f32x4 ww = w[s];
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[0], x0[0], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[1], x0[1], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[2], x0[2], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ww[3], x0[3], c1, 0, 0, 0);
-            if (ROLL) w[s] = *(const f32x4*)(next_w + s * 256);
+            for (int e = 0; e < 4; ++e) a0[e] = (a0[e] + b0[e]) + (a1[e] + b1[e]);
+            epilogue(ITER - 1, a0, residual(ITER - 1));
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) c0[e] += c1[e];
-        epilogue(k, c0, residual(k));
-    }
+    });
 }
 
 // ---- stem conv1: pileup bytes -> 16 channels (valid convolution over the stacked reads) ---------------
@@ -372,13 +402,12 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     const float* __restrict__ W = a.w;
 
     // which of a lane's rows are shared zero rows: bit k = the wave's k-th tile, per image geometry
-    unsigned pad1 = 0, pad2 = 0;
+    unsigned pad1 = 0;
+    const unsigned pad2 = 0;                                  // the 64-channel images hold no zero rows between reads
     {
         const int pg1 = wave / 2;                              // 32-channel layers: 2 blocks x 2 position groups
 #pragma unroll
         for (int k = 0; k < T1 / 2; ++k) pad1 |= ((((pg1 + 2 * k) * 16 + j) % RS1) >= L1 ? 1u : 0u) << k;
-#pragma unroll
-        for (int k = 0; k < T2; ++k) pad2 |= (((k * 16 + j) % RS2) >= L2 ? 1u : 0u) << k;
     }
 
     // X = the trunk's input image [71][32] per read (shared zero rows and row 0 zero), H = the other image
@@ -448,14 +477,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
     load_weights<2>(w2, W + OFF_SC, cb4, lane);
     load_weights<12>(w12, W + OFF_C2, cb4, lane);
-    if (tid < 16) ((f32x4*)H)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};     // zero row 0 of the 64-channel image
+    if (tid < 32) ((f32x4*)H)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};   // rows 0 and 36G+1
     conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false>(
         X, H, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
     conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS, false>(
         X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
     __syncthreads();
-    if (tid < 16) ((f32x4*)X)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
-    conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true>(
+    if (tid < 32) ((f32x4*)X)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
         H, X, w12, slice(OFF_D, cb4, 12), W + OFF_C2 + W6464, sreg, pad2, dump, wave, lane);
     __syncthreads();
 
@@ -463,14 +492,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
         const int off_a = OFF_D + (2 * blk) * (W6464 + 64), off_b = off_a + (W6464 + 64);
-        conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN, true>(
+        conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
             X, H, w12, slice(off_b, cb4, 12), W + off_a + W6464, sreg, pad2, dump, wave, lane);
         __syncthreads();
         if (blk < 2)
-            conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, true>(
+            conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
                 H, X, w12, slice(off_b + (W6464 + 64), cb4, 12), W + off_b + W6464, sreg, pad2, dump, wave, lane);
         else
-            conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, false>(
+            conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, false, GEOM_TRUNK, 16, RS2 * CF::G, true>(
                 H, X, w12, nullptr, W + off_b + W6464, sreg, pad2, dump, wave, lane);
         __syncthreads();
     }
