@@ -414,6 +414,9 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     float* const X = STEM ? bufB : bufA;
     float* const H = STEM ? bufA : bufB;
     f32x4 sreg[CF::NSREG];
+    f32x4 w6[6], w12[12], w2[2];
+    const int cb2 = wave % 2, cb4 = wave;
+    load_weights<6>(w6, W + OFF_B, cb2, lane);      // first trunk layer: requested before anything else waits
     if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
     if (STEM) {
         // the stem, from the uint8 pileups: conv1 bytes -> bufB, conv2 bufB -> bufA, conv3 + max pool
@@ -421,7 +424,31 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         const int ch = a.channels;
         const int n_bytes = n_here * 150 * ch;
         const unsigned char* src = a.reads + read0 * 150 * ch;
-        for (int i = tid; i < CF::U8_BYTES; i += THREADS) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
+        // The group's bytes in ONE round trip to memory: every thread requests all its dwords first and
+        // stores them afterwards (a load-store loop would pay the memory latency once per iteration and
+        // leave the workgroup memory-bound for longer than all its MFMAs take).
+        constexpr int NDW = (CF::U8_BYTES / 4 + THREADS - 1) / THREADS;
+        if ((reinterpret_cast<unsigned long long>(src) & 3ull) == 0) {
+            unsigned v[NDW];
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) {
+                const int d = tid + THREADS * k;                  // dword index inside the staging buffer
+                unsigned x = 0;
+                if (4 * d + 4 <= n_bytes) {
+                    x = ((const unsigned*)src)[d];
+                } else if (4 * d < n_bytes) {                     // the last, partial dword (7-channel reads)
+                    for (int b = 0; b < n_bytes - 4 * d; ++b) x |= (unsigned)src[4 * d + b] << (8 * b);
+                }
+                v[k] = x;
+            }
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) {
+                const int d = tid + THREADS * k;
+                if (4 * d < CF::U8_BYTES) ((unsigned*)s_u8)[d] = v[k];
+            }
+        } else {
+            for (int i = tid; i < CF::U8_BYTES; i += THREADS) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
+        }
         f32x4 ws2[3], ws3[3];
         load_weights<3>(ws2, W + OFF_S2, 0, lane);
         load_weights<3>(ws3, W + OFF_S3, wave % 2, lane);
@@ -454,12 +481,9 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         }
     }
 
-    f32x4 w6[6], w12[12], w2[2];
-    const int cb2 = wave % 2, cb4 = wave;
     auto slice = [&](int off, int cb, int nv) { return W + off + cb * nv * 256 + lane * 4; };   // this wave's block, this lane
 
     // ---- 3 x ResidualBlock(32): x -> relu(conv) -> relu(conv) + x --------------------------------
-    load_weights<6>(w6, W + OFF_B, cb2, lane);
     __syncthreads();
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
