@@ -90,6 +90,7 @@ struct hello_engine {
     PinnedBuf h_csr;
     DevBuf d_logits, d_meta, d_post, d_rcl0, d_rcl1;
     DevBuf d_partial;                // fused read convolver partial sums
+    DevBuf d_feat_in, d_feat_out;    // featurizer staging (host-pointer callers)
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
     hipEvent_t ev_staged = nullptr;  // H2D of the pinned CSR block finished
@@ -238,6 +239,8 @@ void hello_engine_destroy(hello_engine* e) {
     e->d_rcl0.release();
     e->d_rcl1.release();
     e->d_partial.release();
+    e->d_feat_in.release();
+    e->d_feat_out.release();
     if (e->d_weights) (void)hipFree(e->d_weights);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     if (e->ev_staged) (void)hipEventDestroy(e->ev_staged);
@@ -681,6 +684,85 @@ int hello_engine_posteriors(hello_engine* e, const float* logits, const float* m
     if (!out_dev) HIP_TRY(hipMemcpyAsync(out, d_o, o_bytes, hipMemcpyDeviceToHost, stream));
     // the host vectors above die with this frame: the copies from them must have completed
     HIP_TRY(hipStreamSynchronize(stream));
+    return HELLO_OK;
+}
+
+int hello_engine_featurize(hello_engine* e, const uint8_t* bases, const uint8_t* quals, const int64_t* read_offsets,
+                           const uint32_t* cigars, const int64_t* cigar_offsets, const int64_t* ref_starts,
+                           const uint8_t* mapq, const int8_t* orientation, const uint8_t* hp,
+                           const int32_t* site_of_read, const uint8_t* ref_windows,
+                           const int64_t* ref_window_offsets, const int64_t* window_starts,
+                           const int64_t* assembly_starts, const int64_t* assembly_stops, int64_t n_reads,
+                           int32_t n_sites, int32_t feature_length, int32_t channels, uint8_t* out,
+                           int32_t flags, void* hip_stream) {
+    if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
+    if (!bases || !quals || !read_offsets || !cigars || !cigar_offsets || !ref_starts || !mapq || !orientation ||
+        !hp || !site_of_read || !ref_windows || !ref_window_offsets || !window_starts || !assembly_starts ||
+        !assembly_stops || !out)
+        return fail(HELLO_ERR_ARG, "NULL pointer");
+    if (n_reads <= 0 || n_sites <= 0 || feature_length <= 0) return fail(HELLO_ERR_ARG, "empty batch");
+    if (channels != 6 && channels != 7) return fail(HELLO_ERR_ARG, "channels must be 6 or 7");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    e->last_stream = stream;
+    const bool in_dev = flags & HELLO_IN_DEVICE, out_dev = flags & HELLO_OUT_DEVICE;
+    hello::FeaturizeArgs a{};
+    const size_t out_bytes = (size_t)n_reads * feature_length * channels;
+    if (in_dev) {
+        a.bases = bases; a.quals = quals; a.read_off = (const long long*)read_offsets;
+        a.cigars = cigars; a.cigar_off = (const long long*)cigar_offsets;
+        a.ref_start = (const long long*)ref_starts; a.mapq = mapq; a.orientation = orientation; a.hp = hp;
+        a.site_of_read = site_of_read; a.ref = ref_windows; a.ref_off = (const long long*)ref_window_offsets;
+        a.window_start = (const long long*)window_starts; a.asm_start = (const long long*)assembly_starts;
+        a.asm_stop = (const long long*)assembly_stops;
+    } else {
+        // host arrays: validate the offsets, then stage everything in one device block
+        if (read_offsets[0] != 0 || cigar_offsets[0] != 0 || ref_window_offsets[0] != 0)
+            return fail(HELLO_ERR_SHAPE, "offset arrays must start at 0");
+        for (int64_t r = 0; r < n_reads; ++r) {
+            if (read_offsets[r + 1] < read_offsets[r] || cigar_offsets[r + 1] < cigar_offsets[r])
+                return fail(HELLO_ERR_SHAPE, "offsets of read %lld decrease", (long long)r);
+            if (site_of_read[r] < 0 || site_of_read[r] >= n_sites)
+                return fail(HELLO_ERR_SHAPE, "site_of_read[%lld] = %d out of range", (long long)r, site_of_read[r]);
+        }
+        const size_t n_bases = (size_t)read_offsets[n_reads], n_cig = (size_t)cigar_offsets[n_reads];
+        const size_t n_ref = (size_t)ref_window_offsets[n_sites];
+        struct Part { const void* src; size_t bytes; size_t off; };
+        Part parts[15] = {
+            {bases, n_bases, 0}, {quals, n_bases, 0}, {read_offsets, (size_t)(n_reads + 1) * 8, 0},
+            {cigars, n_cig * 4, 0}, {cigar_offsets, (size_t)(n_reads + 1) * 8, 0}, {ref_starts, (size_t)n_reads * 8, 0},
+            {mapq, (size_t)n_reads, 0}, {orientation, (size_t)n_reads, 0}, {hp, (size_t)n_reads, 0},
+            {site_of_read, (size_t)n_reads * 4, 0}, {ref_windows, n_ref, 0},
+            {ref_window_offsets, (size_t)(n_sites + 1) * 8, 0}, {window_starts, (size_t)n_sites * 8, 0},
+            {assembly_starts, (size_t)n_sites * 8, 0}, {assembly_stops, (size_t)n_sites * 8, 0}};
+        size_t total = 0;
+        for (auto& p : parts) { p.off = total; total += (p.bytes + 15) & ~size_t(15); }
+        total += 16;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (e->d_feat_in.ensure(total)) return fail(HELLO_ERR_HIP, "device allocation of %zu bytes failed", total);
+        char* base = (char*)e->d_feat_in.p;
+        for (auto& p : parts)
+            if (p.bytes) HIP_TRY(hipMemcpyAsync(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice, stream));
+        a.bases = (const uint8_t*)(base + parts[0].off); a.quals = (const uint8_t*)(base + parts[1].off);
+        a.read_off = (const long long*)(base + parts[2].off); a.cigars = (const uint32_t*)(base + parts[3].off);
+        a.cigar_off = (const long long*)(base + parts[4].off); a.ref_start = (const long long*)(base + parts[5].off);
+        a.mapq = (const uint8_t*)(base + parts[6].off); a.orientation = (const int8_t*)(base + parts[7].off);
+        a.hp = (const uint8_t*)(base + parts[8].off); a.site_of_read = (const int32_t*)(base + parts[9].off);
+        a.ref = (const uint8_t*)(base + parts[10].off); a.ref_off = (const long long*)(base + parts[11].off);
+        a.window_start = (const long long*)(base + parts[12].off); a.asm_start = (const long long*)(base + parts[13].off);
+        a.asm_stop = (const long long*)(base + parts[14].off);
+    }
+    uint8_t* d_out = out;
+    if (!out_dev) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (e->d_feat_out.ensure(out_bytes)) return fail(HELLO_ERR_HIP, "device allocation of %zu bytes failed", out_bytes);
+        d_out = (uint8_t*)e->d_feat_out.p;
+    }
+    a.n_reads = n_reads; a.length = feature_length; a.channels = channels; a.out = d_out;
+    HIP_TRY(hello::launch_featurize(a, stream));
+    if (!out_dev) HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
+    // host inputs were pageable: the copies above are complete only after this
+    if (!in_dev || !out_dev) HIP_TRY(hipStreamSynchronize(stream));
     return HELLO_OK;
 }
 

@@ -70,4 +70,27 @@ hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
 hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames,
                                     int n_alleles, hipStream_t stream);
 
+// ---- pileup-tensor producer (featurize.hip) ----------------------------------------------------------
+struct FeaturizeArgs {
+    const uint8_t* bases;            // all reads' bases, concatenated (ASCII)
+    const uint8_t* quals;            // all reads' base qualities, same offsets
+    const long long* read_off;       // [R+1]
+    const uint32_t* cigars;          // all reads' CIGAR operations, BAM packing: length << 4 | operation
+    const long long* cigar_off;      // [R+1]
+    const long long* ref_start;      // [R] genome position of the first aligned base
+    const uint8_t* mapq;             // [R]
+    const int8_t* orientation;       // [R] > 0 forward
+    const uint8_t* hp;               // [R] haplotag 0 | 1 | 2
+    const int32_t* site_of_read;     // [R]
+    const uint8_t* ref;              // all sites' reference windows, concatenated (ASCII)
+    const long long* ref_off;        // [S+1]
+    const long long* window_start;   // [S] genome position of ref window byte 0
+    const long long* asm_start;      // [S] allele span (assemblyStart, assemblyStop)
+    const long long* asm_stop;       // [S]
+    long long n_reads;
+    int length, channels;            // feature length L, 6 | 7
+    uint8_t* out;                    // [R][L][C]
+};
+hipError_t launch_featurize(const FeaturizeArgs& a, hipStream_t stream);
+
 }  // namespace hello

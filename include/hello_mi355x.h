@@ -157,6 +157,28 @@ int hello_engine_posteriors(hello_engine* engine, const float* logits, const flo
                             const int32_t* alleles_per_site, int32_t n_sites, int32_t n_alleles,
                             int64_t n_pairs_total, float* out, int32_t flags, void* hip_stream);
 
+/* Stands in for: AlleleSearcherLite.computeFeaturesColoredSimple (the C++ featurizer behind
+ * python/AlleleSearcherLite.py:232-251, c++/src/AlleleSearcherLiteFiltered.cpp:971-1180), batched: every
+ * read of every allele of every site in one launch, written as uint8 [n_reads][feature_length][channels]
+ * ready to be passed to hello_engine_forward as `reads0` / `reads1`.
+ *   bases / quals          all reads' bases (ASCII) and base qualities, concatenated; read_offsets [R+1]
+ *   cigars                 BAM packing (length << 4 | operation), concatenated; cigar_offsets [R+1]
+ *   ref_starts, mapq, orientation (> 0 forward), hp (0|1|2), site_of_read      per read
+ *   ref_windows            all sites' reference windows (ASCII), concatenated; ref_window_offsets [S+1]
+ *   window_starts, assembly_starts, assembly_stops                             per site (genome positions)
+ * A read with zero CIGAR operations yields the all-zero dummy row of an unsupported allele (:1037-1043).
+ * `flags`: HELLO_IN_DEVICE when ALL input arrays are device pointers, HELLO_OUT_DEVICE for `out`. */
+int hello_engine_featurize(hello_engine* engine,
+                           const uint8_t* bases, const uint8_t* quals, const int64_t* read_offsets,
+                           const uint32_t* cigars, const int64_t* cigar_offsets,
+                           const int64_t* ref_starts, const uint8_t* mapq, const int8_t* orientation,
+                           const uint8_t* hp, const int32_t* site_of_read,
+                           const uint8_t* ref_windows, const int64_t* ref_window_offsets,
+                           const int64_t* window_starts, const int64_t* assembly_starts,
+                           const int64_t* assembly_stops,
+                           int64_t n_reads, int32_t n_sites, int32_t feature_length, int32_t channels,
+                           uint8_t* out, int32_t flags, void* hip_stream);
+
 /* Wait for everything the engine has enqueued on its last stream. */
 int hello_engine_synchronize(hello_engine* engine);
 
