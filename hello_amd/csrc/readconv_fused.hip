@@ -5,34 +5,36 @@
 // shortcut, 3 x ResidualBlock(64) -- followed by reduceSlots over the reads of each allele
 // (MixtureOfExpertsAdvanced.py:23-34,163).  That is 5 076 096 MAC per read, 83 % of a 30x site.
 //
-// One workgroup carries G reads through all 18 convolutions with every activation resident in LDS;
-// nothing but the bytes is read and nothing but per-allele partial sums is written.  Two geometries are
-// compiled: <G=4, 4 waves> (two workgroups per CU: one workgroup's barriers and prologue hide behind the
-// other's MFMAs) and <G=8, 8 waves> (one workgroup per CU, less tile padding).
+// One workgroup (256 threads = 4 waves) carries G = 4 reads through all 18 convolutions with every
+// activation resident in LDS; nothing but the bytes is read and nothing but per-allele partial sums is
+// written.  Two workgroups share a CU (2 waves per SIMD): one workgroup's barriers, prologue and epilogues
+// hide behind the other's MFMAs.
 //
-//   LDS     two ping-pong images, float32 channels-last [row][channel]; the reads of the group are
-//           stacked along the row axis with ONE shared zero row between neighbours (row stride 72 at 71
-//           positions, 37 at 36), so the k=3/pad=1 convolutions need no edge handling: the pad row is
-//           written as zero by every epilogue.  16-byte chunks of a row are XOR-swizzled with the row
+//   LDS     two ping-pong images, float32 channels-last [row][channel].  At 32 channels the reads of the
+//           group are stacked along the row axis with ONE shared zero row between neighbours (row stride 72
+//           at 71 positions), so the k=3/pad=1 convolutions need no edge handling.  At 64 channels the reads
+//           are stacked with no rows between them (144 rows = 9 tiles exactly) and the taps that would cross
+//           a read boundary are zeroed in registers.  16-byte chunks of a row are XOR-swizzled with the row
 //           index (chunk ^ 2*(row&7) at 64 channels) so that the ds_read_b128 operand reads of 16
 //           consecutive rows, issued by lanes of two different channel quarters, hit 16 distinct bank
 //           groups whatever the tile's first row is.
 //   MFMA    v_mfma_f32_16x16x4_f32 (exact fp32), D[channel][position] = W[channel][k] X[k][position]:
-//           a wave owns one 16-channel block and walks 16-position tiles, two accumulation chains in
-//           flight so the 40-cycle dependent latency of the 32-cycle instruction is covered.  Lane (j, q)
-//           of a tile ends with channels 4q..4q+3 of position j -> bias / ReLU / residual / store are
-//           float4.  k is ordered so that lane-quarter q supplies channels 16m+4q+t at step (tap, m, t)
-//           for BOTH operands: one ds_read_b128 feeds four MFMAs.
-//   weights each wave keeps ONLY its own 16-channel slice of the layer in registers (<= 48 VGPRs),
-//           loaded straight from L2 in lane order (pre-packed by hello_amd/readconv_pack.py); the next
-//           layer's slice is requested before the current layer's MFMAs start.
-//   stem    runs in sub-batches inside the same kernel with its temporaries in the second image.  Reads
-//           of a sub-batch are stacked at their natural stride of 150 rows, so the three valid
-//           convolutions run over the stacked rows as one sequence; rows whose window straddles two
+//           a wave owns one 16-channel block and walks 16-position tiles in pairs, two accumulation chains
+//           per tile (four in flight: the 40-cycle dependent latency of the 32-cycle instruction never
+//           shows).  Lane (j, q) of a tile ends with channels 4q..4q+3 of position j -> bias / ReLU /
+//           residual / store are float4.  k is ordered so that lane-quarter q supplies channels 16m+4q+t at
+//           step (tap, m, t) for BOTH operands: one ds_read_b128 feeds four MFMAs.
+//   pipeline operands two steps ahead of the MFMAs that use them, across tile pairs; the previous pair's
+//           epilogue interleaved with the current pair's MFMAs; see conv_layer.
+//   weights each wave keeps ONLY its own 16-channel slice of ONE layer in registers (<= 48 VGPRs), loaded
+//           straight from L2 in lane order (pre-packed by hello_amd/readconv_pack.py); the next layer's
+//           slice is rolled in place, each register refilled right after its last use.
+//   stem    runs first in the same kernel over the stacked reads (natural stride 150 rows): the three
+//           valid convolutions run over the stacked rows as one sequence; rows whose window straddles two
 //           reads are garbage nothing valid consumes.  conv1 reads the bytes themselves: with
 //           channels-last bytes the im2col index k = tap*C + c is the byte offset from the row start.
 //           conv3 tiles overlap by two rows (stride 14) so each tile max-pools 7 outputs inside one
-//           16-lane row with two lane shifts, and only the pooled values ever reach LDS.
+//           16-lane row with two DPP lane shifts, and only the pooled values ever reach LDS.
 //   sum     reads of an allele are contiguous, so the group adds its reads per allele in order and
 //           writes one partial [36][64] slot per (group, allele) incidence; a tiny finalize kernel adds
 //           an allele's slots in order.  No atomics: results are bit-reproducible.
