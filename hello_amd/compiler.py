@@ -31,7 +31,7 @@ ROWS_READS0, ROWS_READS1, ROWS_ALLELES, ROWS_SITES = 0, 1, 2, 3
 SEG_R0A, SEG_R1A, SEG_AS = 0, 1, 2
 BUF_NONE, BUF_READS0, BUF_READS1, BUF_REF, BUF_FIRST_SCRATCH = -1, 0, 1, 2, 3
 OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED = range(1, 9)
-FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX = 1, 2, 4
+FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST = 1, 2, 4, 8
 OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
             8: "readconv_fused"}
 
@@ -273,9 +273,9 @@ class _Lowering:
         return y
 
     # -- model -------------------------------------------------------------------------------
-    def read_frames(self, tech: int) -> Value:
+    def read_frames(self, tech: int, stem: str = "read_convolver") -> Value:
         spec = self.spec
-        name = f"read_convolver{tech}"
+        name = f"{stem}{tech}"
         nodes = spec.nets[name]
         cin = spec.channels[tech]
         buf = BUF_READS0 if tech == 0 else BUF_READS1
@@ -316,8 +316,45 @@ class _Lowering:
             self.net(spec.nets[xattn], (ca, (cs0, cs1)), head_slot=slot)
         return (cs0, cs1), ca
 
+    def lower_merged(self):
+        """MoEMergedAdvanced.forward (MixtureOfExpertsAdvanced.py:398-484), useAdditive=True."""
+        spec = self.spec
+        hybrid = spec.has("readConv1")
+
+        def expert(idx, allele: Value, site: Value):
+            x = self.new(ROWS_ALLELES, allele.length, allele.channels)
+            self.ops.append(Op(OP_MIX, ROWS_ALLELES, src0=allele.vid, src1=site.vid, dst=x.vid,
+                               cin=allele.channels, lin=allele.length, lout=allele.length,
+                               a0=2.0, a1=-1.0, seg=SEG_AS, flags=FLAG_MIX_REST))
+            self.net(spec.nets[f"expert{idx}"], x, head_slot=idx)
+
+        a0 = self.net(spec.nets["alleleConv0"], self.read_frames(0, "readConv"))
+        s0 = self.segsum(a0, SEG_AS)
+        expert(0, a0, s0)
+        if not hybrid:
+            return 1, False
+        for need in ("alleleConv1", "expert1", "expert2", "meta"):
+            if not spec.has(need):
+                raise ValueError(f"hybrid MoEMergedAdvanced needs {need}")
+        a1 = self.net(spec.nets["alleleConv1"], self.read_frames(1, "readConv"))
+        s1 = self.segsum(a1, SEG_AS)
+        expert(1, a1, s1)
+        if spec.has("alleleConvCombiner"):
+            a2 = self.net(spec.nets["alleleConvCombiner"], (a0, a1))
+        else:
+            a2 = self.add(a0, a1)                                                     # :419
+        if spec.has("siteConvCombiner"):
+            s2 = self.net(spec.nets["siteConvCombiner"], (s0, s1))
+        else:
+            s2 = self.segsum(a2, SEG_AS)                                              # :434
+        expert(2, a2, s2)
+        self.net(spec.nets["meta"], s2, head_slot=3, softmax=True)
+        return 3, True
+
     def lower(self):
         spec = self.spec
+        if spec.family == "merged":
+            return self.lower_merged()
         hybrid = spec.has("read_convolver1")
         has = [spec.has(f"xattn{i}") for i in range(3)]
         if not hybrid:
@@ -413,6 +450,6 @@ def compile_model(spec: ns.ModelSpec, state, fused: bool = True) -> Program:
     buffers = _allocate(low.ops, low.values)
     return Program(
         spec_name=spec.name, window=spec.window, channels0=spec.channels[0],
-        channels1=spec.channels[1] if spec.has("read_convolver1") else 0,
+        channels1=spec.channels[1] if spec.hybrid_inputs else 0,
         n_experts=n_experts, has_meta=has_meta, uses_ref=low.uses_ref, ops=low.ops,
         buffers=buffers, weights=low.blob.finish(), fused_read_convolver=low.used_fused)

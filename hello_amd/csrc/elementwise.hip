@@ -76,6 +76,9 @@ hipError_t launch_segsum(const float* src, float* dst, const int32_t* off, int n
 }
 
 // ---- dst[a] = a0*src0[a] + a1*src1[owner[a]] -------------------------------------------------
+// REST: dst[a] = src0[a] - (src1[owner[a]] - src0[a]), the "allele minus the other alleles of its site"
+// expert input of MoEMergedAdvanced (MixtureOfExpertsAdvanced.py:372-383), in the reference's rounding order.
+template <bool REST>
 __global__ void mix_kernel(const float* __restrict__ src0, const float* __restrict__ src1,
                            float* __restrict__ dst, const int32_t* __restrict__ owner, long long n4,
                            int row4, float a0, float a1) {
@@ -88,17 +91,21 @@ __global__ void mix_kernel(const float* __restrict__ src0, const float* __restri
         f32x4 v;
         // LinearCombination (NNTools.py:771-777): result = 0; result += c0*x; result += c1*s
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = a0 * x[e] + a1 * s[e];
+        for (int e = 0; e < 4; ++e) v[e] = REST ? x[e] - (s[e] - x[e]) : a0 * x[e] + a1 * s[e];
         *(f32x4*)(dst + i * 4) = v;
     }
 }
 
 hipError_t launch_mix(const float* src0, const float* src1, float* dst, const int32_t* owner,
-                      long long rows, int row_floats, float a0, float a1, hipStream_t stream) {
+                      long long rows, int row_floats, float a0, float a1, bool rest, hipStream_t stream) {
     const long long n4 = rows * (row_floats / 4);
     if (n4 <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mix_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, stream, src0, src1, dst, owner,
-                       n4, row_floats / 4, a0, a1);
+    if (rest)
+        hipLaunchKernelGGL(mix_kernel<true>, dim3(grid_for(n4, 256)), dim3(256), 0, stream, src0, src1, dst, owner,
+                           n4, row_floats / 4, a0, a1);
+    else
+        hipLaunchKernelGGL(mix_kernel<false>, dim3(grid_for(n4, 256)), dim3(256), 0, stream, src0, src1, dst, owner,
+                           n4, row_floats / 4, a0, a1);
     return hipGetLastError();
 }
 

@@ -562,7 +562,8 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
             }
             case HELLO_OP_MIX:
                 HIP_TRY(hello::launch_mix((const float*)ptr(o.src0), (const float*)ptr(o.src1), (float*)ptr(o.dst),
-                                          e->site_of_allele, rows, o.lin * o.cin, o.a0, o.a1, stream));
+                                          e->site_of_allele, rows, o.lin * o.cin, o.a0, o.a1,
+                                          (o.flags & HELLO_FLAG_MIX_REST) != 0, stream));
                 break;
             case HELLO_OP_HEAD: {
                 float* outp;

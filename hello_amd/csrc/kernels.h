@@ -31,7 +31,7 @@ hipError_t launch_segsum(const float* src, float* dst, const int32_t* off, int n
 
 // dst[a][e] = a0*src0[a][e] + a1*src1[owner[a]][e]
 hipError_t launch_mix(const float* src0, const float* src1, float* dst, const int32_t* owner,
-                      long long rows, int row_floats, float a0, float a1, hipStream_t stream);
+                      long long rows, int row_floats, float a0, float a1, bool rest, hipStream_t stream);
 
 // out[o*out_stride_o + row*out_stride_row] = b[o] + sum_c W[o][c] * mean_l src[row][l][c]; optional softmax over o
 hipError_t launch_head(const float* src, const float* w, const float* b, float* out, long long rows,

@@ -193,11 +193,40 @@ _MOE_ATTENTION_NETS = ["read_convolver0", "read_convolver1", "compressor0", "com
                        "xattn0", "xattn1", "xattn2", "combiner0", "combiner1", "meta"]
 
 
+_MOE_MERGED_NETS = ["readConv0", "readConv1", "alleleConv0", "alleleConv1", "expert0", "expert1", "expert2", "meta"]
+
+
+def _spec_from_merged(moe) -> ns.ModelSpec:
+    """Pickled ``MoEMergedAdvanced`` (MixtureOfExpertsAdvanced.py:255-331).  Supported: the additive form
+    (useAdditive=True) without separate meta convolvers -- what MoEMergedConfig250FeatureMap.py describes."""
+    if not moe.__dict__.get("useAdditive", False):
+        raise NotImplementedError("MoEMergedAdvanced with useAdditive=False (concatenated expert input) is not supported")
+    if any(n.endswith("Meta") and m is not None for n, m in moe._modules.items()):
+        raise NotImplementedError("MoEMergedAdvanced with separate meta convolvers is not supported")
+    nets = {}
+    for name in _MOE_MERGED_NETS:
+        sub = moe._modules.get(name)
+        if sub is not None:
+            if _cls(sub) != "Network":
+                raise NotImplementedError(f"{name} is a {_cls(sub)}, expected NNTools.Network")
+            nets[name] = _convert(sub, f"moeMerged.{name}")
+    for name in ("alleleConvCombiner", "siteConvCombiner"):
+        sub = moe._modules.get(name)
+        if sub is not None:          # ConvCombiner: cat along channels, then its Network (:37-44)
+            nets[name] = [ns.Concat()] + _convert(sub._modules["network"], f"moeMerged.{name}.network")
+    first0 = next(ns.walk(nets["readConv0"]))
+    c1 = next(ns.walk(nets["readConv1"])).cin if "readConv1" in nets else first0.cin
+    return ns.ModelSpec(nets, name="reference_pickle", channels=(first0.cin, c1), family="merged")
+
+
 def spec_from_module(wrapper) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:
     """Pickled ``MoEMergedWrapperAdvanced`` (stand-in instance) -> (ModelSpec, state dict)."""
     moe = wrapper._modules.get("moeMerged")
+    if moe is not None and _cls(moe) == "MoEMergedAdvanced":
+        state = {k: v.detach().cpu().numpy() for k, v in wrapper.state_dict().items()}
+        return _spec_from_merged(moe), state
     if moe is None or _cls(moe) != "MoEAttention":
-        raise NotImplementedError(f"only MoEAttention models are supported (got {_cls(moe) if moe is not None else None})")
+        raise NotImplementedError(f"unsupported model class {_cls(moe) if moe is not None else None}")
     nets = {}
     for name in _MOE_ATTENTION_NETS:
         sub = moe._modules.get(name)

@@ -109,14 +109,15 @@ class ModelSpec:
     window: int = 150
     channels: Tuple[int, int] = (6, 6)
     prefix: str = "moeMerged"
+    family: str = "attention"        # "attention": MoEAttention (:71-252);  "merged": MoEMergedAdvanced (:255-484)
 
     def has(self, net: str) -> bool:
         return net in self.nets and self.nets[net] is not None
 
     @property
     def hybrid_inputs(self) -> bool:
-        """Two read technologies are convolved (read_convolver1 configured, :170-172)."""
-        return self.has("read_convolver1")
+        """Two read technologies are convolved (read_convolver1 / readConv1 configured, :170-172, :401)."""
+        return self.has("read_convolver1") or self.has("readConv1")
 
     @property
     def ensemble(self) -> bool:
@@ -334,6 +335,72 @@ def hybrid_ensemble2(norm="wn", prefix="moeMerged") -> ModelSpec:
     return ModelSpec(nets, name="hybrid_ensemble2", prefix=prefix)
 
 
+# --------------------------------------------------------------------------------------------
+# the older family: MoEMergedAdvanced (reference MixtureOfExpertsAdvanced.py:255-484) built by
+# createMoEFullMergedAdvancedModel (:614-654) from the "*Deeper" layer lists.  Same blocks, other names:
+# readConv = MoEReadConvolverDeeper.py, alleleConv = ExpertAlleleConvolverDeeper.py,
+# expert = ExpertGraphConvolverDeeper.py (no Mix node: the model forms a - (s - a) itself, :372-383),
+# combiners = ConvCombinerResNetDeeper.py and meta = MetaCombinerDeeper.py (both always BatchNorm).
+# --------------------------------------------------------------------------------------------
+def graph_convolver(prefix: str, norm="wn") -> List[Node]:
+    """ExpertGraphConvolverDeeper.py: [128,18] -> [256,9] -> logit."""
+    s = _Seq(f"{prefix}.network", norm)
+    s.conv(128, 128, 1)
+    s.residual(128, 256, stride=2)
+    s.residual(256, 256)
+    s.residual(256, 256)
+    s.head(256, 1)
+    return s.nodes
+
+
+def conv_combiner_deeper(prefix: str) -> List[Node]:
+    """ConvCombinerResNetDeeper.py inside a ConvCombiner module (MixtureOfExpertsAdvanced.py:37-44):
+    cat -> 256->512 k3 -> 512->128 k1, BatchNorm; parameters live under <prefix>.network.network."""
+    s = _Seq(f"{prefix}.network.network", "bn")
+    s.nodes.append(Concat())
+    s.conv(256, 512, 3, pad=1)
+    s.conv(512, 128, 1)
+    return s.nodes
+
+
+def meta_combiner_deeper(prefix: str) -> List[Node]:
+    """MetaCombinerDeeper.py: site frames [128,18] -> 3 mixing logits, BatchNorm."""
+    s = _Seq(f"{prefix}.network", "bn")
+    s.conv(128, 128, 1)
+    s.residual(128, 256, stride=2)
+    s.residual(256, 256)
+    s.residual(256, 256)
+    s.head(256, 3)
+    return s.nodes
+
+
+def merged_single(norm="wn", prefix="moeMerged") -> ModelSpec:
+    nets = _nets(prefix, {
+        "readConv0": (read_convolver, dict(norm=norm)),
+        "alleleConv0": (compressor, dict(norm=norm)),
+        "expert0": (graph_convolver, dict(norm=norm)),
+    })
+    return ModelSpec(nets, name="merged_single", prefix=prefix, family="merged")
+
+
+def merged_hybrid(norm="wn", prefix="moeMerged") -> ModelSpec:
+    """Hybrid MoEMergedAdvanced with useAdditive=True and both combiners (the form
+    MoEMergedConfig250FeatureMap.py:3-14 describes, at the shipped 150 bp window)."""
+    nets = _nets(prefix, {
+        "readConv0": (read_convolver, dict(norm=norm)),
+        "readConv1": (read_convolver, dict(norm=norm)),
+        "alleleConv0": (compressor, dict(norm=norm)),
+        "alleleConv1": (compressor, dict(norm=norm)),
+        "expert0": (graph_convolver, dict(norm=norm)),
+        "expert1": (graph_convolver, dict(norm=norm)),
+        "expert2": (graph_convolver, dict(norm=norm)),
+        "alleleConvCombiner": (conv_combiner_deeper, dict()),
+        "siteConvCombiner": (conv_combiner_deeper, dict()),
+        "meta": (meta_combiner_deeper, dict()),
+    })
+    return ModelSpec(nets, name="merged_hybrid", prefix=prefix, family="merged")
+
+
 CONFIGS = {
     "single_tech": lambda **kw: single_tech(**kw),
     "single_tech_hp": lambda **kw: single_tech(in_channels=7, **kw),
@@ -341,6 +408,8 @@ CONFIGS = {
     "hybrid_no_ensemble_wide": lambda **kw: hybrid_no_ensemble(w=2, **kw),
     "hybrid_full": lambda **kw: hybrid_full(**kw),
     "hybrid_ensemble2": lambda **kw: hybrid_ensemble2(**kw),
+    "merged_single": lambda **kw: merged_single(**kw),
+    "merged_hybrid": lambda **kw: merged_hybrid(**kw),
 }
 
 # name of the reference config module each spec corresponds to (used only by the fixture generator,

@@ -53,10 +53,12 @@ def synth_state(spec: ns.ModelSpec, seed: int = 0, gain: float = 1.0) -> Dict[st
                 shape = (node.cout, node.cin)
                 fan_in = node.cin
             layer_gain = gain * float(rng.uniform(0.9, 1.3))
-            if first and net_name.startswith("read_convolver"):
+            if first and net_name.startswith(("read_convolver", "readConv")):
                 layer_gain /= 128.0
-            if first and net_name.startswith("compressor"):
+            if first and net_name.startswith(("compressor", "alleleConv")) and "Combiner" not in net_name:
                 layer_gain /= 24.0          # its input is a sum over ~tens of reads
+            if first and net_name.startswith("expert"):
+                layer_gain /= 4.0           # 2a - s over a handful of alleles
             if ".ffNetwork.network.3" in node.key:
                 layer_gain *= 0.4           # keep x + f(x) from doubling the scale per block
             if isinstance(node, ns.Head):

@@ -167,6 +167,8 @@ class Oracle:
         tensors = (T0, T1|None) with T [sumR, C, L] (any dtype; cast to float32 like ``.float()``).
         Returns logits [sumA, 1] (single expert) or ([e0, e1, e2], meta [S, 3])."""
         spec = self.spec
+        if spec.family == "merged":
+            return self.forward_merged(tensors, alleles_per_site, reads_per_allele)
         aps = np.asarray(alleles_per_site, dtype=np.int64)
         rc0 = self._net("read_convolver0", np.asarray(tensors[0], dtype=F32))
         frames0 = segment_sum(rc0, reads_per_allele[0])
@@ -206,6 +208,41 @@ class Oracle:
         if p2 is None:
             p2 = np.zeros_like(p0)
         return [p0, p1, p2], meta
+
+
+def _forward_merged(self, tensors, alleles_per_site, reads_per_allele):
+    """``MoEMergedAdvanced.forward`` (MixtureOfExpertsAdvanced.py:398-484) with useAdditive=True and no
+    separate meta convolvers: read conv -> allele sums -> allele conv (:332-342); per-site frames
+    (:369-370, :422-436); expert input a - (repeat(s) - a) (:372-383); meta softmax over dim 1 (:480)."""
+    spec = self.spec
+    aps = np.asarray(alleles_per_site, dtype=np.int64)
+    a0 = self._net("alleleConv0", segment_sum(self._net("readConv0", np.asarray(tensors[0], dtype=F32)),
+                                              reads_per_allele[0]))
+    hybrid = spec.has("readConv1") and tensors[1] is not None
+    if hybrid:
+        a1 = self._net("alleleConv1", segment_sum(self._net("readConv1", np.asarray(tensors[1], dtype=F32)),
+                                                  reads_per_allele[1]))
+        a2 = self._net("alleleConvCombiner", (a0, a1)) if spec.has("alleleConvCombiner") else a0 + a1
+    s0 = segment_sum(a0, aps)
+
+    def expert(idx, allele, site):
+        remaining = np.repeat(site, aps, axis=0) - allele
+        return self._net(f"expert{idx}", allele - remaining)
+
+    p0 = expert(0, a0, s0)
+    self.last = {"ca0": a0}
+    if not hybrid:
+        return p0
+    s1 = segment_sum(a1, aps)
+    s2 = self._net("siteConvCombiner", (s0, s1)) if spec.has("siteConvCombiner") else segment_sum(a2, aps)
+    p1, p2 = expert(1, a1, s1), expert(2, a2, s2)
+    logits = self._net("meta", s2)
+    logits = logits - logits.max(axis=1, keepdims=True)
+    e = np.exp(logits)
+    return [p0, p1, p2], (e / e.sum(axis=1, keepdims=True)).astype(F32)
+
+
+Oracle.forward_merged = _forward_merged
 
 
 # --------------------------------------------------------------------------------------------

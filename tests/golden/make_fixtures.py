@@ -41,7 +41,37 @@ def state_digest(state):
     return h.hexdigest()[:16]
 
 
+def reference_merged(config_name):
+    """The older MoEMergedAdvanced family through the reference's own factory
+    (MixtureOfExpertsAdvanced.py:614-654) and its "*Deeper" layer modules, weight-normed where the layer
+    module has the switch; combiners and meta stay BatchNorm, as the factory leaves them."""
+    hybrid = config_name == "merged_hybrid"
+    cfg = {
+        "weight_norm": True,
+        "readConvNGS": "MoEReadConvolverDeeper",
+        "alleleConvSingleNGS": "ExpertAlleleConvolverDeeper",
+        "graphConvSingleNGS": "ExpertGraphConvolverDeeper",
+        "kwargs": {"useAdditive": True},
+    }
+    if hybrid:
+        cfg.update({
+            "readConvTGS": "MoEReadConvolverDeeper",
+            "alleleConvSingleTGS": "ExpertAlleleConvolverDeeper",
+            "graphConvSingleTGS": "ExpertGraphConvolverDeeper",
+            "graphConvHybrid": "ExpertGraphConvolverDeeper",
+            "alleleConvCombiner": "ConvCombinerResNetDeeper",
+            "siteConvCombiner": "ConvCombinerResNetDeeper",
+            "meta": "MetaCombinerDeeper",
+        })
+    moe = REF.createMoEFullMergedAdvancedModel(cfg)
+    wrapper = REF.createMoEFullMergedAdvancedModelWrapper(moe)
+    wrapper.eval()
+    return wrapper
+
+
 def reference_model(config_name, norm):
+    if config_name.startswith("merged"):
+        return reference_merged(config_name)
     modname = ns.REFERENCE_CONFIG_MODULE[config_name]
     module = importlib.import_module(modname)
     module = importlib.reload(module)
@@ -77,7 +107,8 @@ def run_batched(wrapper, batch):
         rpa1 = batch.reads_per_allele1.tolist()
     seg = torch.from_numpy(batch.ref_onehot).float()
     captured = {}
-    hook = wrapper.moeMerged.read_convolver0.register_forward_hook(
+    read_conv = getattr(wrapper.moeMerged, "read_convolver0", None) or wrapper.moeMerged.readConv0
+    hook = read_conv.register_forward_hook(
         lambda m, i, o: captured.__setitem__("rc0", o.detach().numpy().copy()))
     with torch.no_grad():
         out = wrapper.moeMerged((t0, t1), batch.alleles_per_site.tolist(),
@@ -148,6 +179,9 @@ CASES = [
     ("hybrid_full", "hybrid_full", "wn", 3, 16, dict(coverage=25, hybrid_coverage=12), True, False, ("multi",)),
     ("hybrid_ensemble2", "hybrid_ensemble2", "wn", 3, 17, dict(coverage=25, hybrid_coverage=12),
      True, False, ("one", "multi")),
+    ("merged_single", "merged_single", "wn", 4, 18, dict(coverage=25), True, False, ("one", "multi", "dummy")),
+    ("merged_hybrid", "merged_hybrid", "wn", 3, 19, dict(coverage=20, hybrid_coverage=10), True, False,
+     ("one", "multi")),
 ]
 
 
@@ -210,10 +244,77 @@ def make_pickle_fixture():
           f"[{res['logits'].min():.3f},{res['logits'].max():.3f}]")
 
 
+def make_merged_pickle_fixture():
+    """A real reference pickle of the older family: a small hybrid MoEMergedAdvanced (additive, both
+    combiners, meta) built by the reference factory from layer lists, torch.save'd whole."""
+    wn = dict(use_weight_norm=True)
+    rb = dict(kernelSizes=[3, 3], paddings=[1, 1], dilations=[1, 1])
+
+    def read_conv():
+        c = NNTools.SingleConvLayer(6, 8, 3, 0, 1, 1, **wn)
+        c.append({"type": "MaxPool1d", "kwargs": {"kernel_size": 3, "stride": 2, "padding": 0}})
+        return c + [NNTools.ResidualBlockFTShortcut(8, 8, strides=[1, 1], **rb, **wn),
+                    NNTools.ResidualBlockConvShortcut(8, 16, strides=[2, 1, 2], **rb, **wn)]
+
+    def allele_conv():
+        return NNTools.SingleConvLayer(16, 16, 1, 0, 1, 1, **wn) + \
+            [NNTools.ResidualBlockConvShortcut(16, 32, strides=[2, 1, 2], **rb, **wn)]
+
+    def graph_conv(norm_kw, outputs=1):
+        c = NNTools.SingleConvLayer(32, 32, 1, 0, 1, 1, **norm_kw)
+        c += [NNTools.ResidualBlockConvShortcut(32, 64, strides=[2, 1, 2], **rb, **norm_kw)]
+        return c + NNTools.terminus(64, outputs, **norm_kw)
+
+    def combiner():
+        return NNTools.SingleConvLayer(64, 48, 3, 1, 1, 1) + NNTools.SingleConvLayer(48, 32, 1, 0, 1, 1)
+
+    torch.manual_seed(8765)
+    moe = REF.createMoEFullMergedAdvancedModel({
+        "readConvNGS": read_conv(), "readConvTGS": read_conv(),
+        "alleleConvSingleNGS": allele_conv(), "alleleConvSingleTGS": allele_conv(),
+        "graphConvSingleNGS": graph_conv(wn), "graphConvSingleTGS": graph_conv(wn), "graphConvHybrid": graph_conv(wn),
+        "alleleConvCombiner": combiner(), "siteConvCombiner": combiner(), "meta": graph_conv({}, 3),
+        "kwargs": {"useAdditive": True},
+    })
+    wrapper = REF.createMoEFullMergedAdvancedModelWrapper(moe)
+    wrapper.eval()
+    with torch.no_grad():
+        for name, p in wrapper.named_parameters():
+            if name.endswith("weight_g"):
+                p.mul_(1.0 + 0.25 * torch.rand_like(p))
+            if name in ("moeMerged.readConv0.network.0.conv1d.weight_g", "moeMerged.readConv1.network.0.conv1d.weight_g"):
+                p.div_(128.0)
+        for name, b in wrapper.named_buffers():      # non-trivial BatchNorm statistics
+            if name.endswith("running_mean"):
+                b.copy_(0.2 * torch.rand_like(b) - 0.1)
+            if name.endswith("running_var"):
+                b.copy_(0.5 + torch.rand_like(b))
+    path = os.path.join(HERE, "mini_merged.wrapper.dnn")
+    torch.save(wrapper, path)
+    batch = synth.make_sites(4, seed=654, coverage=12, hybrid_coverage=8)
+    res = run_batched(wrapper, batch)
+    res.pop("frames0")
+    res.update(run_wrapper(wrapper, batch, synth.allele_names(batch)))
+    wrapper.providePredictions = False
+    payload = dict(reads0=batch.reads0, reads_per_allele0=batch.reads_per_allele0,
+                   reads1=batch.reads1, reads_per_allele1=batch.reads_per_allele1,
+                   alleles_per_site=batch.alleles_per_site, ref_onehot=batch.ref_onehot)
+    payload.update({"exp_" + k: v for k, v in res.items()})
+    np.savez_compressed(os.path.join(HERE, "mini_merged.npz"), **payload)
+    print(f"mini_merged: pickle {os.path.getsize(path) / 1024:.0f} KB, logits "
+          f"[{res['logits'].min():.3f},{res['logits'].max():.3f}] meta {res['meta'][0]}")
+
+
 def main():
+    only = set(sys.argv[1:])          # optional: regenerate just the named fixtures
     sanity_known_answer()
-    make_pickle_fixture()
+    if not only or "mini_reference" in only:
+        make_pickle_fixture()
+    if not only or "mini_merged" in only:
+        make_merged_pickle_fixture()
     for name, cfg, norm, n_sites, wseed, kw, with_wrapper, keep_frames, need in CASES:
+        if only and name not in only:
+            continue
         spec = ns.build(cfg, norm=norm) if norm != "wn" else ns.build(cfg)
         state = weights.synth_state(spec, seed=wseed)
         wrapper = reference_model(cfg, norm)

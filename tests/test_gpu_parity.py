@@ -48,7 +48,8 @@ def test_golden_logits(engines, name, fused):
         assert meta is None
 
 
-@pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_full", "hybrid_ensemble2", "hybrid_no_ensemble"])
+@pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_full", "hybrid_ensemble2", "hybrid_no_ensemble",
+                                  "merged_single", "merged_hybrid"])
 def test_golden_posteriors(engines, name):
     spec, state, batch, exp = load_fixture(name)
     eng = get_engine(engines, name, spec, state, True)
@@ -67,6 +68,7 @@ def test_golden_posteriors(engines, name):
     ("single_tech", dict(coverage=30)),
     ("single_tech_hp", dict(coverage=(20, 80), channels=7, tech="pacbio")),
     ("hybrid_no_ensemble", dict(coverage=30, hybrid_coverage=15)),
+    ("merged_hybrid", dict(coverage=25, hybrid_coverage=10)),
 ])
 def test_fresh_batches_match_oracle(engines, cfg, kw):
     from oracle import moe_oracle as mo

@@ -31,7 +31,7 @@ def site_dicts(batch, as_float=True):
 
 
 @pytest.mark.parametrize("name", ["single_tech_batched", "single_tech_hp", "hybrid_no_ensemble", "hybrid_full",
-                                  "hybrid_ensemble2"])
+                                  "hybrid_ensemble2", "merged_single", "merged_hybrid"])
 def test_per_site_call_matches_reference_wrapper(name):
     import torch
     from hello_amd.wrapper import ScoringNetwork
@@ -85,6 +85,24 @@ def test_loader_runs_a_real_reference_pickle():
         mix, e0, _, _, meta = net(fd, seg)
         np.testing.assert_allclose(np.array([float(v) for v in mix.values()]), z[f"exp_site{s}_mix"], **PROB)
         assert meta.tolist() == [1.0, 0.0, 0.0]
+    net.close()
+
+
+def test_loader_runs_a_merged_family_pickle():
+    """MoEMergedAdvanced (hybrid, additive, combiners, BatchNorm meta) straight from a reference pickle."""
+    net = loader.load(os.path.join(GOLDEN, "mini_merged.wrapper.dnn"))
+    net.providePredictions = True
+    z = np.load(os.path.join(GOLDEN, "mini_merged.npz"))
+    batch = synth.SiteBatch(z["reads0"], z["reads_per_allele0"], z["alleles_per_site"], z["ref_onehot"],
+                            z["reads1"], z["reads_per_allele1"])
+    logits, meta = net.engine.forward_batch(batch)
+    np.testing.assert_allclose(logits, z["exp_logits"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(meta, z["exp_meta"], rtol=1e-5, atol=2e-6)
+    for s, (fd, seg) in enumerate(site_dicts(batch)):
+        mix, e0, e1, e2, m = net(fd, seg)
+        for got, key in ((mix, "mix"), (e0, "e0"), (e1, "e1"), (e2, "e2")):
+            np.testing.assert_allclose(np.array([float(v) for v in got.values()]), z[f"exp_site{s}_{key}"], **PROB)
+        np.testing.assert_allclose(m.numpy(), z[f"exp_site{s}_meta"], **PROB)
     net.close()
 
 

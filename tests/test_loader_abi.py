@@ -42,6 +42,22 @@ def test_reference_pickle_loads_without_reference_source():
     assert all(o.kind in compiler.OP_NAMES for o in prog.ops)
 
 
+def test_merged_family_pickle_loads_and_matches_reference():
+    """The older MoEMergedAdvanced family (hybrid, additive, BatchNorm combiners + meta)."""
+    spec, state = loader.load_spec(os.path.join(GOLDEN, "mini_merged.wrapper.dnn"))
+    assert spec.family == "merged" and spec.ensemble and spec.hybrid_inputs
+    assert set(spec.nets) == {"readConv0", "readConv1", "alleleConv0", "alleleConv1", "expert0", "expert1",
+                              "expert2", "meta", "alleleConvCombiner", "siteConvCombiner"}
+    z = np.load(os.path.join(GOLDEN, "mini_merged.npz"))
+    batch = synth.SiteBatch(z["reads0"], z["reads_per_allele0"], z["alleles_per_site"], z["ref_onehot"],
+                            z["reads1"], z["reads_per_allele1"])
+    logits, meta = mo.forward_batch(mo.Oracle(spec, state), batch)
+    np.testing.assert_allclose(logits, z["exp_logits"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(meta, z["exp_meta"], rtol=1e-5, atol=1e-6)
+    prog = compiler.compile_model(spec, state)
+    assert prog.n_experts == 3 and prog.has_meta and not prog.uses_ref
+
+
 def test_native_file_round_trip(tmp_path):
     spec = ns.build("single_tech_hp")
     state = weights.synth_state(spec, seed=3)
