@@ -76,9 +76,11 @@ def _stand_in_modules():
             setattr(mod, n, type(n, (torch.nn.Module,), {"__module__": modname}))
         return mod
 
-    saved = {k: sys.modules.get(k) for k in ("NNTools", "MixtureOfExpertsAdvanced")}
+    moe_modules = ("MixtureOfExpertsAdvanced", "MixtureOfExpertsAdvancedXferLearning")
+    saved = {k: sys.modules.get(k) for k in ("NNTools",) + moe_modules}
     sys.modules["NNTools"] = make("NNTools", _NNTOOLS_CLASSES)
-    sys.modules["MixtureOfExpertsAdvanced"] = make("MixtureOfExpertsAdvanced", _MOE_CLASSES)
+    for name in moe_modules:
+        sys.modules[name] = make(name, _MOE_CLASSES)
     try:
         yield
     finally:
@@ -127,7 +129,13 @@ def _conv_node(prefix, idx, layers, pos):
 
 
 def _convert(network, prefix: str) -> List[ns.Node]:
-    """A pickled ``NNTools.Network`` (its ``.network`` Sequential) -> node list."""
+    """A pickled ``NNTools.Network`` (its ``.network`` Sequential) -> node list.  A transfer-learning
+    model holds ``Sequential(Network, Network)`` instead (MixtureOfExpertsAdvancedXferLearning.py:132-137)."""
+    if _cls(network) == "Sequential":
+        nodes: List[ns.Node] = []
+        for name, child in network._modules.items():
+            nodes += _convert(child, f"{prefix}.{name}")
+        return nodes
     layers = _children(network._modules["network"])
     prefix = prefix + ".network"
     nodes: List[ns.Node] = []

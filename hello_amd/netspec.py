@@ -209,13 +209,14 @@ def read_convolver(prefix: str, norm="wn", in_channels=6, w=1, act="relu") -> Li
     return s.nodes
 
 
-def compressor(prefix: str, norm="wn", w=1, act="relu") -> List[Node]:
-    """architectures/compressor_conv_small.py:8-55.  [64,36] -> [128,18]."""
+def compressor(prefix: str, norm="wn", w=1, act="relu", blocks=2) -> List[Node]:
+    """architectures/compressor_conv_small.py:8-55.  [64,36] -> [128,18].  ``blocks`` = identity-shortcut
+    residual blocks after the strided one (3 in ExpertAlleleConvolver250FeatureMap.py)."""
     s = _Seq(f"{prefix}.network", norm, act)
     s.conv(64 * w, 64 * w, 1)
     s.residual(64 * w, 128 * w, stride=2)
-    s.residual(128 * w, 128 * w)
-    s.residual(128 * w, 128 * w)
+    for _ in range(blocks):
+        s.residual(128 * w, 128 * w)
     return s.nodes
 
 
@@ -336,6 +337,56 @@ def hybrid_ensemble2(norm="wn", prefix="moeMerged") -> ModelSpec:
 
 
 # --------------------------------------------------------------------------------------------
+# transfer-learning "addendum" models (MixtureOfExpertsAdvancedXferLearning.py:71-181): every sub-network
+# becomes Sequential(original Network, addendum Network) -- parameters under <net>.0.* and <net>.1.* -- and an
+# expert first loses its terminus (everything after its last residual block), which the addendum re-adds.
+# --------------------------------------------------------------------------------------------
+def _addendum_blocks(prefix: str, norm: str, channels: int, head: Optional[int] = None) -> List[Node]:
+    """architectures/read_convolver_addendum.py (64), compressor_conv_small_addendum.py (128),
+    xattn_subtract_addendum.py (256 + terminus): two identity-shortcut residual blocks."""
+    s = _Seq(f"{prefix}.network", norm)
+    s.residual(channels, channels)
+    s.residual(channels, channels)
+    if head is not None:
+        s.head(channels, head)
+    return s.nodes
+
+
+def _with_addendum(fn, channels, head=None):
+    def build(prefix, norm="wn", **kw):
+        base = fn(f"{prefix}.0", norm=norm, **kw)
+        if head is not None:
+            base = [n for n in base if not isinstance(n, Head)]
+        return base + _addendum_blocks(f"{prefix}.1", norm, channels, head)
+    return build
+
+
+def single_tech_addendum(norm="wn", prefix="moeMerged") -> ModelSpec:
+    """moe_attention_config_single_tech_old_equivalent_weight_norm_addendum.py on top of the single-tech model."""
+    nets = _nets(prefix, {
+        "read_convolver0": (_with_addendum(read_convolver, 64), dict(norm=norm)),
+        "compressor0": (_with_addendum(compressor, 128), dict(norm=norm)),
+        "xattn0": (_with_addendum(xattn_subtract, 256, head=1), dict(norm=norm)),
+    })
+    return ModelSpec(nets, name="single_tech_addendum", prefix=prefix)
+
+
+def hybrid_no_ensemble_addendum(norm="wn", prefix="moeMerged") -> ModelSpec:
+    """moe_attention_config_full_hybrid_old_equivalent_weight_norm_no_ensemble_addendum.py on top of the hybrid
+    no-ensemble model (the combiners get no addendum)."""
+    nets = _nets(prefix, {
+        "read_convolver0": (_with_addendum(read_convolver, 64), dict(norm=norm)),
+        "read_convolver1": (_with_addendum(read_convolver, 64), dict(norm=norm)),
+        "compressor0": (_with_addendum(compressor, 128), dict(norm=norm)),
+        "compressor1": (_with_addendum(compressor, 128), dict(norm=norm)),
+        "combiner0": (conv_combiner, dict(norm=norm)),
+        "combiner1": (conv_combiner, dict(norm=norm)),
+        "xattn2": (_with_addendum(xattn_subtract, 256, head=1), dict(norm=norm)),
+    })
+    return ModelSpec(nets, name="hybrid_no_ensemble_addendum", prefix=prefix)
+
+
+# --------------------------------------------------------------------------------------------
 # the older family: MoEMergedAdvanced (reference MixtureOfExpertsAdvanced.py:255-484) built by
 # createMoEFullMergedAdvancedModel (:614-654) from the "*Deeper" layer lists.  Same blocks, other names:
 # readConv = MoEReadConvolverDeeper.py, alleleConv = ExpertAlleleConvolverDeeper.py,
@@ -359,6 +410,19 @@ def conv_combiner_deeper(prefix: str) -> List[Node]:
     s = _Seq(f"{prefix}.network.network", "bn")
     s.nodes.append(Concat())
     s.conv(256, 512, 3, pad=1)
+    s.conv(512, 128, 1)
+    return s.nodes
+
+
+def conv_combiner_250(prefix: str) -> List[Node]:
+    """ConvCombiner250FeatureMap.py inside a ConvCombiner module: cat -> grouped (2) k3 256->256 ->
+    grouped strided residual block 256->512 -> 2 residual blocks 512 -> 1x1 512->128, BatchNorm."""
+    s = _Seq(f"{prefix}.network.network", "bn")
+    s.nodes.append(Concat())
+    s.conv(256, 256, 3, pad=1, groups=2)
+    s.residual(256, 512, stride=2, groups=(2, 2, 2))
+    s.residual(512, 512)
+    s.residual(512, 512)
     s.conv(512, 128, 1)
     return s.nodes
 
@@ -401,6 +465,25 @@ def merged_hybrid(norm="wn", prefix="moeMerged") -> ModelSpec:
     return ModelSpec(nets, name="merged_hybrid", prefix=prefix, family="merged")
 
 
+def merged_hybrid_250(prefix="moeMerged") -> ModelSpec:
+    """The 250 bp feature-map variant of MoEMergedAdvanced (MoEMergedConfig250FeatureMap.py:3-14 expressed
+    in the current factory's keys): BatchNorm throughout, a three-block allele convolver, the grouped
+    ConvCombiner250FeatureMap on allele features, no site-level combiner (site frames = sum of the combined
+    allele features, MixtureOfExpertsAdvanced.py:434)."""
+    nets = _nets(prefix, {
+        "readConv0": (read_convolver, dict(norm="bn")),
+        "readConv1": (read_convolver, dict(norm="bn")),
+        "alleleConv0": (compressor, dict(norm="bn", blocks=3)),
+        "alleleConv1": (compressor, dict(norm="bn", blocks=3)),
+        "expert0": (graph_convolver, dict(norm="bn")),
+        "expert1": (graph_convolver, dict(norm="bn")),
+        "expert2": (graph_convolver, dict(norm="bn")),
+        "alleleConvCombiner": (conv_combiner_250, dict()),
+        "meta": (meta_combiner_deeper, dict()),
+    })
+    return ModelSpec(nets, name="merged_hybrid_250", window=250, prefix=prefix, family="merged")
+
+
 CONFIGS = {
     "single_tech": lambda **kw: single_tech(**kw),
     "single_tech_hp": lambda **kw: single_tech(in_channels=7, **kw),
@@ -408,8 +491,11 @@ CONFIGS = {
     "hybrid_no_ensemble_wide": lambda **kw: hybrid_no_ensemble(w=2, **kw),
     "hybrid_full": lambda **kw: hybrid_full(**kw),
     "hybrid_ensemble2": lambda **kw: hybrid_ensemble2(**kw),
+    "single_tech_addendum": lambda **kw: single_tech_addendum(**kw),
+    "hybrid_no_ensemble_addendum": lambda **kw: hybrid_no_ensemble_addendum(**kw),
     "merged_single": lambda **kw: merged_single(**kw),
     "merged_hybrid": lambda **kw: merged_hybrid(**kw),
+    "merged_hybrid_250": lambda **kw: merged_hybrid_250(**kw),
 }
 
 # name of the reference config module each spec corresponds to (used only by the fixture generator,
@@ -421,6 +507,8 @@ REFERENCE_CONFIG_MODULE = {
     "hybrid_no_ensemble_wide": "moe_attention_config_full_hybrid_old_equivalent_weight_norm_no_ensemble_wide",
     "hybrid_full": "moe_attention_config_full_hybrid_old_equivalent_weight_norm",
     "hybrid_ensemble2": "moe_attention_config_full_hybrid_old_equivalent_weight_norm_ensemble2",
+    "single_tech_addendum": "moe_attention_config_single_tech_old_equivalent_weight_norm_addendum",
+    "hybrid_no_ensemble_addendum": "moe_attention_config_full_hybrid_old_equivalent_weight_norm_no_ensemble_addendum",
 }
 
 

@@ -63,15 +63,56 @@ def reference_merged(config_name):
             "siteConvCombiner": "ConvCombinerResNetDeeper",
             "meta": "MetaCombinerDeeper",
         })
+    if config_name == "merged_hybrid_250":
+        cfg = {
+            "readConvNGS": "MoEReadConvolver250FeatureMap", "readConvTGS": "MoEReadConvolver250FeatureMap",
+            "alleleConvSingleNGS": "ExpertAlleleConvolver250FeatureMap",
+            "alleleConvSingleTGS": "ExpertAlleleConvolver250FeatureMap",
+            "graphConvSingleNGS": "ExpertGraphConvolver250FeatureMap",
+            "graphConvSingleTGS": "ExpertGraphConvolver250FeatureMap",
+            "graphConvHybrid": "ExpertGraphConvolver250FeatureMap",
+            "alleleConvCombiner": "ConvCombiner250FeatureMap",
+            "meta": "MetaCombiner250FeatureMap",
+            "kwargs": {"useAdditive": True},
+        }
     moe = REF.createMoEFullMergedAdvancedModel(cfg)
     wrapper = REF.createMoEFullMergedAdvancedModelWrapper(moe)
     wrapper.eval()
     return wrapper
 
 
+class _Holder:
+    pass
+
+
+def _build_on_top(moe, addendum_cfg):
+    """MixtureOfExpertsDNNFastXferLearning.py:494-502: addendum layer lists -> Networks -> build_on_top."""
+    import MixtureOfExpertsAdvancedXferLearning as XF
+    orig = _Holder()
+    orig.module = _Holder()
+    orig.module.dnn = moe
+    params = {k: XF.make_network(addendum_cfg, k) for k in addendum_cfg}
+    new_moe, _ = XF.build_on_top(orig, **params)
+    wrapper = XF.createMoEFullMergedAdvancedModelWrapper(new_moe)
+    wrapper.eval()
+    return wrapper
+
+
+def reference_addendum(config_name):
+    """Transfer-learning models: the base model + the reference's own *_addendum config through
+    MixtureOfExpertsAdvancedXferLearning.build_on_top."""
+    import MixtureOfExpertsAdvancedXferLearning as XF
+    base = config_name[:-len("_addendum")]
+    base_cfg = importlib.reload(importlib.import_module(ns.REFERENCE_CONFIG_MODULE[base])).configDict
+    add_cfg = importlib.reload(importlib.import_module(ns.REFERENCE_CONFIG_MODULE[base] + "_addendum")).configDict
+    return _build_on_top(XF.create_moe_attention_model(base_cfg), add_cfg)
+
+
 def reference_model(config_name, norm):
     if config_name.startswith("merged"):
         return reference_merged(config_name)
+    if config_name.endswith("_addendum"):
+        return reference_addendum(config_name)
     modname = ns.REFERENCE_CONFIG_MODULE[config_name]
     module = importlib.import_module(modname)
     module = importlib.reload(module)
@@ -182,6 +223,11 @@ CASES = [
     ("merged_single", "merged_single", "wn", 4, 18, dict(coverage=25), True, False, ("one", "multi", "dummy")),
     ("merged_hybrid", "merged_hybrid", "wn", 3, 19, dict(coverage=20, hybrid_coverage=10), True, False,
      ("one", "multi")),
+    ("single_tech_addendum", "single_tech_addendum", "wn", 3, 21, dict(coverage=20), True, False, ("multi",)),
+    ("hybrid_no_ensemble_addendum", "hybrid_no_ensemble_addendum", "wn", 3, 22, dict(coverage=20, hybrid_coverage=10),
+     True, False, ("multi",)),
+    ("merged_hybrid_250", "merged_hybrid_250", "wn", 3, 20, dict(coverage=12, hybrid_coverage=6, window=250), True,
+     False, ("multi",)),
 ]
 
 
@@ -305,6 +351,50 @@ def make_merged_pickle_fixture():
           f"[{res['logits'].min():.3f},{res['logits'].max():.3f}] meta {res['meta'][0]}")
 
 
+def make_addendum_pickle_fixture():
+    """A real pickle of a transfer-learning model: the small single-tech architecture of mini_reference with
+    two more residual blocks on every sub-network, assembled by the reference's build_on_top."""
+    import MixtureOfExpertsAdvancedXferLearning as XF
+    wn = dict(use_weight_norm=True)
+    rb = dict(kernelSizes=[3, 3], paddings=[1, 1], dilations=[1, 1])
+    read_conv = NNTools.SingleConvLayer(6, 8, 3, 0, 1, 1, **wn)
+    read_conv.append({"type": "MaxPool1d", "kwargs": {"kernel_size": 3, "stride": 2, "padding": 0}})
+    read_conv += [NNTools.ResidualBlockConvShortcut(8, 16, strides=[2, 1, 2], **rb, **wn)]
+    comp = NNTools.SingleConvLayer(16, 16, 1, 0, 1, 1, **wn)
+    comp += [NNTools.ResidualBlockConvShortcut(16, 32, strides=[2, 1, 2], **rb, **wn)]
+    xattn = [{"type": "Fork", "kwargs": {"net_args": [[{"type": "Noop", "kwargs": {}}],
+                                                       [{"type": "SelectArgument", "kwargs": {"select": 1}}]]}},
+             {"type": "LinearCombination", "kwargs": {"coefficients": [2, -1]}}]
+    xattn += NNTools.SingleConvLayer(32, 32, 1, 0, 1, 1, **wn)
+    xattn += [NNTools.ResidualBlockConvShortcut(32, 64, strides=[2, 1, 2], **rb, **wn)]
+    xattn += NNTools.terminus(64, 1, use_weight_norm=True)
+    more = lambda c: [NNTools.ResidualBlockFTShortcut(c, c, strides=[1, 1], **rb, **wn) for _ in range(2)]   # noqa: E731
+    torch.manual_seed(2468)
+    moe = XF.create_moe_attention_model({"read_conv0": read_conv, "compressor0": comp, "xattn0": xattn})
+    wrapper = _build_on_top(moe, {
+        "read_convolver0_addendum": more(16), "compressor0_addendum": more(32),
+        "xattn0_addendum": more(64) + NNTools.terminus(64, 1, use_weight_norm=True)})
+    with torch.no_grad():
+        for name, p in wrapper.named_parameters():
+            if name.endswith("weight_g"):
+                p.mul_(1.0 + 0.25 * torch.rand_like(p))
+            if name == "moeMerged.read_convolver0.0.network.0.conv1d.weight_g":
+                p.div_(128.0)
+    path = os.path.join(HERE, "mini_addendum.wrapper.dnn")
+    torch.save(wrapper, path)
+    batch = synth.make_sites(4, seed=975, coverage=12)
+    res = run_batched(wrapper, batch)
+    res.pop("frames0")
+    res.update(run_wrapper(wrapper, batch, synth.allele_names(batch)))
+    wrapper.providePredictions = False
+    payload = dict(reads0=batch.reads0, reads_per_allele0=batch.reads_per_allele0,
+                   alleles_per_site=batch.alleles_per_site, ref_onehot=batch.ref_onehot)
+    payload.update({"exp_" + k: v for k, v in res.items()})
+    np.savez_compressed(os.path.join(HERE, "mini_addendum.npz"), **payload)
+    print(f"mini_addendum: pickle {os.path.getsize(path) / 1024:.0f} KB, logits "
+          f"[{res['logits'].min():.3f},{res['logits'].max():.3f}]")
+
+
 def main():
     only = set(sys.argv[1:])          # optional: regenerate just the named fixtures
     sanity_known_answer()
@@ -312,6 +402,8 @@ def main():
         make_pickle_fixture()
     if not only or "mini_merged" in only:
         make_merged_pickle_fixture()
+    if not only or "mini_addendum" in only:
+        make_addendum_pickle_fixture()
     for name, cfg, norm, n_sites, wseed, kw, with_wrapper, keep_frames, need in CASES:
         if only and name not in only:
             continue

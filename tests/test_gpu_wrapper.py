@@ -88,6 +88,18 @@ def test_loader_runs_a_real_reference_pickle():
     net.close()
 
 
+def test_loader_runs_a_transfer_learning_pickle():
+    net = loader.load(os.path.join(GOLDEN, "mini_addendum.wrapper.dnn"))
+    z = np.load(os.path.join(GOLDEN, "mini_addendum.npz"))
+    batch = synth.SiteBatch(z["reads0"], z["reads_per_allele0"], z["alleles_per_site"], z["ref_onehot"])
+    logits, _ = net.engine.forward_batch(batch)
+    np.testing.assert_allclose(logits, z["exp_logits"], rtol=2e-5, atol=2e-5)
+    for s, (fd, seg) in enumerate(site_dicts(batch)):
+        d = net(fd, seg)
+        np.testing.assert_allclose(np.array([float(v) for v in d.values()]), z[f"exp_site{s}_mix"], **PROB)
+    net.close()
+
+
 def test_loader_runs_a_merged_family_pickle():
     """MoEMergedAdvanced (hybrid, additive, combiners, BatchNorm meta) straight from a reference pickle."""
     net = loader.load(os.path.join(GOLDEN, "mini_merged.wrapper.dnn"))

@@ -58,6 +58,18 @@ def test_merged_family_pickle_loads_and_matches_reference():
     assert prog.n_experts == 3 and prog.has_meta and not prog.uses_ref
 
 
+def test_transfer_learning_pickle_loads_and_matches_reference():
+    """Sequential(original, addendum) sub-networks built by the reference's build_on_top."""
+    spec, state = loader.load_spec(os.path.join(GOLDEN, "mini_addendum.wrapper.dnn"))
+    assert set(spec.nets) == {"read_convolver0", "compressor0", "xattn0"}
+    assert sum(isinstance(n, ns.Head) for n in spec.nets["xattn0"]) == 1      # the original terminus is gone
+    z = np.load(os.path.join(GOLDEN, "mini_addendum.npz"))
+    batch = synth.SiteBatch(z["reads0"], z["reads_per_allele0"], z["alleles_per_site"], z["ref_onehot"])
+    logits, _ = mo.forward_batch(mo.Oracle(spec, state), batch)
+    np.testing.assert_allclose(logits, z["exp_logits"], rtol=2e-5, atol=2e-6)
+    assert compiler.compile_model(spec, state).n_experts == 1
+
+
 def test_native_file_round_trip(tmp_path):
     spec = ns.build("single_tech_hp")
     state = weights.synth_state(spec, seed=3)
