@@ -139,13 +139,13 @@ def pack_conv(w: np.ndarray, b: np.ndarray, groups: int = 1):
 
 
 # canonical read-convolver shape the fused kernel implements (architectures/read_convolver.py)
-def _is_canonical_read_convolver(nodes, cin) -> bool:
+def _canonical_read_convolver_extras(nodes, cin) -> int:
+    """-1 if ``nodes`` is not the canonical read convolver; otherwise the number of extra identity-shortcut
+    64-channel residual blocks appended to it (transfer-learning models add 2, read_convolver_addendum.py)."""
     try:
         ref = ns.read_convolver("x", in_channels=cin)
     except Exception:
-        return False
-    if len(nodes) != len(ref):
-        return False
+        return -1
 
     def sig(n):
         if isinstance(n, ns.Conv):
@@ -156,7 +156,18 @@ def _is_canonical_read_convolver(nodes, cin) -> bool:
             return ("r", tuple(sig(m) for m in n.body), tuple(sig(m) for m in n.shortcut))
         return ("?", type(n).__name__)
 
-    return all(sig(a) == sig(b) for a, b in zip(nodes, ref)) and cin in (6, 7)
+    if len(nodes) < len(ref) or cin not in (6, 7):
+        return -1
+    if not all(sig(a) == sig(b) for a, b in zip(nodes, ref)):
+        return -1
+    extras = nodes[len(ref):]
+    if not all(sig(x) == sig(ref[-1]) for x in extras):
+        return -1
+    return len(extras)
+
+
+def _is_canonical_read_convolver(nodes, cin) -> bool:
+    return _canonical_read_convolver_extras(nodes, cin) == 0
 
 
 class _Lowering:
@@ -283,8 +294,9 @@ class _Lowering:
         seg = SEG_R0A if tech == 0 else SEG_R1A
         x = self.input(buf, dom, spec.window, cin)
         from . import readconv_pack
+        extras = _canonical_read_convolver_extras(nodes, cin)
         if (self.fused and readconv_pack.AVAILABLE and spec.window == 150
-                and _is_canonical_read_convolver(nodes, cin)):
+                and extras in readconv_pack.EXTRA_BLOCKS):
             y = self.new(ROWS_ALLELES, 36, 64)
             w_off = self.blob.add(readconv_pack.pack(nodes, self.folded, cin))
             if self.fused == "trunk":
@@ -292,12 +304,12 @@ class _Lowering:
                 pooled = self.net(nodes[:readconv_pack.TRUNK_FIRST_NODE], x)
                 assert (pooled.length, pooled.channels) == (71, 32)
                 self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=pooled.vid, dst=y.vid, cin=32, cout=64,
-                                   lin=71, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name + ".trunk",
+                                   k=extras, lin=71, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name + ".trunk",
                                    macs_per_row=ns.macs(nodes[readconv_pack.TRUNK_FIRST_NODE:], 71)))
             else:
                 # the whole read convolver (stem included) + segment sum in one kernel, straight from the bytes
                 self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=buf, dst=y.vid, cin=cin, cout=64,
-                                   lin=150, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name,
+                                   k=extras, lin=150, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name,
                                    flags=FLAG_SRC_U8, macs_per_row=ns.macs(nodes, 150)))
             self.used_fused = True
             return y

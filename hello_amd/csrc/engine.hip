@@ -161,6 +161,8 @@ int validate_model(const hello_model_desc* d) {
         if ((o.kind == HELLO_OP_SEGSUM || o.kind == HELLO_OP_MIX || o.kind == HELLO_OP_READCONV_FUSED) &&
             (o.seg < 0 || o.seg > 2))
             return fail(HELLO_ERR_MODEL, "op %d: bad segment kind", i);
+        if (o.kind == HELLO_OP_READCONV_FUSED && !hello::readconv_supports_extra_blocks(o.k))
+            return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver takes 0 or 2 extra blocks (k), got %d", i, o.k);
     }
     return 0;
 }
@@ -598,7 +600,8 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.allele_of_read = t1 ? e->allele_of_read1 : e->allele_of_read0;
                 a.slot_of_group = t1 ? e->group_slot1 : e->group_slot0;
                 a.n_reads = t1 ? R1 : R0;
-                if ((size_t)o.w_off + hello::readconv_weight_floats() > e->n_weight_floats)
+                a.extra_blocks = o.k;
+                if ((size_t)o.w_off + hello::readconv_weight_floats(o.k) > e->n_weight_floats)
                     return fail(HELLO_ERR_MODEL, "op %d: fused read-convolver weight block truncated", op_index);
                 HIP_TRY(hello::launch_readconv_fused(a, stream));
                 HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,

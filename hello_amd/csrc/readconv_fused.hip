@@ -66,6 +66,9 @@ constexpr int OFF_S1 = W_TRUNK;                            // [6 steps][64 lanes
 constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps][64 lanes][4], bias[16]
 constexpr int OFF_S3 = OFF_S2 + 3 * 256 + 16;              // [2 blocks][3 taps][64 lanes][4], bias[32]
 constexpr int W_TOTAL = OFF_S3 + 2 * 3 * 256 + 32;
+// transfer-learning models append identity-shortcut 64-channel blocks (read_convolver_addendum.py); their
+// weights follow the canonical blob.  First conv of 64-channel block `blk`:
+constexpr int off_d(int blk) { return blk < 3 ? OFF_D + 2 * blk * (W6464 + 64) : W_TOTAL + 2 * (blk - 3) * (W6464 + 64); }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -94,7 +97,8 @@ struct Cfg {
 };
 }  // namespace rc
 
-int readconv_weight_floats() { return rc::W_TOTAL; }
+int readconv_weight_floats(int extra_blocks) { return rc::off_d(3 + extra_blocks); }
+bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0 || extra_blocks == 2; }
 
 using Geometry = rc::Cfg<4, 4>;    // 4 reads x 4 waves per workgroup, two workgroups per CU
 int readconv_reads_per_group() { return Geometry::G; }
@@ -383,7 +387,7 @@ __device__ __forceinline__ void stem_conv1(const unsigned char* __restrict__ s_u
     }
 }
 
-template <class CF, bool STEM>
+template <class CF, bool STEM, int NB64>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
     constexpr int G = CF::G, T1 = CF::T1, T2 = CF::T2, BUF_FLOATS = CF::BUF_FLOATS, THREADS = CF::THREADS;
@@ -514,16 +518,16 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         H, X, w12, slice(OFF_D, cb4, 12), W + OFF_C2 + W6464, sreg, pad2, dump, wave, lane);
     __syncthreads();
 
-    // ---- 3 x ResidualBlock(64) --------------------------------------------------------------------
+    // ---- NB64 x ResidualBlock(64) (3 in the canonical read convolver) ------------------------------
 #pragma unroll
-    for (int blk = 0; blk < 3; ++blk) {
-        const int off_a = OFF_D + (2 * blk) * (W6464 + 64), off_b = off_a + (W6464 + 64);
+    for (int blk = 0; blk < NB64; ++blk) {
+        const int off_a = off_d(blk), off_b = off_a + (W6464 + 64);
         conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
             X, H, w12, slice(off_b, cb4, 12), W + off_a + W6464, sreg, pad2, dump, wave, lane);
         __syncthreads();
-        if (blk < 2)
+        if (blk < NB64 - 1)
             conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
-                H, X, w12, slice(off_b + (W6464 + 64), cb4, 12), W + off_b + W6464, sreg, pad2, dump, wave, lane);
+                H, X, w12, slice(off_d(blk + 1), cb4, 12), W + off_b + W6464, sreg, pad2, dump, wave, lane);
         else
             conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, false, GEOM_TRUNK, 16, RS2 * CF::G, true>(
                 H, X, w12, nullptr, W + off_b + W6464, sreg, pad2, dump, wave, lane);
@@ -555,14 +559,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
 }
 
-template <class CF>
+template <class CF, int NB64>
 static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false>,
+        hipError_t e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false, NB64>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true>,
+            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e != hipSuccess) return e;
         configured = true;
@@ -570,16 +574,18 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     const unsigned groups = (unsigned)((a.n_reads + CF::G - 1) / CF::G);
     if (a.reads) {
         if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((readconv_kernel<CF, true>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, true, NB64>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     } else {
-        hipLaunchKernelGGL((readconv_kernel<CF, false>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, false, NB64>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
     if (a.n_reads <= 0) return hipSuccess;
-    return launch_cfg<Geometry>(a, stream);
+    if (a.extra_blocks == 0) return launch_cfg<Geometry, 3>(a, stream);
+    if (a.extra_blocks == 2) return launch_cfg<Geometry, 5>(a, stream);
+    return hipErrorInvalidValue;
 }
 
 // frames[a] = sum over the allele's partial slots, in slot (= read) order

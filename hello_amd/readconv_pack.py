@@ -15,6 +15,7 @@ from . import netspec as ns
 
 AVAILABLE = True
 TRUNK_FIRST_NODE = 4          # nodes[0:4] = the stem (3 valid convs + max pool), run layer by layer
+EXTRA_BLOCKS = (0, 2)         # identity 64-channel blocks the kernel accepts after the canonical three
 
 
 def _pack_conv(w: np.ndarray, b: np.ndarray) -> np.ndarray:
@@ -29,8 +30,8 @@ def _pack_conv(w: np.ndarray, b: np.ndarray) -> np.ndarray:
 
 
 def trunk_convs(nodes):
-    """The 15 convolutions in kernel order."""
-    blocks = nodes[TRUNK_FIRST_NODE:]
+    """The 15 convolutions of the canonical trunk in kernel order."""
+    blocks = nodes[TRUNK_FIRST_NODE:TRUNK_FIRST_NODE + 7]
     assert len(blocks) == 7 and all(isinstance(b, ns.Residual) for b in blocks)
     order = []
     for blk in blocks[:3]:
@@ -61,7 +62,11 @@ def pack(nodes, folded, cin=None) -> np.ndarray:
     parts.append(_pack_first_conv(*folded[stem[0].key]))
     parts.append(_pack_conv(*folded[stem[1].key]))
     parts.append(_pack_conv(*folded[stem[2].key]))
+    extras = nodes[TRUNK_FIRST_NODE + 7:]               # transfer-learning blocks follow the canonical blob
+    assert len(extras) in EXTRA_BLOCKS
+    for blk in extras:
+        parts += [_pack_conv(*folded[blk.body[0].key]), _pack_conv(*folded[blk.body[1].key])]
     blob = np.concatenate(parts)
     trunk = 6 * (3072 + 32) + (6144 + 64) + (2048 + 64) + (12288 + 64) + 6 * (12288 + 64)
-    assert blob.size == trunk + (384 + 16) + (768 + 16) + (1536 + 32), blob.size
+    assert blob.size == trunk + (384 + 16) + (768 + 16) + (1536 + 32) + 2 * len(extras) * (12288 + 64), blob.size
     return blob

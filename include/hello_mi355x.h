@@ -90,7 +90,7 @@ typedef struct hello_op {
     int32_t dst;         /* buffer id; HEAD: output slot */
     int32_t res;         /* residual buffer id or HELLO_BUF_NONE */
     int32_t cin, cout;   /* channels */
-    int32_t k, stride, pad;
+    int32_t k, stride, pad;     /* READCONV_FUSED: k = extra identity 64-channel blocks after the canonical 3 (0 | 2) */
     int32_t lin, lout;   /* positions per row before / after */
     int32_t flags;
     int32_t seg;         /* hello_segment (SEGSUM / MIX / READCONV_FUSED) */

@@ -70,6 +70,7 @@ def test_golden_posteriors(engines, name):
     ("single_tech_hp", dict(coverage=(20, 80), channels=7, tech="pacbio")),
     ("hybrid_no_ensemble", dict(coverage=30, hybrid_coverage=15)),
     ("merged_hybrid", dict(coverage=25, hybrid_coverage=10)),
+    ("single_tech_addendum", dict(coverage=30)),
 ])
 def test_fresh_batches_match_oracle(engines, cfg, kw):
     from oracle import moe_oracle as mo

@@ -83,11 +83,14 @@ def test_native_file_round_trip(tmp_path):
 
 
 def test_canonical_models_use_the_fused_trunk_and_small_scratch():
-    for cfg in ("single_tech", "single_tech_hp", "hybrid_no_ensemble", "hybrid_full", "hybrid_ensemble2"):
+    for cfg in ("single_tech", "single_tech_hp", "hybrid_no_ensemble", "hybrid_full", "hybrid_ensemble2",
+                "merged_single", "merged_hybrid", "single_tech_addendum", "hybrid_no_ensemble_addendum"):
         spec = ns.build(cfg)
         prog = compiler.compile_model(spec, weights.synth_state(spec, seed=1))
         assert prog.fused_read_convolver
         kinds = [o.kind for o in prog.ops]
+        extra = 2 if cfg.endswith("_addendum") else 0      # transfer-learning blocks run inside the fused kernel
+        assert all(o.k == extra for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED)
         assert kinds.count(compiler.OP_READCONV_FUSED) == (2 if spec.hybrid_inputs else 1)
         # no op may write the buffer it reads (conv taps / segment sums read neighbours)
         for o in prog.ops:
