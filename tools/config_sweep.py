@@ -1,0 +1,79 @@
+"""Throughput of every BASELINE.json configuration and model variant on one MI355X, device-resident inputs,
+logits + pair posteriors per step.  Prints one row per configuration (sites/s, ms/step, algorithmic TFLOP/s and
+its fraction of the 157.3 TFLOP/s FP32 MFMA peak; FLOPs = 2 x MAC of the ops the engine ran).
+
+    python tools/config_sweep.py [--sites 4096] [--steps 10]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+PEAK = 157.3e12
+CASES = [
+    # label, config, build kwargs, make_sites kwargs, site divisor
+    ("C2 Illumina 30x single-tech", "single_tech", {}, dict(coverage=30), 1),
+    ("C3 PacBio HiFi single-tech, cov U{8..52}, R<=128", "single_tech", {}, dict(coverage=(8, 52), tech="pacbio", max_reads=128), 1),
+    ("C4 hybrid no-ensemble, Illumina 30x + PacBio 15x", "hybrid_no_ensemble", {}, dict(coverage=30, hybrid_coverage=15), 1),
+    ("C5 haplotagged (7 ch), cov U{20..80}", "single_tech_hp", {}, dict(coverage=(20, 80), channels=7, tech="pacbio"), 1),
+    ("hybrid full (3 experts + meta)", "hybrid_full", {}, dict(coverage=30, hybrid_coverage=15), 1),
+    ("hybrid ensemble2 (meta on reference)", "hybrid_ensemble2", {}, dict(coverage=30, hybrid_coverage=15), 1),
+    ("hybrid no-ensemble wide (2x channels)", "hybrid_no_ensemble", dict(w=2), dict(coverage=30, hybrid_coverage=15), 4),
+    ("single-tech + transfer-learning addendum", "single_tech_addendum", {}, dict(coverage=30), 1),
+    ("MoEMergedAdvanced hybrid (older family)", "merged_hybrid", {}, dict(coverage=30, hybrid_coverage=15), 1),
+    ("MoEMergedAdvanced 250 bp feature map", "merged_hybrid_250", {}, dict(coverage=30, hybrid_coverage=15, window=250), 4),
+]
+
+
+def main():
+    import torch
+    from hello_amd import compiler, netspec as ns, synth, weights
+    from hello_amd.engine import Engine, n_pairs
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sites", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--only", type=str, default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    print(f"{'configuration':52s} {'sites':>6s} {'reads/site':>10s} {'ms/step':>8s} {'sites/s':>10s} {'TFLOP/s':>8s} {'of peak':>7s} fused")
+    for label, cfg, bkw, skw, div in CASES:
+        if args.only and args.only not in label and args.only != cfg:
+            continue
+        spec = ns.build(cfg, **bkw)
+        eng = Engine(spec, weights.synth_state(spec, seed=1), device=0)
+        n = max(args.sites // div, 64)
+        b = synth.make_sites(n, seed=7, **skw)
+        t = lambda x: None if x is None else torch.from_numpy(x).to(dev)      # noqa: E731
+        r0, r1 = t(b.reads0), t(b.reads1)
+        ref = t(b.ref_onehot) if eng.program.uses_ref else None
+        rows = {compiler.ROWS_READS0: b.reads0.shape[0], compiler.ROWS_READS1: 0 if b.reads1 is None else b.reads1.shape[0],
+                compiler.ROWS_ALLELES: b.n_alleles, compiler.ROWS_SITES: b.n_sites}
+        flops = 2.0 * sum(o.macs_per_row * rows[o.domain if o.kind != compiler.OP_READCONV_FUSED else
+                                                 (compiler.ROWS_READS0 if o.seg == compiler.SEG_R0A else compiler.ROWS_READS1)]
+                          for o in eng.program.ops)
+
+        def step():
+            eng.forward(r0, b.reads_per_allele0, b.alleles_per_site, r1, b.reads_per_allele1, ref, posteriors=True)
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        reads = (rows[compiler.ROWS_READS0] + rows[compiler.ROWS_READS1]) / n
+        print(f"{label:52s} {n:6d} {reads:10.1f} {dt * 1e3:8.2f} {n / dt:10.0f} {flops / dt / 1e12:8.1f} "
+              f"{flops / dt / PEAK:7.1%} {eng.program.fused_read_convolver}", flush=True)
+        eng.close()
+        del r0, r1
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
