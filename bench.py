@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0
+PARITY_SITES = 96
 
 
 def site_flops(spec, batch):
@@ -107,6 +108,15 @@ def cpu_baseline(seed, budget_s=12.0):
         mo.forward_batch(oracle, sample.site_slice(done, done + chunk), chunk_sites=chunk)
         done += chunk
     dt = time.perf_counter() - t0
+    # the other half of BASELINE.json's metric: what the CPU path answers on a fixed sample, kept aside for
+    # the comparison with the engine's answers on the same sites (``parity`` in the JSON line)
+    check = synth.make_sites(PARITY_SITES, seed=seed + 4242, coverage=30)
+    want_logits, _ = mo.forward_batch(mo.Oracle(spec, weights.synth_state(spec, seed=seed)), check, chunk_sites=1)
+    aoff = np.concatenate([[0], np.cumsum(check.alleles_per_site)])
+    probs = mo.sigmoid(want_logits[0])
+    want_post = np.concatenate([mo.posteriors([probs[aoff[s]:aoff[s + 1]]] + [np.zeros(aoff[s + 1] - aoff[s], np.float32)] * 2,
+                                              np.array([1, 0, 0], np.float32))[0] for s in range(check.n_sites)])
+    cpu_baseline.reference_answers = (check, probs, want_post)
     return {"value": round(rate, 2), "unit": "sites/s", "cores": int(cores), "kind": "port",
             "sample": f"{done_sites} synthetic sites (cov 30) in {budget_s:.0f} s: {cores} single-threaded worker "
                       f"processes, one site per call through oracle/moe_oracle.py's per-site wrapper (the "
@@ -263,6 +273,16 @@ def main():
         "hbm_algorithmic_gbs": round((900.0 * reads_step) / (dt / args.steps) / 1e9, 3),
     }
 
+    parity = None
+    if cpu is not None:
+        check, want_probs, want_post = cpu_baseline.reference_answers
+        got_logits, _, got_post = eng.forward_batch(check, posteriors=True)
+        got_probs = 1.0 / (1.0 + np.exp(-got_logits[0].astype(np.float64)))
+        parity = {"max_abs_delta_allele_probability": float(np.abs(got_probs - want_probs).max()),
+                  "max_abs_delta_pair_posterior": float(np.abs(got_post[0] - want_post).max()),
+                  "tolerance": 1e-4, "sites": int(check.n_sites), "alleles": int(check.n_alleles),
+                  "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
+
     if rank == 0:
         b0 = pool[0]["batch"]
         line = {
@@ -279,6 +299,7 @@ def main():
                        "fused_read_convolver": bool(fused), "outputs": "logits + genotype-pair posteriors"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "parity": parity,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

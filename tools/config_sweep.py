@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--sites", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--op-times", action="store_true", help="per-op device time and TFLOP/s of each configuration")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     print(f"{'configuration':52s} {'sites':>6s} {'reads/site':>10s} {'ms/step':>8s} {'sites/s':>10s} {'TFLOP/s':>8s} {'of peak':>7s} fused")
@@ -67,6 +68,19 @@ def main():
             step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
+        if args.op_times:
+            eng.set_profiling(args.steps)
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            op_rows, _ = eng.op_times_ms()
+            eng.set_profiling(0)
+            for o, (kind, name, ms) in zip(eng.program.ops, op_rows):
+                r = rows[o.domain if o.kind != compiler.OP_READCONV_FUSED else
+                         (compiler.ROWS_READS0 if o.seg == compiler.SEG_R0A else compiler.ROWS_READS1)]
+                tf = 2.0 * o.macs_per_row * r / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                print(f"    {kind:14s} {ms:8.4f} ms {tf:7.1f} TF/s  cin={o.cin:4d} cout={o.cout:4d} k={o.k} s={o.stride} "
+                      f"L {o.lin}->{o.lout} rows={r}  {name}")
         reads = (rows[compiler.ROWS_READS0] + rows[compiler.ROWS_READS1]) / n
         print(f"{label:52s} {n:6d} {reads:10.1f} {dt * 1e3:8.2f} {n / dt:10.0f} {flops / dt / 1e12:8.1f} "
               f"{flops / dt / PEAK:7.1%} {eng.program.fused_read_convolver}", flush=True)
