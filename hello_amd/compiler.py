@@ -31,7 +31,7 @@ ROWS_READS0, ROWS_READS1, ROWS_ALLELES, ROWS_SITES = 0, 1, 2, 3
 SEG_R0A, SEG_R1A, SEG_AS = 0, 1, 2
 BUF_NONE, BUF_READS0, BUF_READS1, BUF_REF, BUF_FIRST_SCRATCH = -1, 0, 1, 2, 3
 OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED = range(1, 9)
-FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST = 1, 2, 4, 8
+FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS = 1, 2, 4, 8, 16
 OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
             8: "readconv_fused"}
 
@@ -196,7 +196,7 @@ class _Lowering:
 
     # -- single nodes ------------------------------------------------------------------------
     def conv(self, node: ns.Conv, x: Value, res: Optional[Value] = None) -> Value:
-        if node.act not in ("relu", "none"):
+        if node.act not in ("relu", "none", "softplus"):
             raise NotImplementedError(f"activation {node.act!r} is not implemented by the HIP engine")
         if node.dilation != 1:
             raise NotImplementedError("dilated convs are not implemented by the HIP engine")
@@ -209,7 +209,7 @@ class _Lowering:
             OP_CONV1D, x.domain, src0=x.vid, dst=y.vid, res=res.vid if res is not None else BUF_NONE,
             cin=node.cin, cout=node.cout, k=node.k, stride=node.stride, pad=node.pad,
             lin=x.length, lout=lout,
-            flags=(FLAG_RELU if node.act == "relu" else 0) | (FLAG_SRC_U8 if x.u8 else 0),
+            flags={"relu": FLAG_RELU, "softplus": FLAG_SOFTPLUS, "none": 0}[node.act] | (FLAG_SRC_U8 if x.u8 else 0),
             w_off=self.blob.add(packed), b_off=self.blob.add(bias), name=node.key,
             macs_per_row=lout * node.cout * (node.cin // node.groups) * node.k))
         return y

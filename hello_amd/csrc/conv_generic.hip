@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = acc[cw][tp][4 * q + e] + b4[e];
-                    v[e] = a.relu ? fmaxf(x, 0.f) : x;
+                    // torch.nn.Softplus: x above the threshold 20 passes through, else log1p(exp(x))
+                    v[e] = a.relu == 1 ? fmaxf(x, 0.f) : (a.relu == 2 ? (x > 20.f ? x : log1pf(expf(x))) : x);
                 }
                 const long long o = mg * a.cout + ch;
                 if (a.res) {

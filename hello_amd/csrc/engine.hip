@@ -545,7 +545,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.k = o.k; a.stride = o.stride; a.pad = o.pad;
                 a.kpad = ((o.k * o.cin + 31) / 32) * 32;
                 a.cout_pad = ((o.cout + 31) / 32) * 32;
-                a.relu = (o.flags & HELLO_FLAG_RELU) ? 1 : 0;
+                a.relu = (o.flags & HELLO_FLAG_RELU) ? 1 : ((o.flags & HELLO_FLAG_SOFTPLUS) ? 2 : 0);
                 a.src_u8 = (o.flags & HELLO_FLAG_SRC_U8) ? 1 : 0;
                 if (!a.src) return fail(HELLO_ERR_ARG, "op %d reads an input the caller did not supply", op_index);
                 HIP_TRY(hello::launch_conv1d(a, stream));

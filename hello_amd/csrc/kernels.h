@@ -17,7 +17,7 @@ struct ConvArgs {
     int lin, lout, cin, cout, k, stride, pad;
     int kpad;             // multiple of 32
     int cout_pad;         // multiple of 32
-    int relu;
+    int relu;                  // activation: 0 none, 1 ReLU, 2 Softplus (beta 1, threshold 20)
     int src_u8;
 };
 hipError_t launch_conv1d(const ConvArgs& a, hipStream_t stream);

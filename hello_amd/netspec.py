@@ -158,8 +158,8 @@ class _Seq:
     # -- layers --------------------------------------------------------------------------------
     def conv(self, cin, cout, k, pad=0, stride=1, groups=1):
         node = self._conv_node(self.prefix, self.slot, cin, cout, k, stride, pad, groups, self.act)
-        # conv [+ BatchNorm] + activation
-        return self.add(node, 3 if self.norm == "bn" else 2)
+        # weight-normed conv + activation, or plain conv + (BatchNorm | Noop) + activation (NNTools.py:72-115)
+        return self.add(node, 2 if self.norm == "wn" else 3)
 
     def maxpool(self, k, stride, pad=0):
         return self.add(MaxPool(k, stride, pad))
@@ -182,13 +182,13 @@ class _Seq:
         return self.add(Residual(body, shortcut))
 
     def head(self, cin, cout):
+        """terminus (NNTools.py:517-566): weight-normed Linear, or BatchNorm1d + Linear -- the terminus keeps
+        its default BatchNorm1d even in a network whose conv layers were generated with norm_type "Noop"."""
         lin = self.slot + 3
         if self.norm == "wn":
             node = Head(f"{self.prefix}.{lin}.linear", cin, cout, "wn", None)
-        elif self.norm == "bn":
-            node = Head(f"{self.prefix}.{lin}", cin, cout, "bn", f"{self.prefix}.{self.slot + 2}")
         else:
-            node = Head(f"{self.prefix}.{lin}", cin, cout, "none", None)
+            node = Head(f"{self.prefix}.{lin}", cin, cout, "bn", f"{self.prefix}.{self.slot + 2}")
         return self.add(node, 4)
 
 
@@ -277,10 +277,12 @@ def _nets(prefix, table) -> Dict[str, List[Node]]:
 
 def single_tech(norm="wn", in_channels=6, prefix="moeMerged", act="relu") -> ModelSpec:
     """moe_attention_config_single_tech_old_equivalent_weight_norm.py:6-14 (and
-    ..._with_hp_channel.py for in_channels=7)."""
+    ..._with_hp_channel.py for in_channels=7).  ``act`` reaches the read convolver and the expert only:
+    architectures/compressor_conv_small.py has no activation switch, so the compressor keeps ReLU even in
+    the ..._layer_norm.py configuration that asks for Softplus."""
     nets = _nets(prefix, {
         "read_convolver0": (read_convolver, dict(norm=norm, in_channels=in_channels, act=act)),
-        "compressor0": (compressor, dict(norm=norm, act=act)),
+        "compressor0": (compressor, dict(norm=norm)),
         "xattn0": (xattn_subtract, dict(norm=norm, act=act)),
     })
     name = "single_tech" + ("_hp" if in_channels == 7 else "")
@@ -491,6 +493,8 @@ CONFIGS = {
     "hybrid_no_ensemble_wide": lambda **kw: hybrid_no_ensemble(w=2, **kw),
     "hybrid_full": lambda **kw: hybrid_full(**kw),
     "hybrid_ensemble2": lambda **kw: hybrid_ensemble2(**kw),
+    # moe_attention_config_single_tech_old_equivalent_layer_norm.py: plain convs, no normalisation, Softplus
+    "single_tech_softplus": lambda **kw: single_tech(norm="none", act="softplus", **kw),
     "single_tech_addendum": lambda **kw: single_tech_addendum(**kw),
     "hybrid_no_ensemble_addendum": lambda **kw: hybrid_no_ensemble_addendum(**kw),
     "merged_single": lambda **kw: merged_single(**kw),
@@ -507,6 +511,7 @@ REFERENCE_CONFIG_MODULE = {
     "hybrid_no_ensemble_wide": "moe_attention_config_full_hybrid_old_equivalent_weight_norm_no_ensemble_wide",
     "hybrid_full": "moe_attention_config_full_hybrid_old_equivalent_weight_norm",
     "hybrid_ensemble2": "moe_attention_config_full_hybrid_old_equivalent_weight_norm_ensemble2",
+    "single_tech_softplus": "moe_attention_config_single_tech_old_equivalent_layer_norm",
     "single_tech_addendum": "moe_attention_config_single_tech_old_equivalent_weight_norm_addendum",
     "hybrid_no_ensemble_addendum": "moe_attention_config_full_hybrid_old_equivalent_weight_norm_no_ensemble_addendum",
 }

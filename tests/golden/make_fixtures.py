@@ -113,6 +113,22 @@ def reference_model(config_name, norm):
         return reference_merged(config_name)
     if config_name.endswith("_addendum"):
         return reference_addendum(config_name)
+    if config_name == "single_tech_softplus":
+        # the config module rewrites globals of the shared architecture modules: restore them afterwards
+        import architectures.read_convolver as rc
+        import architectures.compressor_conv_small as cc
+        import architectures.xattn_subtract as xs
+        try:
+            for m in (rc, cc, xs):
+                m.weight_norm = False           # as in a fresh interpreter (other configs switch it on)
+            cfg = importlib.reload(importlib.import_module(ns.REFERENCE_CONFIG_MODULE[config_name])).configDict
+            wrapper = REF.createMoEFullMergedAdvancedModelWrapper(REF.create_moe_attention_model(cfg))
+        finally:
+            for m in (rc, cc, xs):
+                m.norm_type, m.activation = "BatchNorm1d", "ReLU"
+                m.gen_config()
+        wrapper.eval()
+        return wrapper
     modname = ns.REFERENCE_CONFIG_MODULE[config_name]
     module = importlib.import_module(modname)
     module = importlib.reload(module)
@@ -223,6 +239,7 @@ CASES = [
     ("merged_single", "merged_single", "wn", 4, 18, dict(coverage=25), True, False, ("one", "multi", "dummy")),
     ("merged_hybrid", "merged_hybrid", "wn", 3, 19, dict(coverage=20, hybrid_coverage=10), True, False,
      ("one", "multi")),
+    ("single_tech_softplus", "single_tech_softplus", "wn", 4, 23, dict(coverage=20), True, False, ("one", "multi")),
     ("single_tech_addendum", "single_tech_addendum", "wn", 3, 21, dict(coverage=20), True, False, ("multi",)),
     ("hybrid_no_ensemble_addendum", "hybrid_no_ensemble_addendum", "wn", 3, 22, dict(coverage=20, hybrid_coverage=10),
      True, False, ("multi",)),
