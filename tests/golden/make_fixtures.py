@@ -239,6 +239,8 @@ CASES = [
     ("merged_single", "merged_single", "wn", 4, 18, dict(coverage=25), True, False, ("one", "multi", "dummy")),
     ("merged_hybrid", "merged_hybrid", "wn", 3, 19, dict(coverage=20, hybrid_coverage=10), True, False,
      ("one", "multi")),
+    ("hybrid_no_ensemble_wide", "hybrid_no_ensemble_wide", "wn", 3, 24, dict(coverage=20, hybrid_coverage=10), True,
+     False, ("multi",)),
     ("single_tech_softplus", "single_tech_softplus", "wn", 4, 23, dict(coverage=20), True, False, ("one", "multi")),
     ("single_tech_addendum", "single_tech_addendum", "wn", 3, 21, dict(coverage=20), True, False, ("multi",)),
     ("hybrid_no_ensemble_addendum", "hybrid_no_ensemble_addendum", "wn", 3, 22, dict(coverage=20, hybrid_coverage=10),

@@ -50,7 +50,8 @@ def test_golden_logits(engines, name, fused):
 
 @pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_full", "hybrid_ensemble2", "hybrid_no_ensemble",
                                   "merged_single", "merged_hybrid", "merged_hybrid_250", "single_tech_addendum",
-                                  "hybrid_no_ensemble_addendum", "single_tech_softplus"])
+                                  "hybrid_no_ensemble_addendum", "single_tech_softplus",
+                                  "hybrid_no_ensemble_wide"])
 def test_golden_posteriors(engines, name):
     spec, state, batch, exp = load_fixture(name)
     eng = get_engine(engines, name, spec, state, True)
