@@ -31,7 +31,7 @@ ROWS_READS0, ROWS_READS1, ROWS_ALLELES, ROWS_SITES = 0, 1, 2, 3
 SEG_R0A, SEG_R1A, SEG_AS = 0, 1, 2
 BUF_NONE, BUF_READS0, BUF_READS1, BUF_REF, BUF_FIRST_SCRATCH = -1, 0, 1, 2, 3
 OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED = range(1, 9)
-FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS = 1, 2, 4, 8, 16
+FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS, FLAG_WINOGRAD = 1, 2, 4, 8, 16, 32
 OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
             8: "readconv_fused"}
 
@@ -171,10 +171,11 @@ def _is_canonical_read_convolver(nodes, cin) -> bool:
 
 
 class _Lowering:
-    def __init__(self, spec: ns.ModelSpec, state, fused: bool):
+    def __init__(self, spec: ns.ModelSpec, state, fused: bool, winograd: bool = True):
         self.spec = spec
         self.folded = wts.fold(spec, state)
         self.fused = fused
+        self.winograd = bool(winograd)
         self.ops: List[Op] = []
         self.values: Dict[int, Value] = {}
         self.blob = _WeightBlob()
@@ -298,19 +299,21 @@ class _Lowering:
         if (self.fused and readconv_pack.AVAILABLE and spec.window == 150
                 and extras in readconv_pack.EXTRA_BLOCKS):
             y = self.new(ROWS_ALLELES, 36, 64)
-            w_off = self.blob.add(readconv_pack.pack(nodes, self.folded, cin))
+            w_off = self.blob.add(readconv_pack.pack(nodes, self.folded, cin, winograd=self.winograd))
+            wflag = FLAG_WINOGRAD if self.winograd else 0
             if self.fused == "trunk":
                 # stem layer by layer (3 valid convs + max pool), fused residual trunk + segment sum
                 pooled = self.net(nodes[:readconv_pack.TRUNK_FIRST_NODE], x)
                 assert (pooled.length, pooled.channels) == (71, 32)
                 self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=pooled.vid, dst=y.vid, cin=32, cout=64,
                                    k=extras, lin=71, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name + ".trunk",
+                                   flags=wflag,
                                    macs_per_row=ns.macs(nodes[readconv_pack.TRUNK_FIRST_NODE:], 71)))
             else:
                 # the whole read convolver (stem included) + segment sum in one kernel, straight from the bytes
                 self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=buf, dst=y.vid, cin=cin, cout=64,
                                    k=extras, lin=150, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name,
-                                   flags=FLAG_SRC_U8, macs_per_row=ns.macs(nodes, 150)))
+                                   flags=FLAG_SRC_U8 | wflag, macs_per_row=ns.macs(nodes, 150)))
             self.used_fused = True
             return y
         return self.segsum(self.net(nodes, x), seg)
@@ -456,8 +459,11 @@ def _allocate(ops: List[Op], values: Dict[int, Value]):
     return phys
 
 
-def compile_model(spec: ns.ModelSpec, state, fused: bool = True) -> Program:
-    low = _Lowering(spec, state, fused)
+def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool = True) -> Program:
+    """``winograd``: the fused read convolver evaluates the k=3 convolutions of its identity-shortcut residual
+    blocks in Winograd F(2,3) form (4 instead of 6 contractions per pair of positions; same fp32 arithmetic,
+    results differ from the direct form by float re-association only)."""
+    low = _Lowering(spec, state, fused, winograd)
     n_experts, has_meta = low.lower()
     buffers = _allocate(low.ops, low.values)
     return Program(

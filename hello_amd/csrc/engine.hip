@@ -601,7 +601,8 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.slot_of_group = t1 ? e->group_slot1 : e->group_slot0;
                 a.n_reads = t1 ? R1 : R0;
                 a.extra_blocks = o.k;
-                if ((size_t)o.w_off + hello::readconv_weight_floats(o.k) > e->n_weight_floats)
+                a.winograd = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
+                if ((size_t)o.w_off + hello::readconv_weight_floats(o.k, a.winograd) > e->n_weight_floats)
                     return fail(HELLO_ERR_MODEL, "op %d: fused read-convolver weight block truncated", op_index);
                 HIP_TRY(hello::launch_readconv_fused(a, stream));
                 HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,

@@ -63,9 +63,10 @@ struct ReadConvArgs {
     const int32_t* slot_of_group;    // [n_groups + 1] first partial slot of each read group
     long long n_reads;
     int extra_blocks;          // identity-shortcut 64-channel blocks after the canonical three: 0 | 2
+    int winograd;              // residual-block convolutions in Winograd F(2,3) form (weights packed accordingly)
 };
 int readconv_reads_per_group();
-int readconv_weight_floats(int extra_blocks);
+int readconv_weight_floats(int extra_blocks, bool winograd);
 bool readconv_supports_extra_blocks(int extra_blocks);
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
 // frames[a] = sum of the partial slots of allele a, in slot order

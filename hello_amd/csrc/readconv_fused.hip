@@ -53,22 +53,31 @@ constexpr int L2 = 36, RS2 = 36;     // ... at 64 channels: reads stacked WITHOU
                                      // 36*G rows tile exactly; the taps that would cross a read boundary are
                                      // zeroed in registers instead (BMASK)
 
-// packed weight block (floats): per conv [COUT/16][KT][CIN/16][64 lanes][4], then bias [COUT]
-constexpr int W3232 = 2 * 3 * 2 * 256, W3264 = 4 * 3 * 2 * 256, W3264S = 4 * 1 * 2 * 256, W6464 = 4 * 3 * 4 * 256;
-constexpr int OFF_B = 0;                                   // 6 convs 32->32
-constexpr int OFF_C1 = OFF_B + 6 * (W3232 + 32);           // 32->64 k3 s2
-constexpr int OFF_SC = OFF_C1 + W3264 + 64;                // 32->64 k1 s2
-constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3
-constexpr int OFF_D = OFF_C2 + W6464 + 64;                 // 6 convs 64->64
-constexpr int W_TRUNK = OFF_D + 6 * (W6464 + 64);
+// packed weight block (floats): per conv [COUT/16][KT][CIN/16][64 lanes][4], then bias [COUT].  With WINO the
+// convolutions of the identity-shortcut residual blocks are stored in their Winograd F(2,3) form: KT = 4
+// transformed taps U = G g (computed on the host in float64) instead of 3.
 constexpr int S1_STEPS = 6;                                // stem conv1: K = 3*C <= 21 -> 6 MFMA steps of 4
-constexpr int OFF_S1 = W_TRUNK;                            // [6 steps][64 lanes], bias[16]
-constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps][64 lanes][4], bias[16]
-constexpr int OFF_S3 = OFF_S2 + 3 * 256 + 16;              // [2 blocks][3 taps][64 lanes][4], bias[32]
-constexpr int W_TOTAL = OFF_S3 + 2 * 3 * 256 + 32;
-// transfer-learning models append identity-shortcut 64-channel blocks (read_convolver_addendum.py); their
-// weights follow the canonical blob.  First conv of 64-channel block `blk`:
-constexpr int off_d(int blk) { return blk < 3 ? OFF_D + 2 * blk * (W6464 + 64) : W_TOTAL + 2 * (blk - 3) * (W6464 + 64); }
+template <bool WINO>
+struct Offs {
+    static constexpr int KT = WINO ? 4 : 3;
+    static constexpr int W3232 = 2 * KT * 2 * 256, W3264 = 4 * 3 * 2 * 256, W3264S = 4 * 1 * 2 * 256;
+    static constexpr int W6464 = 4 * KT * 4 * 256, W6464D = 4 * 3 * 4 * 256;
+    static constexpr int OFF_B = 0;                                   // 6 convs 32->32 (residual blocks)
+    static constexpr int OFF_C1 = OFF_B + 6 * (W3232 + 32);           // 32->64 k3 s2
+    static constexpr int OFF_SC = OFF_C1 + W3264 + 64;                // 32->64 k1 s2
+    static constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3 of the strided block (always direct)
+    static constexpr int OFF_D = OFF_C2 + W6464D + 64;                // 6 convs 64->64 (residual blocks)
+    static constexpr int W_TRUNK = OFF_D + 6 * (W6464 + 64);
+    static constexpr int OFF_S1 = W_TRUNK;                            // [6 steps][64 lanes], bias[16]
+    static constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps][64 lanes][4], bias[16]
+    static constexpr int OFF_S3 = OFF_S2 + 3 * 256 + 16;              // [2 blocks][3 taps][64 lanes][4], bias[32]
+    static constexpr int W_TOTAL = OFF_S3 + 2 * 3 * 256 + 32;
+    // transfer-learning models append identity-shortcut 64-channel blocks (read_convolver_addendum.py); their
+    // weights follow the canonical blob.  First conv of 64-channel block `blk`:
+    static constexpr int off_d(int blk) {
+        return blk < 3 ? OFF_D + 2 * blk * (W6464 + 64) : W_TOTAL + 2 * (blk - 3) * (W6464 + 64);
+    }
+};
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -97,7 +106,9 @@ struct Cfg {
 };
 }  // namespace rc
 
-int readconv_weight_floats(int extra_blocks) { return rc::off_d(3 + extra_blocks); }
+int readconv_weight_floats(int extra_blocks, bool winograd) {
+    return winograd ? rc::Offs<true>::off_d(3 + extra_blocks) : rc::Offs<false>::off_d(3 + extra_blocks);
+}
 bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0 || extra_blocks == 2; }
 
 using Geometry = rc::Cfg<4, 4>;    // 4 reads x 4 waves per workgroup, two workgroups per CU
@@ -107,6 +118,24 @@ int readconv_reads_per_group() { return Geometry::G; }
 template <int C>
 __device__ __forceinline__ int swz(int row) {
     return C == 64 ? 2 * (row & 7) : (C == 32 ? 2 * ((row >> 1) & 3) : 2 * ((row >> 2) & 1));
+}
+
+// Images read by the Winograd layers (and by the stride-2 convolutions) are walked two rows per lane, so
+// they carry a swizzle (SW_W) that makes rows r, r+2, ..., r+30 conflict-free instead of r, r+1, ..., r+15:
+// at 64 channels chunk ^ 2*((row>>1)&7); at 32 channels (a row is half the banks) rows 4a+1 and 4a+2 also
+// trade places and the chunk is XORed with 2*((row>>2)&3).
+enum { SW_OLD = 0, SW_W = 1 };
+template <int C, int SW>
+__device__ __forceinline__ int img_off(int row, int chunk) {     // float offset of 16-byte chunk `chunk` of `row`
+    if constexpr (SW == SW_OLD) {
+        return row * C + 4 * (chunk ^ swz<C>(row));
+    } else if constexpr (C == 64) {
+        return row * 64 + 4 * (chunk ^ (2 * ((row >> 1) & 7)));
+    } else {
+        static_assert(C == 32, "SW_W images have 32 or 64 channels");
+        const int prow = (row & ~3) | ((row & 1) << 1) | ((row >> 1) & 1);
+        return prow * 32 + 4 * (chunk ^ (2 * ((row >> 2) & 3)));
+    }
 }
 
 template <int NV>
@@ -144,7 +173,8 @@ __device__ __forceinline__ float row_shl(float v, int n) {
 //            flat stacks (150 rows per read, no leading row): tile t starts at row TS*t, valid convolution
 //   VROWS    output rows >= VROWS are discarded;  `aux` = reads present in the group (MODE_POOL only)
 template <class CF, int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE,
-          bool ROLL, int GEOM = GEOM_TRUNK, int TS = 16, int VROWS = RS_OUT * CF::G, bool BMASK = false>
+          bool ROLL, int GEOM = GEOM_TRUNK, int TS = 16, int VROWS = RS_OUT * CF::G, bool BMASK = false,
+          int SIN = SW_OLD, int SOUT = SW_OLD>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* __restrict__ out,
                                            f32x4 (&w)[KT * CIN / 16], const float* __restrict__ next_w,
                                            const float* __restrict__ bias, f32x4 (&sreg)[CF::NSREG],
@@ -166,7 +196,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
 #pragma unroll
     for (int s = 0; s < KT * M; ++s) {
         const int x = j + LEAD - PAD + s / M;
-        opbase[s] = in + (16 * pg + x) * CIN + 4 * ((4 * (s % M) + q) ^ swz<CIN>(x));
+        opbase[s] = in + 16 * pg * CIN + img_off<CIN, SIN>(x, 4 * (s % M) + q);
     }
     auto tile_operand = [&](int k, int s) -> f32x4 {     // k-th tile of this wave, step s = tap*M + m
         if (IDENT) return *(const f32x4*)(opbase[s] + k * NPG * 16 * CIN);
@@ -178,10 +208,10 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
             const int rd = r / RS_OUT;
             row = 1 + rd * RS_IN + (r - rd * RS_OUT) * STRIDE - PAD + s / M;
         }
-        return *(const f32x4*)(in + row * CIN + 4 * ((4 * (s % M) + q) ^ swz<CIN>(row)));
+        return *(const f32x4*)(in + img_off<CIN, SIN>(row, 4 * (s % M) + q));
     };
     // output pointer of the k-th tile: base + constant; rows past the group go to the dump slot
-    float* const outbase = out + (16 * pg + j + LEAD) * COUT + 4 * ((4 * cb + q) ^ swz<COUT>(j + LEAD));
+    float* const outbase = out + 16 * pg * COUT + img_off<COUT, SOUT>(j + LEAD, 4 * cb + q);
     auto out_ptr = [&](int k) -> float* {
         float* ptr = outbase + k * NPG * 16 * COUT;
         if ((NPG - 1 + NPG * k) * 16 + 15 >= VROWS)                   // only the last tile(s) can overrun
@@ -203,7 +233,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
             const int rd = r / 150;
             const int p = (r - rd * 150) >> 1;
             const int row = 1 + rd * rc::RS1 + p;
-            float* ptr = out + row * 32 + 4 * ((4 * cb + q) ^ swz<32>(row));
+            float* ptr = out + img_off<32, SOUT>(row, 4 * cb + q);
             const bool ok = ((j & 1) == 0) && (j <= 12) && (p < rc::L1) && (rd < aux);
             *(f32x4*)(ok ? ptr : dump) = m;
             return;
@@ -330,6 +360,121 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     });
 }
 
+// ---- Winograd F(2,3) form of a k = 3, stride 1, pad 1 convolution C -> C over a trunk image ------------
+// Two neighbouring outputs share four inputs d0..d3 (image rows 2P .. 2P+3 for the pair P of flat rows 2P, 2P+1):
+//     V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3        (per channel, in the lane that read them)
+//     Mc = Uc * Vc  over the input channels, c = 0..3                (4 MFMA accumulators = 4 independent chains)
+//     y(2P) = M0 + M1 + M2,   y(2P+1) = M1 - M2 - M3
+// i.e. 4 contractions per pair of positions instead of 6.  A tile is 16 PAIRS (32 rows): lane (j, q) reads rows
+// 32 t + 2 j + i, so the images use the SW_W swizzle.  A step = one 16-channel input group: 4 ds_read_b128
+// (requested one step ahead), 16 VALU, 16 MFMAs.  `w` holds U for this wave's 16 output channels:
+// w[c * C/16 + m]; with ROLL it is refilled in place with the next layer's registers after their last use.
+//   zmask   (32 channels) bit k: this lane's odd row of the wave's k-th tile is a shared zero row
+template <class CF, int C, int MODE, bool ROLL>
+__device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* __restrict__ out,
+                                           f32x4 (&w)[4 * C / 16], const float* __restrict__ next_w,
+                                           const float* __restrict__ bias, unsigned zmask, float* __restrict__ dump,
+                                           int wave, int lane) {
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE, "residual-block convolutions only");
+    constexpr int M = C / 16, NCB = C / 16, NPG = CF::NW / NCB;
+    constexpr int PAIRS = (C == 64 ? rc::RS2 : rc::RS1) * CF::G / 2;       // 72 | 144 pairs of rows in the group
+    constexpr int NT = (PAIRS + 15) / 16;                                    // 5 | 9 tiles
+    constexpr int ITER = (NT + NPG - 1) / NPG;                               // tiles of position group 0
+    constexpr int TOFF = NPG * 32 * C;                                       // floats between a wave's tiles
+    static_assert(NCB * NPG == CF::NW, "waves must tile channel blocks x position groups");
+    const int cb = wave % NCB, pg = wave / NCB;
+    const int j = lane & 15, q = lane >> 4;
+    const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    const float* opb[4 * M];                                                 // row 32 pg + 2 j + i, input group m
+#pragma unroll
+    for (int s = 0; s < 4 * M; ++s) opb[s] = in + 32 * pg * C + img_off<C, SW_W>(2 * j + s / M, 4 * (s % M) + q);
+    float* const o0 = out + 32 * pg * C + img_off<C, SW_W>(2 * j + 1, 4 * cb + q);   // flat row 2P   = image row 2P + 1
+    float* const o1 = out + 32 * pg * C + img_off<C, SW_W>(2 * j + 2, 4 * cb + q);   // flat row 2P+1 = image row 2P + 2
+    const bool last_tile_here = (pg + NPG * (ITER - 1)) < NT;                // wave-uniform
+
+    f32x4 ring[2][4];
+    f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+    f32x4 res0 = zero4, res1 = zero4;
+    constexpr int NU = ITER * M;
+    auto issue = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int k = u / M, m = u % M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[u & 1][i] = *(const f32x4*)(opb[i * M + m] + k * TOFF);
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int k = u / M, m = u % M;
+        constexpr bool tail = (k == ITER - 1) && (NT % NPG != 0);            // a tile only position group 0 owns
+        if constexpr (u + 1 < NU) issue(std::integral_constant<int, u + 1>{});
+        if constexpr (MODE == MODE_RESID_INPLACE && m == 0) {
+            res0 = *(const f32x4*)(o0 + k * TOFF);
+            res1 = *(const f32x4*)(o1 + k * TOFF);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!tail || last_tile_here) {
+            f32x4 d0 = ring[u & 1][0], d1 = ring[u & 1][1], d2 = ring[u & 1][2], d3 = ring[u & 1][3];
+            if constexpr (C == 64) {
+                // reads are stacked without zero rows: the row before a read's first and after its last is zero
+                constexpr int lo = ((16 * k + 17) / 18) * 18;                // first pair >= 16 k that starts a read
+                constexpr int hi = ((16 * k + 18) / 18) * 18 - 1;            // first pair >= 16 k that ends a read
+                if constexpr (lo > 0 && lo <= 16 * k + 15) d0 = (j == lo - 16 * k) ? zero4 : d0;
+                if constexpr (hi <= 16 * k + 15 && hi < PAIRS - 1) d3 = (j == hi - 16 * k) ? zero4 : d3;
+            }
+            f32x4 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[0][e] = d0[e] - d2[e];
+                v[1][e] = d1[e] + d2[e];
+                v[2][e] = d2[e] - d1[e];
+                v[3][e] = d1[e] - d3[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c * M + m][e], v[c][e], acc[c], 0, 0, 0);
+        }
+        if constexpr (ROLL && k == ITER - 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[c * M + m] = *(const f32x4*)(next_w + (c * M + m) * 256);
+        }
+        if constexpr (m == M - 1) {
+            if (!tail || last_tile_here) {
+                f32x4 y0, y1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y0[e] = fmaxf(((acc[0][e] + acc[1][e]) + acc[2][e]) + b4[e], 0.f);
+                    y1[e] = fmaxf(((acc[1][e] - acc[2][e]) - acc[3][e]) + b4[e], 0.f);
+                }
+                if constexpr (MODE == MODE_RESID_INPLACE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y0[e] += res0[e];
+                        y1[e] += res1[e];
+                    }
+                }
+                if constexpr (C == 32) {
+                    if ((zmask >> k) & 1u) y1 = zero4;                        // the shared zero row between reads
+                }
+                float* p0 = o0 + k * TOFF;
+                float* p1 = o1 + k * TOFF;
+                if constexpr (16 * (NT - 1) + 15 >= PAIRS && k == ITER - 1) {  // only the last tile can overrun
+                    const bool ok = 16 * (pg + NPG * k) + j < PAIRS;
+                    p0 = ok ? p0 : dump;
+                    p1 = ok ? p1 : dump;
+                }
+                *(f32x4*)p0 = y0;
+                *(f32x4*)p1 = y1;
+            }
+            acc[0] = acc[1] = acc[2] = acc[3] = zero4;
+        }
+    });
+}
+
 // ---- stem conv1: pileup bytes -> 16 channels (valid convolution over the stacked reads) ---------------
 // The bytes are read as they are (no float copy): lane (j, q) of a tile needs k = 4*step + q of row j, and
 // k = tap*C + c is the byte offset from the row start.  Tiles of a wave: t = wave + 4*i; pairs of tiles in
@@ -344,8 +489,8 @@ __device__ __forceinline__ void stem_conv1(const unsigned char* __restrict__ s_u
     const int j = lane & 15, q = lane >> 4;
     float w1[S1_STEPS];
 #pragma unroll
-    for (int s = 0; s < S1_STEPS; ++s) w1[s] = W[OFF_S1 + s * 64 + lane];
-    const f32x4 b4 = *(const f32x4*)(W + OFF_S1 + S1_STEPS * 64 + 4 * q);
+    for (int s = 0; s < S1_STEPS; ++s) w1[s] = W[s * 64 + lane];              // W = the conv1 block of the blob
+    const f32x4 b4 = *(const f32x4*)(W + S1_STEPS * 64 + 4 * q);
     const unsigned char* base = s_u8 + (16 * wave + j) * ch + q;       // tile `wave`, row j, byte q
     const int tile_bytes = 16 * ch;
     unsigned char cur0[S1_STEPS], cur1[S1_STEPS], nxt0[S1_STEPS], nxt1[S1_STEPS];
@@ -387,9 +532,15 @@ __device__ __forceinline__ void stem_conv1(const unsigned char* __restrict__ s_u
     }
 }
 
-template <class CF, bool STEM, int NB64>
+template <class CF, bool STEM, int NB64, bool WINO>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
+    using O = Offs<WINO>;
+    constexpr int W3232 = O::W3232, W3264 = O::W3264, W3264S = O::W3264S, W6464 = O::W6464, W6464D = O::W6464D;
+    constexpr int OFF_B = O::OFF_B, OFF_C1 = O::OFF_C1, OFF_SC = O::OFF_SC, OFF_C2 = O::OFF_C2;
+    constexpr int OFF_S1 = O::OFF_S1, OFF_S2 = O::OFF_S2, OFF_S3 = O::OFF_S3;
+    constexpr int SWX = WINO ? SW_W : SW_OLD;                 // swizzle of the images the residual blocks walk
+    constexpr int NVA = WINO ? 8 : 6, NVB = WINO ? 16 : 12;   // weight registers of a 32- / 64-channel block conv
     constexpr int G = CF::G, T1 = CF::T1, T2 = CF::T2, BUF_FLOATS = CF::BUF_FLOATS, THREADS = CF::THREADS;
     static_assert(CF::NW == 4, "the layer schedule below maps 4 waves to (2 blocks x 2 groups) / (4 blocks)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -412,17 +563,24 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     const unsigned pad2 = 0;                                  // the 64-channel images hold no zero rows between reads
     {
         const int pg1 = wave / 2;                              // 32-channel layers: 2 blocks x 2 position groups
+        if (WINO) {                                            // tile = 16 pairs of rows; the odd row of pair P = 35 mod 36
 #pragma unroll
-        for (int k = 0; k < T1 / 2; ++k) pad1 |= ((((pg1 + 2 * k) * 16 + j) % RS1) >= L1 ? 1u : 0u) << k;
+            for (int k = 0; k < (T1 / 2 + 1) / 2; ++k) pad1 |= ((((pg1 + 2 * k) * 16 + j) % (RS1 / 2)) == RS1 / 2 - 1 ? 1u : 0u) << k;
+        } else {
+#pragma unroll
+            for (int k = 0; k < T1 / 2; ++k) pad1 |= ((((pg1 + 2 * k) * 16 + j) % RS1) >= L1 ? 1u : 0u) << k;
+        }
     }
 
     // X = the trunk's input image [71][32] per read (shared zero rows and row 0 zero), H = the other image
     float* const X = STEM ? bufB : bufA;
     float* const H = STEM ? bufA : bufB;
     f32x4 sreg[CF::NSREG];
-    f32x4 w6[6], w12[12], w2[2];
+    f32x4 wA[NVA], wB[NVB], w2[2];
+    f32x4 (&w6)[6] = reinterpret_cast<f32x4 (&)[6]>(wA);       // the direct-form views of the same registers
+    f32x4 (&w12)[12] = reinterpret_cast<f32x4 (&)[12]>(wB);
     const int cb2 = wave % 2, cb4 = wave;
-    load_weights<6>(w6, W + OFF_B, cb2, lane);      // first trunk layer: requested before anything else waits
+    load_weights<NVA>(wA, W + OFF_B, cb2, lane);    // first trunk layer: requested before anything else waits
     if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
     if (STEM) {
         // the stem, from the uint8 pileups: conv1 bytes -> bufB, conv2 bufB -> bufA, conv3 + max pool
@@ -459,7 +617,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         load_weights<3>(ws2, W + OFF_S2, 0, lane);
         load_weights<3>(ws3, W + OFF_S3, wave % 2, lane);
         __syncthreads();
-        stem_conv1<CF>(s_u8, bufB, W, ch, dump, wave, lane);
+        stem_conv1<CF>(s_u8, bufB, W + OFF_S1, ch, dump, wave, lane);
         __syncthreads();
         conv_layer<CF, 16, 16, 3, 1, 0, 1, 1, 0, CF::ST12, MODE_PLAIN, false, GEOM_STEM, 16, CF::SROWS>(
             bufB, bufA, ws2, nullptr, W + OFF_S2 + 3 * 256, sreg, 0u, dump, wave, lane);
@@ -468,7 +626,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             const int row = (tid >> 3) * RS1;
             *(f32x4*)(X + row * 32 + 4 * (tid & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        conv_layer<CF, 16, 32, 3, 1, 0, 1, 1, 0, CF::ST3, MODE_POOL, false, GEOM_STEM, 14>(
+        conv_layer<CF, 16, 32, 3, 1, 0, 1, 1, 0, CF::ST3, MODE_POOL, false, GEOM_STEM, 14, RS1 * CF::G, false, SW_OLD, SWX>(
             bufA, X, ws3, nullptr, W + OFF_S3 + 2 * 3 * 256, sreg, 0u, dump, wave, lane, n_here);
         __syncthreads();
         if (tid < 8) ((f32x4*)H)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};        // row 0 of the 32-channel image
@@ -483,7 +641,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             const int rem = f - rd * (L1 * 8);
             const int p = rem >> 3, c = rem & 7;
             const int row = 1 + rd * RS1 + p;
-            *(f32x4*)(bufA + row * 32 + 4 * (c ^ swz<32>(row))) = src[f];
+            *(f32x4*)(bufA + img_off<32, SWX>(row, c)) = src[f];
         }
     }
 
@@ -494,13 +652,20 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
         const int off_a = OFF_B + (2 * blk) * (W3232 + 32), off_b = off_a + (W3232 + 32);
-        conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN, true>(
-            X, H, w6, slice(off_b, cb2, 6), W + off_a + W3232, sreg, pad1, dump, wave, lane);
-        __syncthreads();
-        // the block's second conv rolls in the next block's first conv, or the strided conv (4 channel blocks)
-        const float* nxt = (blk < 2) ? slice(off_b + (W3232 + 32), cb2, 6) : slice(OFF_C1, cb4, 6);
-        conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_RESID_INPLACE, true>(
-            H, X, w6, nxt, W + off_b + W3232, sreg, pad1, dump, wave, lane);
+        // the block's second conv rolls in the next block's first conv, or the strided conv (4 channel blocks;
+        // its 6 registers are the first 6 of the 8 a Winograd layer refills)
+        const float* nxt = (blk < 2) ? slice(off_b + (W3232 + 32), cb2, NVA) : slice(OFF_C1, cb4, 6);
+        if constexpr (WINO) {
+            wino_layer<CF, 32, MODE_PLAIN, true>(X, H, wA, slice(off_b, cb2, NVA), W + off_a + W3232, pad1, dump, wave, lane);
+            __syncthreads();
+            wino_layer<CF, 32, MODE_RESID_INPLACE, true>(H, X, wA, nxt, W + off_b + W3232, pad1, dump, wave, lane);
+        } else {
+            conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN, true>(
+                X, H, w6, slice(off_b, cb2, 6), W + off_a + W3232, sreg, pad1, dump, wave, lane);
+            __syncthreads();
+            conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_RESID_INPLACE, true>(
+                H, X, w6, nxt, W + off_b + W3232, sreg, pad1, dump, wave, lane);
+        }
         __syncthreads();
     }
 
@@ -508,29 +673,43 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     load_weights<2>(w2, W + OFF_SC, cb4, lane);
     load_weights<12>(w12, W + OFF_C2, cb4, lane);
     if (tid < 32) ((f32x4*)H)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};   // rows 0 and 36G+1
-    conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false>(
+    conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX, SW_OLD>(
         X, H, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
-    conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS, false>(
+    conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX, SW_OLD>(
         X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
     __syncthreads();
     if (tid < 32) ((f32x4*)X)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
-    conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
-        H, X, w12, slice(OFF_D, cb4, 12), W + OFF_C2 + W6464, sreg, pad2, dump, wave, lane);
+    conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true, GEOM_TRUNK, 16, RS2 * CF::G, true, SW_OLD, SWX>(
+        H, X, w12, slice(O::off_d(0), cb4, NVB), W + OFF_C2 + W6464D, sreg, pad2, dump, wave, lane);
+    if constexpr (WINO) {                            // the direct layer rolled in 12 of the 16 registers
+#pragma unroll
+        for (int i = 12; i < 16; ++i) wB[i] = *(const f32x4*)(slice(O::off_d(0), cb4, NVB) + i * 256);
+    }
     __syncthreads();
 
     // ---- NB64 x ResidualBlock(64) (3 in the canonical read convolver) ------------------------------
 #pragma unroll
     for (int blk = 0; blk < NB64; ++blk) {
-        const int off_a = off_d(blk), off_b = off_a + (W6464 + 64);
-        conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
-            X, H, w12, slice(off_b, cb4, 12), W + off_a + W6464, sreg, pad2, dump, wave, lane);
-        __syncthreads();
-        if (blk < NB64 - 1)
-            conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
-                H, X, w12, slice(off_d(blk + 1), cb4, 12), W + off_b + W6464, sreg, pad2, dump, wave, lane);
-        else
-            conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, false, GEOM_TRUNK, 16, RS2 * CF::G, true>(
-                H, X, w12, nullptr, W + off_b + W6464, sreg, pad2, dump, wave, lane);
+        const int off_a = O::off_d(blk), off_b = off_a + (W6464 + 64);
+        if constexpr (WINO) {
+            wino_layer<CF, 64, MODE_PLAIN, true>(X, H, wB, slice(off_b, cb4, NVB), W + off_a + W6464, 0u, dump, wave, lane);
+            __syncthreads();
+            if (blk < NB64 - 1)
+                wino_layer<CF, 64, MODE_RESID_INPLACE, true>(H, X, wB, slice(O::off_d(blk + 1), cb4, NVB), W + off_b + W6464,
+                                                             0u, dump, wave, lane);
+            else
+                wino_layer<CF, 64, MODE_RESID_INPLACE, false>(H, X, wB, nullptr, W + off_b + W6464, 0u, dump, wave, lane);
+        } else {
+            conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
+                X, H, w12, slice(off_b, cb4, 12), W + off_a + W6464, sreg, pad2, dump, wave, lane);
+            __syncthreads();
+            if (blk < NB64 - 1)
+                conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
+                    H, X, w12, slice(O::off_d(blk + 1), cb4, 12), W + off_b + W6464, sreg, pad2, dump, wave, lane);
+            else
+                conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, false, GEOM_TRUNK, 16, RS2 * CF::G, true>(
+                    H, X, w12, nullptr, W + off_b + W6464, sreg, pad2, dump, wave, lane);
+        }
         __syncthreads();
     }
 
@@ -550,7 +729,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
                     cur = al;
                 }
                 const int row = 1 + rd * RS2 + p;
-                const f32x4 v = *(const f32x4*)(X + row * 64 + 4 * (c ^ swz<64>(row)));
+                const f32x4 v = *(const f32x4*)(X + img_off<64, SWX>(row, c));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += v[e];
             }
@@ -559,14 +738,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
 }
 
-template <class CF, int NB64>
+template <class CF, int NB64, bool WINO>
 static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false, NB64>,
+        hipError_t e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false, NB64, WINO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64>,
+            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64, WINO>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e != hipSuccess) return e;
         configured = true;
@@ -574,17 +753,17 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     const unsigned groups = (unsigned)((a.n_reads + CF::G - 1) / CF::G);
     if (a.reads) {
         if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((readconv_kernel<CF, true, NB64>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     } else {
-        hipLaunchKernelGGL((readconv_kernel<CF, false, NB64>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, false, NB64, WINO>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
     if (a.n_reads <= 0) return hipSuccess;
-    if (a.extra_blocks == 0) return launch_cfg<Geometry, 3>(a, stream);
-    if (a.extra_blocks == 2) return launch_cfg<Geometry, 5>(a, stream);
+    if (a.extra_blocks == 0) return a.winograd ? launch_cfg<Geometry, 3, true>(a, stream) : launch_cfg<Geometry, 3, false>(a, stream);
+    if (a.extra_blocks == 2) return a.winograd ? launch_cfg<Geometry, 5, true>(a, stream) : launch_cfg<Geometry, 5, false>(a, stream);
     return hipErrorInvalidValue;
 }
 

@@ -55,9 +55,27 @@ def _pack_first_conv(w: np.ndarray, b: np.ndarray, steps: int = 6) -> np.ndarray
     return np.concatenate([packed.ravel(), b.astype(np.float32).ravel()])
 
 
-def pack(nodes, folded, cin=None) -> np.ndarray:
-    """trunk block followed by the stem block (conv1 bytes form, conv2, conv3)."""
-    parts = [_pack_conv(*folded[c.key]) for c in trunk_convs(nodes)]
+def winograd_taps(w: np.ndarray) -> np.ndarray:
+    """[cout, cin, 3] -> [cout, cin, 4]: the F(2,3) filter transform U = G g, evaluated in float64 and rounded
+    once: g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2."""
+    g = w.astype(np.float64)
+    u = np.stack([g[..., 0], (g[..., 0] + g[..., 1] + g[..., 2]) / 2, (g[..., 0] - g[..., 1] + g[..., 2]) / 2,
+                  g[..., 2]], axis=-1)
+    return u.astype(np.float32)
+
+
+def pack(nodes, folded, cin=None, winograd: bool = False) -> np.ndarray:
+    """trunk block followed by the stem block (conv1 bytes form, conv2, conv3), then any extra 64-channel
+    blocks.  With ``winograd`` the two convolutions of every identity-shortcut residual block are stored as
+    their four Winograd F(2,3) taps (the strided block stays in direct form)."""
+    convs = trunk_convs(nodes)
+    strided = set(range(6, 9))                       # kernel order: 6 x (32->32), strided a / shortcut / b, 6 x (64->64)
+
+    def one(i, c):
+        w, b = folded[c.key]
+        return _pack_conv(winograd_taps(w), b) if (winograd and i not in strided) else _pack_conv(w, b)
+
+    parts = [one(i, c) for i, c in enumerate(convs)]
     stem = nodes[:3]
     parts.append(_pack_first_conv(*folded[stem[0].key]))
     parts.append(_pack_conv(*folded[stem[1].key]))
@@ -65,8 +83,10 @@ def pack(nodes, folded, cin=None) -> np.ndarray:
     extras = nodes[TRUNK_FIRST_NODE + 7:]               # transfer-learning blocks follow the canonical blob
     assert len(extras) in EXTRA_BLOCKS
     for blk in extras:
-        parts += [_pack_conv(*folded[blk.body[0].key]), _pack_conv(*folded[blk.body[1].key])]
+        parts += [one(9, blk.body[0]), one(9, blk.body[1])]
     blob = np.concatenate(parts)
-    trunk = 6 * (3072 + 32) + (6144 + 64) + (2048 + 64) + (12288 + 64) + 6 * (12288 + 64)
-    assert blob.size == trunk + (384 + 16) + (768 + 16) + (1536 + 32) + 2 * len(extras) * (12288 + 64), blob.size
+    kt = 4 if winograd else 3
+    w32, w64 = 2 * kt * 2 * 256, 4 * kt * 4 * 256
+    trunk = 6 * (w32 + 32) + (6144 + 64) + (2048 + 64) + (12288 + 64) + 6 * (w64 + 64)
+    assert blob.size == trunk + (384 + 16) + (768 + 16) + (1536 + 32) + 2 * len(extras) * (w64 + 64), blob.size
     return blob

@@ -27,14 +27,15 @@ def engines():
 
 
 def get_engine(cache, name, spec, state, fused):
+    """fused: False | "trunk" | True (Winograd residual blocks, the default) | "direct" (fused, direct form)"""
     from hello_amd.engine import Engine
     key = (name, fused)
     if key not in cache:
-        cache[key] = Engine(spec, state, device=0, fused=fused)
+        cache[key] = Engine(spec, state, device=0, fused=True if fused == "direct" else fused, winograd=fused != "direct")
     return cache[key]
 
 
-@pytest.mark.parametrize("fused", [False, "trunk", True])
+@pytest.mark.parametrize("fused", [False, "trunk", True, "direct"])
 @pytest.mark.parametrize("name", FIXTURES)
 def test_golden_logits(engines, name, fused):
     spec, state, batch, exp = load_fixture(name)
