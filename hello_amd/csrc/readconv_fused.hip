@@ -153,6 +153,29 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// packed fp32 add / subtract of two lanes' worth of a float4 (v_pk_add_f32: two IEEE adds per instruction)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_add2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_add2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_sub2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_sub2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3, MODE_POOL = 4 };
 enum { GEOM_TRUNK = 0, GEOM_STEM = 1 };
 
@@ -370,7 +393,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
 // (requested one step ahead), 16 VALU, 16 MFMAs.  `w` holds U for this wave's 16 output channels:
 // w[c * C/16 + m]; with ROLL it is refilled in place with the next layer's registers after their last use.
 //   zmask   (32 channels) bit k: this lane's odd row of the wave's k-th tile is a shared zero row
-template <class CF, int C, int MODE, bool ROLL>
+template <class CF, int C, int MODE, bool ROLL, bool FLIP = false>
 __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* __restrict__ out,
                                            f32x4 (&w)[4 * C / 16], const float* __restrict__ next_w,
                                            const float* __restrict__ bias, unsigned zmask, float* __restrict__ dump,
@@ -381,96 +404,116 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
     constexpr int NT = (PAIRS + 15) / 16;                                    // 5 | 9 tiles
     constexpr int ITER = (NT + NPG - 1) / NPG;                               // tiles of position group 0
     constexpr int TOFF = NPG * 32 * C;                                       // floats between a wave's tiles
+    constexpr bool HAS_TAIL = (NT % NPG) != 0;                               // the last tile exists for group 0 only
     static_assert(NCB * NPG == CF::NW, "waves must tile channel blocks x position groups");
-    const int cb = wave % NCB, pg = wave / NCB;
+    // FLIP hands the odd tile to the other position group: alternate layers load the SIMDs evenly
+    const int cb = wave % NCB, pg = FLIP ? NPG - 1 - wave / NCB : wave / NCB;
     const int j = lane & 15, q = lane >> 4;
     const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    const float* opb[4 * M];                                                 // row 32 pg + 2 j + i, input group m
+    // rows 32 pg + 2 j + i, i = 0..3: rows i and i+1 (i even) share their swizzle and sit a constant apart
+    // (64 floats in either image), so one pointer per (i / 2, input group) serves both
+    const float* opb[2 * M];
 #pragma unroll
-    for (int s = 0; s < 4 * M; ++s) opb[s] = in + 32 * pg * C + img_off<C, SW_W>(2 * j + s / M, 4 * (s % M) + q);
+    for (int s = 0; s < 2 * M; ++s) opb[s] = in + 32 * pg * C + img_off<C, SW_W>(2 * j + 2 * (s / M), 4 * (s % M) + q);
+    constexpr int ODD = 64;                                                  // img_off(r + 1, c) - img_off(r, c), r even
     float* const o0 = out + 32 * pg * C + img_off<C, SW_W>(2 * j + 1, 4 * cb + q);   // flat row 2P   = image row 2P + 1
     float* const o1 = out + 32 * pg * C + img_off<C, SW_W>(2 * j + 2, 4 * cb + q);   // flat row 2P+1 = image row 2P + 2
-    const bool last_tile_here = (pg + NPG * (ITER - 1)) < NT;                // wave-uniform
+    const bool last_tile_here = !HAS_TAIL || (pg + NPG * (ITER - 1)) < NT;   // wave-uniform
 
     f32x4 ring[2][4];
-    f32x4 acc[4] = {zero4, zero4, zero4, zero4};
-    f32x4 res0 = zero4, res1 = zero4;
+    f32x4 acc[2][4];                                                         // accumulator sets of even / odd tiles
+    f32x4 res0 = zero4, res1 = zero4, y0 = zero4, y1 = zero4;
     constexpr int NU = ITER * M;
     auto issue = [&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int k = u / M, m = u % M;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ring[u & 1][i] = *(const f32x4*)(opb[i * M + m] + k * TOFF);
+        for (int i = 0; i < 4; ++i) ring[u & 1][i] = *(const f32x4*)(opb[(i / 2) * M + m] + (i & 1) * ODD + k * TOFF);
+    };
+    // output transform, bias, ReLU, residual of element e of tile kk (its accumulators are complete)
+    auto epi_store = [&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        {
+            const f32x4(&a)[4] = acc[kk & 1];
+            y0 = pk_add(pk_add(pk_add(a[0], a[1]), a[2]), b4);
+            y1 = pk_add(pk_sub(pk_sub(a[1], a[2]), a[3]), b4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y0[e] = fmaxf(y0[e], 0.f);
+                y1[e] = fmaxf(y1[e], 0.f);
+            }
+            if constexpr (MODE == MODE_RESID_INPLACE) {
+                y0 = pk_add(y0, res0);
+                y1 = pk_add(y1, res1);
+            }
+        }
+        if constexpr (C == 32) {
+            if ((zmask >> kk) & 1u) y1 = zero4;                               // the shared zero row between reads
+        }
+        float* p0 = o0 + kk * TOFF;
+        float* p1 = o1 + kk * TOFF;
+        if constexpr (16 * (NT - 1) + 15 >= PAIRS && kk == ITER - 1) {       // only the last tile can overrun
+            const bool ok = 16 * (pg + NPG * kk) + j < PAIRS;
+            p0 = ok ? p0 : dump;
+            p1 = ok ? p1 : dump;
+        }
+        *(f32x4*)p0 = y0;
+        *(f32x4*)p1 = y1;
     };
     issue(std::integral_constant<int, 0>{});
     static_for<0, NU>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int k = u / M, m = u % M;
-        constexpr bool tail = (k == ITER - 1) && (NT % NPG != 0);            // a tile only position group 0 owns
+        constexpr bool tail = HAS_TAIL && (k == ITER - 1);                   // a tile only position group 0 owns
+        constexpr bool pending = (m == 0) && (k >= 1);                       // tile k-1 awaits its epilogue
         if constexpr (u + 1 < NU) issue(std::integral_constant<int, u + 1>{});
-        if constexpr (MODE == MODE_RESID_INPLACE && m == 0) {
-            res0 = *(const f32x4*)(o0 + k * TOFF);
-            res1 = *(const f32x4*)(o1 + k * TOFF);
-        }
         __builtin_amdgcn_sched_barrier(0);
+        // the previous tile's epilogue: one block of VALU work + two stores ahead of this step's MFMAs
+        if constexpr (pending) epi_store(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
         if (!tail || last_tile_here) {
             f32x4 d0 = ring[u & 1][0], d1 = ring[u & 1][1], d2 = ring[u & 1][2], d3 = ring[u & 1][3];
+#if defined(RC_EXP) && RC_EXP <= 2
+            if constexpr (false) {
+#else
             if constexpr (C == 64) {
+#endif
                 // reads are stacked without zero rows: the row before a read's first and after its last is zero
                 constexpr int lo = ((16 * k + 17) / 18) * 18;                // first pair >= 16 k that starts a read
                 constexpr int hi = ((16 * k + 18) / 18) * 18 - 1;            // first pair >= 16 k that ends a read
                 if constexpr (lo > 0 && lo <= 16 * k + 15) d0 = (j == lo - 16 * k) ? zero4 : d0;
                 if constexpr (hi <= 16 * k + 15 && hi < PAIRS - 1) d3 = (j == hi - 16 * k) ? zero4 : d3;
             }
-            f32x4 v[4];
+            f32x4(&a)[4] = acc[k & 1];
+            // The input transform runs as ONE block of (packed) VALU operations ahead of the step's MFMAs: VALU
+            // and MFMA instructions share the SIMD's issue port, and a VALU operation in front of every MFMA
+            // costs the other wave of the SIMD an issue slot per MFMA (measured: 16 % of the layer).
+#if defined(RC_EXP) && RC_EXP == 1
+            const f32x4 t0 = d0, t1 = d1, t2 = d2, t3 = d3;
+#else
+            const f32x4 t0 = pk_sub(d0, d2), t1 = pk_add(d1, d2), t2 = pk_sub(d2, d1), t3 = pk_sub(d1, d3);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[0][e] = d0[e] - d2[e];
-                v[1][e] = d1[e] + d2[e];
-                v[2][e] = d2[e] - d1[e];
-                v[3][e] = d1[e] - d3[e];
+                const bool first = (m == 0) && (e == 0);
+                a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0 * M + m][e], t0[e], first ? zero4 : a[0], 0, 0, 0);
+                a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1 * M + m][e], t1[e], first ? zero4 : a[1], 0, 0, 0);
+                a[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * M + m][e], t2[e], first ? zero4 : a[2], 0, 0, 0);
+                a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3 * M + m][e], t3[e], first ? zero4 : a[3], 0, 0, 0);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c * M + m][e], v[c][e], acc[c], 0, 0, 0);
+        }
+        if constexpr (MODE == MODE_RESID_INPLACE && m == M - 1) {            // residual input of this tile's epilogue
+            res0 = *(const f32x4*)(o0 + k * TOFF);
+            res1 = *(const f32x4*)(o1 + k * TOFF);
         }
         if constexpr (ROLL && k == ITER - 1) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) w[c * M + m] = *(const f32x4*)(next_w + (c * M + m) * 256);
         }
-        if constexpr (m == M - 1) {
-            if (!tail || last_tile_here) {
-                f32x4 y0, y1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    y0[e] = fmaxf(((acc[0][e] + acc[1][e]) + acc[2][e]) + b4[e], 0.f);
-                    y1[e] = fmaxf(((acc[1][e] - acc[2][e]) - acc[3][e]) + b4[e], 0.f);
-                }
-                if constexpr (MODE == MODE_RESID_INPLACE) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        y0[e] += res0[e];
-                        y1[e] += res1[e];
-                    }
-                }
-                if constexpr (C == 32) {
-                    if ((zmask >> k) & 1u) y1 = zero4;                        // the shared zero row between reads
-                }
-                float* p0 = o0 + k * TOFF;
-                float* p1 = o1 + k * TOFF;
-                if constexpr (16 * (NT - 1) + 15 >= PAIRS && k == ITER - 1) {  // only the last tile can overrun
-                    const bool ok = 16 * (pg + NPG * k) + j < PAIRS;
-                    p0 = ok ? p0 : dump;
-                    p1 = ok ? p1 : dump;
-                }
-                *(f32x4*)p0 = y0;
-                *(f32x4*)p1 = y1;
-            }
-            acc[0] = acc[1] = acc[2] = acc[3] = zero4;
+        if constexpr (u == NU - 1) {
+            if (!tail || last_tile_here) epi_store(std::integral_constant<int, ITER - 1>{});
         }
     });
 }
@@ -559,13 +602,16 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     const float* __restrict__ W = a.w;
 
     // which of a lane's rows are shared zero rows: bit k = the wave's k-th tile, per image geometry
-    unsigned pad1 = 0;
+    unsigned pad1 = 0, pad1f = 0;                             // pad1f: the same for a FLIPped Winograd layer
     const unsigned pad2 = 0;                                  // the 64-channel images hold no zero rows between reads
     {
         const int pg1 = wave / 2;                              // 32-channel layers: 2 blocks x 2 position groups
         if (WINO) {                                            // tile = 16 pairs of rows; the odd row of pair P = 35 mod 36
 #pragma unroll
-            for (int k = 0; k < (T1 / 2 + 1) / 2; ++k) pad1 |= ((((pg1 + 2 * k) * 16 + j) % (RS1 / 2)) == RS1 / 2 - 1 ? 1u : 0u) << k;
+            for (int k = 0; k < (T1 / 2 + 1) / 2; ++k) {
+                pad1 |= ((((pg1 + 2 * k) * 16 + j) % (RS1 / 2)) == RS1 / 2 - 1 ? 1u : 0u) << k;
+                pad1f |= ((((1 - pg1 + 2 * k) * 16 + j) % (RS1 / 2)) == RS1 / 2 - 1 ? 1u : 0u) << k;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < T1 / 2; ++k) pad1 |= ((((pg1 + 2 * k) * 16 + j) % RS1) >= L1 ? 1u : 0u) << k;
@@ -649,8 +695,11 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
 
     // ---- 3 x ResidualBlock(32): x -> relu(conv) -> relu(conv) + x --------------------------------
     __syncthreads();
+#ifndef RC_PHASES
+#define RC_PHASES 7
+#endif
 #pragma unroll
-    for (int blk = 0; blk < 3; ++blk) {
+    for (int blk = 0; blk < ((RC_PHASES & 1) ? 3 : 0); ++blk) {
         const int off_a = OFF_B + (2 * blk) * (W3232 + 32), off_b = off_a + (W3232 + 32);
         // the block's second conv rolls in the next block's first conv, or the strided conv (4 channel blocks;
         // its 6 registers are the first 6 of the 8 a Winograd layer refills)
@@ -658,7 +707,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         if constexpr (WINO) {
             wino_layer<CF, 32, MODE_PLAIN, true>(X, H, wA, slice(off_b, cb2, NVA), W + off_a + W3232, pad1, dump, wave, lane);
             __syncthreads();
-            wino_layer<CF, 32, MODE_RESID_INPLACE, true>(H, X, wA, nxt, W + off_b + W3232, pad1, dump, wave, lane);
+            wino_layer<CF, 32, MODE_RESID_INPLACE, true, true>(H, X, wA, nxt, W + off_b + W3232, pad1f, dump, wave, lane);
         } else {
             conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN, true>(
                 X, H, w6, slice(off_b, cb2, 6), W + off_a + W3232, sreg, pad1, dump, wave, lane);
@@ -670,6 +719,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
 
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
+    if (RC_PHASES & 2) {
     load_weights<2>(w2, W + OFF_SC, cb4, lane);
     load_weights<12>(w12, W + OFF_C2, cb4, lane);
     if (tid < 32) ((f32x4*)H)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};   // rows 0 and 36G+1
@@ -687,9 +737,10 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
     __syncthreads();
 
+    }
     // ---- NB64 x ResidualBlock(64) (3 in the canonical read convolver) ------------------------------
 #pragma unroll
-    for (int blk = 0; blk < NB64; ++blk) {
+    for (int blk = 0; blk < ((RC_PHASES & 4) ? NB64 : 0); ++blk) {
         const int off_a = O::off_d(blk), off_b = off_a + (W6464 + 64);
         if constexpr (WINO) {
             wino_layer<CF, 64, MODE_PLAIN, true>(X, H, wB, slice(off_b, cb4, NVB), W + off_a + W6464, 0u, dump, wave, lane);
