@@ -138,6 +138,16 @@ def pack_conv(w: np.ndarray, b: np.ndarray, groups: int = 1):
     return packed, bias
 
 
+def pack_conv_winograd(w: np.ndarray, b: np.ndarray):
+    """[cout, cin, 3] -> [cout][cin/8][4 Winograd taps][8 channels] (hello_amd/csrc/conv_wino.hip), bias [cout]."""
+    from .readconv_pack import winograd_taps
+    cout, cin, k = w.shape
+    assert k == 3 and cin % 8 == 0
+    u = winograd_taps(w)                                   # [cout, cin, 4]
+    packed = u.reshape(cout, cin // 8, 8, 4).transpose(0, 1, 3, 2).reshape(cout, 4 * cin)
+    return np.ascontiguousarray(packed, dtype=np.float32), b.astype(np.float32)
+
+
 # canonical read-convolver shape the fused kernel implements (architectures/read_convolver.py)
 def _canonical_read_convolver_extras(nodes, cin) -> int:
     """-1 if ``nodes`` is not the canonical read convolver; otherwise the number of extra identity-shortcut
@@ -196,6 +206,11 @@ class _Lowering:
         return v
 
     # -- single nodes ------------------------------------------------------------------------
+    @staticmethod
+    def _winograd_ok(node: ns.Conv, x: Value) -> bool:
+        return (node.k == 3 and node.stride == 1 and node.pad == 1 and node.groups == 1 and node.dilation == 1
+                and not x.u8 and node.cin % 8 == 0 and node.cout % 64 == 0)
+
     def conv(self, node: ns.Conv, x: Value, res: Optional[Value] = None) -> Value:
         if node.act not in ("relu", "none", "softplus"):
             raise NotImplementedError(f"activation {node.act!r} is not implemented by the HIP engine")
@@ -203,14 +218,16 @@ class _Lowering:
             raise NotImplementedError("dilated convs are not implemented by the HIP engine")
         assert x.channels == node.cin, (node.key, x.channels, node.cin)
         w, b = self.folded[node.key]
-        packed, bias = pack_conv(w, b, node.groups)
+        wino = self.winograd and self._winograd_ok(node, x)
+        packed, bias = pack_conv_winograd(w, b) if wino else pack_conv(w, b, node.groups)
         lout = ns.out_length([node], x.length)
         y = self.new(x.domain, lout, node.cout)
         self.ops.append(Op(
             OP_CONV1D, x.domain, src0=x.vid, dst=y.vid, res=res.vid if res is not None else BUF_NONE,
             cin=node.cin, cout=node.cout, k=node.k, stride=node.stride, pad=node.pad,
             lin=x.length, lout=lout,
-            flags={"relu": FLAG_RELU, "softplus": FLAG_SOFTPLUS, "none": 0}[node.act] | (FLAG_SRC_U8 if x.u8 else 0),
+            flags=({"relu": FLAG_RELU, "softplus": FLAG_SOFTPLUS, "none": 0}[node.act] | (FLAG_SRC_U8 if x.u8 else 0)
+                   | (FLAG_WINOGRAD if wino else 0)),
             w_off=self.blob.add(packed), b_off=self.blob.add(bias), name=node.key,
             macs_per_row=lout * node.cout * (node.cin // node.groups) * node.k))
         return y

@@ -547,7 +547,16 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.cout_pad = ((o.cout + 31) / 32) * 32;
                 a.relu = (o.flags & HELLO_FLAG_RELU) ? 1 : ((o.flags & HELLO_FLAG_SOFTPLUS) ? 2 : 0);
                 a.src_u8 = (o.flags & HELLO_FLAG_SRC_U8) ? 1 : 0;
+                a.wino = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
                 if (!a.src) return fail(HELLO_ERR_ARG, "op %d reads an input the caller did not supply", op_index);
+                if (a.wino) {
+                    a.kpad = 4 * o.cin;
+                    a.cout_pad = o.cout;
+                    if (!hello::conv1d_wino_supported(a))
+                        return fail(HELLO_ERR_MODEL, "op %d: this convolution has no Winograd form", op_index);
+                    HIP_TRY(hello::launch_conv1d_wino(a, stream));
+                    break;
+                }
                 HIP_TRY(hello::launch_conv1d(a, stream));
                 break;
             }

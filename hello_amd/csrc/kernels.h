@@ -19,8 +19,11 @@ struct ConvArgs {
     int cout_pad;         // multiple of 32
     int relu;                  // activation: 0 none, 1 ReLU, 2 Softplus (beta 1, threshold 20)
     int src_u8;
+    int wino;                  // Winograd F(2,3) form (conv_wino.hip): w packed [cout][cin/8][4 components][8], kpad = 4*cin
 };
 hipError_t launch_conv1d(const ConvArgs& a, hipStream_t stream);
+bool conv1d_wino_supported(const ConvArgs& a);
+hipError_t launch_conv1d_wino(const ConvArgs& a, hipStream_t stream);
 
 hipError_t launch_maxpool(const float* src, float* dst, long long rows, int lin, int lout, int c,
                           int k, int stride, int pad, hipStream_t stream);
