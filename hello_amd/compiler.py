@@ -73,7 +73,8 @@ class Op:
     w_off: int = 0
     b_off: int = 0
     name: str = ""
-    macs_per_row: int = 0
+    macs_per_row: int = 0            # algorithmic (direct-form) MACs per row of the op's domain
+    exec_macs_per_row: float = 0.0   # MACs the matrix instructions execute per row (0: same as macs_per_row)
 
 
 @dataclass
@@ -89,6 +90,7 @@ class Program:
     buffers: List[Tuple[int, int]]          # (domain, floats_per_row) per physical buffer id
     weights: np.ndarray                      # float32 blob
     fused_read_convolver: bool = False
+    winograd: bool = False           # k3/s1/p1 convolutions run in Winograd F(2,3) form where a kernel offers it
 
     def describe(self) -> str:
         lines = [f"program {self.spec_name}: {len(self.ops)} ops, {len(self.buffers)} buffers, "
@@ -229,7 +231,8 @@ class _Lowering:
             flags=({"relu": FLAG_RELU, "softplus": FLAG_SOFTPLUS, "none": 0}[node.act] | (FLAG_SRC_U8 if x.u8 else 0)
                    | (FLAG_WINOGRAD if wino else 0)),
             w_off=self.blob.add(packed), b_off=self.blob.add(bias), name=node.key,
-            macs_per_row=lout * node.cout * (node.cin // node.groups) * node.k))
+            macs_per_row=lout * node.cout * (node.cin // node.groups) * node.k,
+            exec_macs_per_row=float(((lout + 1) // 2) * 4 * node.cout * node.cin) if wino else 0.0))
         return y
 
     def net(self, nodes, x, head_slot: Optional[int] = None, softmax=False):
@@ -330,7 +333,8 @@ class _Lowering:
                 # the whole read convolver (stem included) + segment sum in one kernel, straight from the bytes
                 self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=buf, dst=y.vid, cin=cin, cout=64,
                                    k=extras, lin=150, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name,
-                                   flags=FLAG_SRC_U8 | wflag, macs_per_row=ns.macs(nodes, 150)))
+                                   flags=FLAG_SRC_U8 | wflag, macs_per_row=ns.macs(nodes, 150),
+                                   exec_macs_per_row=readconv_pack.executed_macs_per_read(self.winograd, extras)))
             self.used_fused = True
             return y
         return self.segsum(self.net(nodes, x), seg)
@@ -487,4 +491,4 @@ def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool 
         spec_name=spec.name, window=spec.window, channels0=spec.channels[0],
         channels1=spec.channels[1] if spec.hybrid_inputs else 0,
         n_experts=n_experts, has_meta=has_meta, uses_ref=low.uses_ref, ops=low.ops,
-        buffers=buffers, weights=low.blob.finish(), fused_read_convolver=low.used_fused)
+        buffers=buffers, weights=low.blob.finish(), fused_read_convolver=low.used_fused, winograd=low.winograd)

@@ -55,6 +55,26 @@ def _pack_first_conv(w: np.ndarray, b: np.ndarray, steps: int = 6) -> np.ndarray
     return np.concatenate([packed.ravel(), b.astype(np.float32).ravel()])
 
 
+def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, reads_per_group: int = 4) -> float:
+    """MACs the fused kernel's MFMA instructions really execute per read (tile padding included), from its
+    tile schedule in readconv_fused.hip: v_mfma_f32_16x16x4_f32 = 16*16*4 MACs.  Direct form: 5 052 MFMAs per
+    wave and group of 4 reads; Winograd form: 3 948 on average (the residual blocks need 4 instead of 6
+    contractions per pair of positions, minus what their half-empty last tile gives back)."""
+    g = reads_per_group
+    t_stem12 = -(-(-(-150 * g // 16)) // 4) * 4                  # 16-row tiles of conv1 / conv2, 4 position groups
+    t_stem3 = -(-(-(-150 * g // 14)) // 4) * 4                   # stride-14 tiles of conv3
+    stem = t_stem12 * 6 + t_stem12 * 3 * 4 + t_stem3 * 2 * 3 * 4
+    t1, t2 = -(-72 * g // 16), -(-36 * g // 16)                  # direct tiles at 32 / 64 channels
+    strided = t2 * 4 * 6 * 4 + t2 * 4 * 2 * 4 + t2 * 4 * 12 * 4
+    n64 = 6 + 2 * extra_blocks
+    if winograd:
+        w1, w2 = -(-36 * g // 16), -(-18 * g // 16)              # tiles of 16 pairs
+        blocks = 6 * (w1 * 2 * 2 * 16) + n64 * (w2 * 4 * 4 * 16)
+    else:
+        blocks = 6 * (t1 * 2 * 6 * 4) + n64 * (t2 * 4 * 12 * 4)
+    return (stem + strided + blocks) * 1024.0 / g
+
+
 def winograd_taps(w: np.ndarray) -> np.ndarray:
     """[cout, cin, 3] -> [cout, cin, 4]: the F(2,3) filter transform U = G g, evaluated in float64 and rounded
     once: g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2."""
