@@ -663,8 +663,12 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         load_weights<3>(ws2, W + OFF_S2, 0, lane);
         load_weights<3>(ws3, W + OFF_S3, wave % 2, lane);
         __syncthreads();
-        stem_conv1<CF>(s_u8, bufB, W + OFF_S1, ch, dump, wave, lane);
+#ifndef RC_STEM
+#define RC_STEM 7
+#endif
+        if (RC_STEM & 1) stem_conv1<CF>(s_u8, bufB, W + OFF_S1, ch, dump, wave, lane);
         __syncthreads();
+        if (RC_STEM & 2)
         conv_layer<CF, 16, 16, 3, 1, 0, 1, 1, 0, CF::ST12, MODE_PLAIN, false, GEOM_STEM, 16, CF::SROWS>(
             bufB, bufA, ws2, nullptr, W + OFF_S2 + 3 * 256, sreg, 0u, dump, wave, lane);
         __syncthreads();
@@ -672,6 +676,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             const int row = (tid >> 3) * RS1;
             *(f32x4*)(X + row * 32 + 4 * (tid & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (RC_STEM & 4)
         conv_layer<CF, 16, 32, 3, 1, 0, 1, 1, 0, CF::ST3, MODE_POOL, false, GEOM_STEM, 14, RS1 * CF::G, false, SW_OLD, SWX>(
             bufA, X, ws3, nullptr, W + OFF_S3 + 2 * 3 * 256, sreg, 0u, dump, wave, lane, n_here);
         __syncthreads();
