@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_wino_kernel(ConvArgs a) {
         for (int g = 0; g < CPC / 8; ++g) {
             f32x4 wa[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) wa[c] = *(const f32x4*)&s_w[(wn * 32 + lj) * LD + c * CPC + g * 8 + lh * 4];
+            // the host packs the taps per 8-channel group ([cin/8][4 components][8]) whatever the chunk size is
+            for (int c = 0; c < 4; ++c) wa[c] = *(const f32x4*)&s_w[(wn * 32 + lj) * LD + (g * 4 + c) * 8 + lh * 4];
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp) {
                 const float* row = &s_act[(ptile0 + tp * 32 + lj) * LD + g * 8 + lh * 4];

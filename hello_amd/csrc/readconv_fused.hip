@@ -474,11 +474,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
         if constexpr (pending) epi_store(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
         if (!tail || last_tile_here) {
             f32x4 d0 = ring[u & 1][0], d1 = ring[u & 1][1], d2 = ring[u & 1][2], d3 = ring[u & 1][3];
-#if defined(RC_EXP) && RC_EXP <= 2
-            if constexpr (false) {
-#else
             if constexpr (C == 64) {
-#endif
                 // reads are stacked without zero rows: the row before a read's first and after its last is zero
                 constexpr int lo = ((16 * k + 17) / 18) * 18;                // first pair >= 16 k that starts a read
                 constexpr int hi = ((16 * k + 18) / 18) * 18 - 1;            // first pair >= 16 k that ends a read
@@ -489,11 +485,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
             // The input transform runs as ONE block of (packed) VALU operations ahead of the step's MFMAs: VALU
             // and MFMA instructions share the SIMD's issue port, and a VALU operation in front of every MFMA
             // costs the other wave of the SIMD an issue slot per MFMA (measured: 16 % of the layer).
-#if defined(RC_EXP) && RC_EXP == 1
-            const f32x4 t0 = d0, t1 = d1, t2 = d2, t3 = d3;
-#else
             const f32x4 t0 = pk_sub(d0, d2), t1 = pk_add(d1, d2), t2 = pk_sub(d2, d1), t3 = pk_sub(d1, d3);
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -573,6 +565,88 @@ __device__ __forceinline__ void stem_conv1(const unsigned char* __restrict__ s_u
             cur1[s] = nxt1[s];
         }
     }
+}
+
+// ---- stem conv3 (16 -> 32, valid) + ReLU + MaxPool1d(3, 2), one read per wave ------------------------------
+// A tile is 16 conv3 positions of ONE read, tiles 14 apart (11 per read): lane row j holds position 14 t + j, so
+// the pooled outputs 7 t .. 7 t + 6 = max over positions (2p, 2p+1, 2p+2) are two DPP row shifts away and only
+// pooled values reach LDS (image row 1 + read*72 + p).  The wave computes BOTH 16-channel blocks of its tiles:
+// the three operand reads of a tile feed 24 MFMAs (4 chains), and one output-row computation serves both
+// blocks.  Everything a tile adds to the lane's addresses is a compile-time constant: the 16-channel image's
+// swizzle bit depends on (row + c) mod 8 only, so 8 per-lane base pointers cover every (tile, tap).
+// Bias and ReLU are applied AFTER the max: x -> fl(x + b) and ReLU are monotone, so the bits are the same.
+template <class CF, int SOUT>
+__device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, float* __restrict__ out,
+                                                const float* __restrict__ W3, float* __restrict__ dump, int wave,
+                                                int lane, int n_here) {
+    static_assert(CF::NW == CF::G, "one read per wave");
+    constexpr int NTT = 11;                                   // ceil(71 / 7) tiles per read
+    const int j = lane & 15, q = lane >> 4;
+    const int rd = wave;
+    f32x4 w[2][3];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) w[blk][tap] = *(const f32x4*)(W3 + ((blk * 3 + tap) * 64 + lane) * 4);
+    f32x4 b4[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) b4[blk] = *(const f32x4*)(W3 + 2 * 3 * 256 + blk * 16 + 4 * q);
+    const int lrow = rd * 150 + j;
+    const float* pin[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pin[k] = in + lrow * 16 + 4 * (q ^ (2 * (((lrow + k) >> 2) & 1)));
+    const int orow = 1 + rd * rc::RS1 + (j >> 1);
+    const bool lane_ok = ((j & 1) == 0) && (j <= 12) && (rd < n_here);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ring[2][3];
+    f32x4 acc[2][2][2];                                       // [tile parity][block][chain]
+    auto issue = [&](auto tc) {
+        constexpr int tt = decltype(tc)::value;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            constexpr int c0 = 14 * tt;
+            ring[tt & 1][tap] = *(const f32x4*)(pin[(c0 + tap) & 7] + (c0 + tap) * 16);
+        }
+    };
+    auto epilogue = [&](auto tc) {
+        constexpr int tt = decltype(tc)::value;
+        const int row = orow + 7 * tt;
+        const bool ok = lane_ok && (7 * tt + 6 < rc::L1 || (j >> 1) < rc::L1 - 7 * tt);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const f32x4 sum = pk_add(acc[tt & 1][blk][0], acc[tt & 1][blk][1]);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float m = fmaxf(fmaxf(sum[e], row_shl(sum[e], 1)), row_shl(sum[e], 2));
+                v[e] = fmaxf(m + b4[blk][e], 0.f);
+            }
+            float* ptr = out + img_off<32, SOUT>(row, 4 * blk + q);
+            *(f32x4*)(ok ? ptr : dump) = v;
+        }
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NTT>([&](auto tc) {
+        constexpr int tt = decltype(tc)::value;
+        if constexpr (tt + 1 < NTT) issue(std::integral_constant<int, tt + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (tt >= 1) epilogue(std::integral_constant<int, (tt >= 1 ? tt - 1 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const f32x4 x = ring[tt & 1][tap];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool first = (tap == 0) && (e < 2);
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+                    acc[tt & 1][blk][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        w[blk][tap][e], x[e], first ? zero4 : acc[tt & 1][blk][e & 1], 0, 0, 0);
+            }
+        }
+    });
+    epilogue(std::integral_constant<int, NTT - 1>{});
 }
 
 template <class CF, bool STEM, int NB64, bool WINO>
@@ -659,9 +733,8 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         } else {
             for (int i = tid; i < CF::U8_BYTES; i += THREADS) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
         }
-        f32x4 ws2[3], ws3[3];
+        f32x4 ws2[3];
         load_weights<3>(ws2, W + OFF_S2, 0, lane);
-        load_weights<3>(ws3, W + OFF_S3, wave % 2, lane);
         __syncthreads();
 #ifndef RC_STEM
 #define RC_STEM 7
@@ -676,9 +749,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             const int row = (tid >> 3) * RS1;
             *(f32x4*)(X + row * 32 + 4 * (tid & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (RC_STEM & 4)
-        conv_layer<CF, 16, 32, 3, 1, 0, 1, 1, 0, CF::ST3, MODE_POOL, false, GEOM_STEM, 14, RS1 * CF::G, false, SW_OLD, SWX>(
-            bufA, X, ws3, nullptr, W + OFF_S3 + 2 * 3 * 256, sreg, 0u, dump, wave, lane, n_here);
+        if (RC_STEM & 4) stem_conv3_pool<CF, SWX>(bufA, X, W + OFF_S3, dump, wave, lane, n_here);
         __syncthreads();
         if (tid < 8) ((f32x4*)H)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};        // row 0 of the 32-channel image
     } else {
