@@ -61,12 +61,12 @@ template <bool WINO>
 struct Offs {
     static constexpr int KT = WINO ? 4 : 3;
     static constexpr int W3232 = 2 * KT * 2 * 256, W3264 = 4 * 3 * 2 * 256, W3264S = 4 * 1 * 2 * 256;
-    static constexpr int W6464 = 4 * KT * 4 * 256, W6464D = 4 * 3 * 4 * 256;
+    static constexpr int W6464 = 4 * KT * 4 * 256;
     static constexpr int OFF_B = 0;                                   // 6 convs 32->32 (residual blocks)
     static constexpr int OFF_C1 = OFF_B + 6 * (W3232 + 32);           // 32->64 k3 s2
     static constexpr int OFF_SC = OFF_C1 + W3264 + 64;                // 32->64 k1 s2
-    static constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3 of the strided block (always direct)
-    static constexpr int OFF_D = OFF_C2 + W6464D + 64;                // 6 convs 64->64 (residual blocks)
+    static constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3 of the strided block
+    static constexpr int OFF_D = OFF_C2 + W6464 + 64;                 // 6 convs 64->64 (residual blocks)
     static constexpr int W_TRUNK = OFF_D + 6 * (W6464 + 64);
     static constexpr int OFF_S1 = W_TRUNK;                            // [6 steps][64 lanes], bias[16]
     static constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps][64 lanes][4], bias[16]
@@ -97,7 +97,9 @@ struct Cfg {
     static constexpr int BUF_FLOATS = cmax(cmax(ROWS2 * 64, ROWS1 * 32), SROWS * 16);
     static constexpr int U8_BYTES = ((ST12 * 16 + 8) * 7 + 15) / 16 * 16;   // every conv1 tile reads in bounds
 
-    static constexpr int NSREG = (T2 * 4 + NW_ - 1) / NW_;   // shortcut tiles a wave keeps in registers
+    // shortcut tiles a wave keeps in registers: T2 16-position tiles, or (Winograd form of the block's second
+    // conv) two 16-position tiles per tile of 16 pairs
+    static constexpr int NSREG = cmax((T2 * 4 + NW_ - 1) / NW_, 2 * ((RS2 * G_ / 2 + 15) / 16));
     // Tiles past the last read of the group are computed and discarded; their operand reads run up to
     // (T2*16 + 2) rows of 64 floats past the start of the SECOND image, so the allocation covers that
     // extent (the bytes read there are never consumed by a stored result).
@@ -153,7 +155,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// packed fp32 add / subtract of two lanes' worth of a float4 (v_pk_add_f32: two IEEE adds per instruction)
+// packed fp32 add / subtract of two lanes' worth of a float4 (v_pk_add_f32: two IEEE adds per instruction).
+// ONLY for operands that come from LDS / plain VALU results: the compiler's hazard recogniser does not look
+// inside inline asm, so feeding it a fresh MFMA result would read the accumulator before the matrix pipe has
+// written it (the software-managed MFMA -> VALU hazard).  Epilogues therefore use ordinary vector arithmetic.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) {
     f32x2 r;
@@ -177,7 +182,7 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
 }
 
 enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3, MODE_POOL = 4 };
-enum { GEOM_TRUNK = 0, GEOM_STEM = 1 };
+enum { GEOM_TRUNK = 0, GEOM_STEM = 1, GEOM_WPAIR = 2 };   // WPAIR: tile 2t / 2t+1 = even / odd rows of the pairs of Winograd tile t
 
 // value of lane+n of the same 16-lane row (DPP row_shl); lanes shifted in from outside keep their own value
 __device__ __forceinline__ float row_shl(float v, int n) {
@@ -227,7 +232,8 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
         if (GEOM == GEOM_STEM) {
             row = TS * (pg + NPG * k) + j + s / M;
         } else {
-            const int r = (pg + NPG * k) * 16 + j;
+            const int kk = pg + NPG * k;
+            const int r = (GEOM == GEOM_WPAIR) ? 32 * (kk / 2) + 2 * j + (kk & 1) : kk * 16 + j;
             const int rd = r / RS_OUT;
             row = 1 + rd * RS_IN + (r - rd * RS_OUT) * STRIDE - PAD + s / M;
         }
@@ -397,8 +403,9 @@ template <class CF, int C, int MODE, bool ROLL, bool FLIP = false>
 __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* __restrict__ out,
                                            f32x4 (&w)[4 * C / 16], const float* __restrict__ next_w,
                                            const float* __restrict__ bias, unsigned zmask, float* __restrict__ dump,
-                                           int wave, int lane) {
-    static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE, "residual-block convolutions only");
+                                           int wave, int lane, const f32x4* __restrict__ sreg = nullptr) {
+    // MODE_ADD_REGS: the block's shortcut waits in `sreg` (GEOM_WPAIR layout: 2k = even rows, 2k+1 = odd rows)
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE || MODE == MODE_ADD_REGS, "block convolutions only");
     constexpr int M = C / 16, NCB = C / 16, NPG = CF::NW / NCB;
     constexpr int PAIRS = (C == 64 ? rc::RS2 : rc::RS1) * CF::G / 2;       // 72 | 144 pairs of rows in the group
     constexpr int NT = (PAIRS + 15) / 16;                                    // 5 | 9 tiles
@@ -437,16 +444,20 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
         constexpr int kk = decltype(kc)::value;
         {
             const f32x4(&a)[4] = acc[kk & 1];
-            y0 = pk_add(pk_add(pk_add(a[0], a[1]), a[2]), b4);
-            y1 = pk_add(pk_sub(pk_sub(a[1], a[2]), a[3]), b4);
+            y0 = ((a[0] + a[1]) + a[2]) + b4;
+            y1 = ((a[1] - a[2]) - a[3]) + b4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 y0[e] = fmaxf(y0[e], 0.f);
                 y1[e] = fmaxf(y1[e], 0.f);
             }
             if constexpr (MODE == MODE_RESID_INPLACE) {
-                y0 = pk_add(y0, res0);
-                y1 = pk_add(y1, res1);
+                y0 = y0 + res0;
+                y1 = y1 + res1;
+            }
+            if constexpr (MODE == MODE_ADD_REGS) {
+                y0 = y0 + sreg[2 * kk];
+                y1 = y1 + sreg[2 * kk + 1];
             }
         }
         if constexpr (C == 32) {
@@ -486,6 +497,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
             // and MFMA instructions share the SIMD's issue port, and a VALU operation in front of every MFMA
             // costs the other wave of the SIMD an issue slot per MFMA (measured: 16 % of the layer).
             const f32x4 t0 = pk_sub(d0, d2), t1 = pk_add(d1, d2), t2 = pk_sub(d2, d1), t3 = pk_sub(d1, d3);
+            asm volatile("s_nop 1");         // VALU write -> MFMA source read distance, whatever the MFMA order below
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -615,7 +627,7 @@ __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, fl
         const bool ok = lane_ok && (7 * tt + 6 < rc::L1 || (j >> 1) < rc::L1 - 7 * tt);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            const f32x4 sum = pk_add(acc[tt & 1][blk][0], acc[tt & 1][blk][1]);
+            const f32x4 sum = acc[tt & 1][blk][0] + acc[tt & 1][blk][1];
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -653,7 +665,7 @@ template <class CF, bool STEM, int NB64, bool WINO>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
     using O = Offs<WINO>;
-    constexpr int W3232 = O::W3232, W3264 = O::W3264, W3264S = O::W3264S, W6464 = O::W6464, W6464D = O::W6464D;
+    constexpr int W3232 = O::W3232, W3264 = O::W3264, W3264S = O::W3264S, W6464 = O::W6464;
     constexpr int OFF_B = O::OFF_B, OFF_C1 = O::OFF_C1, OFF_SC = O::OFF_SC, OFF_C2 = O::OFF_C2;
     constexpr int OFF_S1 = O::OFF_S1, OFF_S2 = O::OFF_S2, OFF_S3 = O::OFF_S3;
     constexpr int SWX = WINO ? SW_W : SW_OLD;                 // swizzle of the images the residual blocks walk
@@ -797,19 +809,26 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
     if (RC_PHASES & 2) {
     load_weights<2>(w2, W + OFF_SC, cb4, lane);
-    load_weights<12>(w12, W + OFF_C2, cb4, lane);
+    load_weights<NVB>(wB, W + OFF_C2, cb4, lane);
     if (tid < 32) ((f32x4*)H)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};   // rows 0 and 36G+1
-    conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX, SW_OLD>(
+    conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX, SWX>(
         X, H, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
-    conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX, SW_OLD>(
-        X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
+    if constexpr (WINO) {
+        // the shortcut in the row order the Winograd epilogue of the block's second conv holds its outputs in
+        conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, CF::NSREG, MODE_TO_REGS, false, GEOM_WPAIR, 16, RS2 * CF::G, false, SWX,
+                   SWX>(X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
+    } else {
+        conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX, SWX>(
+            X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
+    }
     __syncthreads();
     if (tid < 32) ((f32x4*)X)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
-    conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true, GEOM_TRUNK, 16, RS2 * CF::G, true, SW_OLD, SWX>(
-        H, X, w12, slice(O::off_d(0), cb4, NVB), W + OFF_C2 + W6464D, sreg, pad2, dump, wave, lane);
-    if constexpr (WINO) {                            // the direct layer rolled in 12 of the 16 registers
-#pragma unroll
-        for (int i = 12; i < 16; ++i) wB[i] = *(const f32x4*)(slice(O::off_d(0), cb4, NVB) + i * 256);
+    if constexpr (WINO) {
+        wino_layer<CF, 64, MODE_ADD_REGS, true>(H, X, wB, slice(O::off_d(0), cb4, NVB), W + OFF_C2 + W6464, 0u, dump, wave,
+                                                lane, sreg);
+    } else {
+        conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true, GEOM_TRUNK, 16, RS2 * CF::G, true, SWX, SWX>(
+            H, X, w12, slice(O::off_d(0), cb4, NVB), W + OFF_C2 + W6464, sreg, pad2, dump, wave, lane);
     }
     __syncthreads();
 

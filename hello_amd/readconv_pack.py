@@ -65,12 +65,13 @@ def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, reads_per_grou
     t_stem3 = -(-(-(-150 * g // 14)) // 4) * 4                   # stride-14 tiles of conv3
     stem = t_stem12 * 6 + t_stem12 * 3 * 4 + t_stem3 * 2 * 3 * 4
     t1, t2 = -(-72 * g // 16), -(-36 * g // 16)                  # direct tiles at 32 / 64 channels
-    strided = t2 * 4 * 6 * 4 + t2 * 4 * 2 * 4 + t2 * 4 * 12 * 4
     n64 = 6 + 2 * extra_blocks
     if winograd:
         w1, w2 = -(-36 * g // 16), -(-18 * g // 16)              # tiles of 16 pairs
+        strided = t2 * 4 * 6 * 4 + 2 * w2 * 4 * 2 * 4 + w2 * 4 * 4 * 16
         blocks = 6 * (w1 * 2 * 2 * 16) + n64 * (w2 * 4 * 4 * 16)
     else:
+        strided = t2 * 4 * 6 * 4 + t2 * 4 * 2 * 4 + t2 * 4 * 12 * 4
         blocks = 6 * (t1 * 2 * 6 * 4) + n64 * (t2 * 4 * 12 * 4)
     return (stem + strided + blocks) * 1024.0 / g
 
@@ -89,7 +90,8 @@ def pack(nodes, folded, cin=None, winograd: bool = False) -> np.ndarray:
     blocks.  With ``winograd`` the two convolutions of every identity-shortcut residual block are stored as
     their four Winograd F(2,3) taps (the strided block stays in direct form)."""
     convs = trunk_convs(nodes)
-    strided = set(range(6, 9))                       # kernel order: 6 x (32->32), strided a / shortcut / b, 6 x (64->64)
+    strided = {6, 7}                                 # kernel order: 6 x (32->32), strided a / shortcut / b, 6 x (64->64);
+                                                     # the strided block's second conv (b) is k3/s1/p1 too
 
     def one(i, c):
         w, b = folded[c.key]
@@ -107,6 +109,6 @@ def pack(nodes, folded, cin=None, winograd: bool = False) -> np.ndarray:
     blob = np.concatenate(parts)
     kt = 4 if winograd else 3
     w32, w64 = 2 * kt * 2 * 256, 4 * kt * 4 * 256
-    trunk = 6 * (w32 + 32) + (6144 + 64) + (2048 + 64) + (12288 + 64) + 6 * (w64 + 64)
+    trunk = 6 * (w32 + 32) + (6144 + 64) + (2048 + 64) + (w64 + 64) + 6 * (w64 + 64)
     assert blob.size == trunk + (384 + 16) + (768 + 16) + (1536 + 32) + 2 * len(extras) * (w64 + 64), blob.size
     return blob

@@ -1,0 +1,80 @@
+"""Static check of the fused kernel's device assembly: no inline-asm instruction may read a register that a
+v_mfma wrote a few instructions earlier.
+
+The MFMA -> VALU read-after-write hazard is software managed on gfx950: the compiler pads it with s_nop, but
+its hazard recogniser does not look inside inline asm.  hello_amd/csrc/readconv_fused.hip uses inline asm for
+v_pk_add_f32 (input transform of the Winograd layers) and feeds it LDS-loaded operands only; this script
+fails if a future edit routes an accumulator into one of those instructions.
+
+    python tools/check_asm_hazards.py [file.hip ...]      # exit code 1 on a violation
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WINDOW = 24          # instructions; the longest MFMA here (32x32x2 f32) needs 18 wait states
+
+
+def regs(tok):
+    tok = tok.strip().rstrip(",")
+    m = re.match(r"[va]\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"[va](\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check(path):
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                        "--cuda-device-only", "-S", path, "-o", out], check=True, cwd=os.path.dirname(path),
+                       stderr=subprocess.DEVNULL)
+        lines = open(out).read().split("\n")
+    last_writer, count, in_asm, bad, n_asm = {}, 0, False, [], 0      # register -> (instruction, index)
+    for ln in lines:
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not re.match(r"[a-z]", t):
+            if t.endswith(":") and not t.startswith("."):
+                last_writer = {}                      # a new function
+            continue
+        ops = t.split(None, 1)
+        toks = ops[1].split(",") if len(ops) > 1 else []
+        count += 1
+        if in_asm and ops[0].startswith("v_"):
+            n_asm += 1
+            for x in toks[1:]:
+                for r in regs(x.split()[0] if x.strip() else ""):
+                    name, idx = last_writer.get(r, ("", -10 ** 9))
+                    if name.startswith("v_mfma") and count - idx <= WINDOW:
+                        bad.append((t, count - idx))
+                        break
+        if toks and not ops[0].startswith(("ds_write", "global_store", "buffer_store", "s_", "ds_store")):
+            for r in regs(toks[0]):
+                last_writer[r] = (ops[0], count)
+    return n_asm, bad
+
+
+def main():
+    files = sys.argv[1:] or [os.path.join(ROOT, "hello_amd", "csrc", "readconv_fused.hip")]
+    rc = 0
+    for f in files:
+        n, bad = check(os.path.abspath(f))
+        print(f"{os.path.basename(f)}: {n} inline-asm vector instructions, {len(bad)} read a fresh MFMA result")
+        for t, back in bad[:10]:
+            print(f"   {t}    <- v_mfma {back} instructions earlier")
+        rc |= bool(bad)
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())
