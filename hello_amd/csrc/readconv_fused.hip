@@ -2,8 +2,8 @@
 //
 // Reference semantics: architectures/read_convolver.py:9-144 -- the stem (6|7 -> 16 -> 16 -> 32, kernel 3,
 // no padding, ReLU each, MaxPool1d(3,2)), 3 x ResidualBlock(32), the strided 32->64 block with its 1x1
-// shortcut, 3 x ResidualBlock(64) -- followed by reduceSlots over the reads of each allele
-// (MixtureOfExpertsAdvanced.py:23-34,163).  That is 5 076 096 MAC per read, 83 % of a 30x site.
+// shortcut, 3 (or 5: transfer-learning models) x ResidualBlock(64) -- followed by reduceSlots over the reads of
+// each allele (MixtureOfExpertsAdvanced.py:23-34,163).  That is 5 076 096 MAC per read, 83 % of a 30x site.
 //
 // One workgroup (256 threads = 4 waves) carries G = 4 reads through all 18 convolutions with every
 // activation resident in LDS; nothing but the bytes is read and nothing but per-allele partial sums is
@@ -13,28 +13,26 @@
 //   LDS     two ping-pong images, float32 channels-last [row][channel].  At 32 channels the reads of the
 //           group are stacked along the row axis with ONE shared zero row between neighbours (row stride 72
 //           at 71 positions), so the k=3/pad=1 convolutions need no edge handling.  At 64 channels the reads
-//           are stacked with no rows between them (144 rows = 9 tiles exactly) and the taps that would cross
-//           a read boundary are zeroed in registers.  16-byte chunks of a row are XOR-swizzled with the row
-//           index (chunk ^ 2*(row&7) at 64 channels) so that the ds_read_b128 operand reads of 16
-//           consecutive rows, issued by lanes of two different channel quarters, hit 16 distinct bank
-//           groups whatever the tile's first row is.
+//           are stacked with no rows between them (144 rows) and the taps that would cross a read boundary
+//           are zeroed in registers.  16-byte chunks of a row are XOR-swizzled with the row index so that a
+//           ds_read_b128 of 16 lanes hits 16 distinct bank groups: SW_OLD for images walked one row per lane,
+//           SW_W for images walked two rows per lane (Winograd layers, stride-2 convs); see img_off.
 //   MFMA    v_mfma_f32_16x16x4_f32 (exact fp32), D[channel][position] = W[channel][k] X[k][position]:
-//           a wave owns one 16-channel block and walks 16-position tiles in pairs, two accumulation chains
-//           per tile (four in flight: the 40-cycle dependent latency of the 32-cycle instruction never
-//           shows).  Lane (j, q) of a tile ends with channels 4q..4q+3 of position j -> bias / ReLU /
-//           residual / store are float4.  k is ordered so that lane-quarter q supplies channels 16m+4q+t at
-//           step (tap, m, t) for BOTH operands: one ds_read_b128 feeds four MFMAs.
-//   pipeline operands two steps ahead of the MFMAs that use them, across tile pairs; the previous pair's
-//           epilogue interleaved with the current pair's MFMAs; see conv_layer.
-//   weights each wave keeps ONLY its own 16-channel slice of ONE layer in registers (<= 48 VGPRs), loaded
+//           a wave owns one 16-channel block; lane (j, q) of a tile ends with channels 4q..4q+3 of column j
+//           -> bias / ReLU / residual / store are float4.  k is ordered so that lane-quarter q supplies
+//           channels 16m+4q+t at step (tap, m, t) for BOTH operands: one ds_read_b128 feeds four MFMAs.
+//   form    WINO (default): the k=3 / stride-1 / pad-1 convolutions of the residual blocks (13 of the 18
+//           convs, 96 % of the MACs outside the stem) run in Winograd F(2,3) form, 4 instead of 6 channel
+//           contractions per pair of positions: wino_layer.  Everything else, and the whole kernel with
+//           WINO = false, runs the direct form: conv_layer (tile pairs, two accumulation chains per tile,
+//           operands two steps ahead, deferred epilogue).
+//   weights each wave keeps ONLY its own 16-channel slice of ONE layer in registers (<= 64 VGPRs), loaded
 //           straight from L2 in lane order (pre-packed by hello_amd/readconv_pack.py); the next layer's
 //           slice is rolled in place, each register refilled right after its last use.
-//   stem    runs first in the same kernel over the stacked reads (natural stride 150 rows): the three
-//           valid convolutions run over the stacked rows as one sequence; rows whose window straddles two
-//           reads are garbage nothing valid consumes.  conv1 reads the bytes themselves: with
-//           channels-last bytes the im2col index k = tap*C + c is the byte offset from the row start.
-//           conv3 tiles overlap by two rows (stride 14) so each tile max-pools 7 outputs inside one
-//           16-lane row with two DPP lane shifts, and only the pooled values ever reach LDS.
+//   stem    runs first in the same kernel over the stacked reads (natural stride 150 rows): conv1 reads the
+//           bytes themselves (channels-last bytes: the im2col index k = tap*C + c is the byte offset from
+//           the row start), conv2 runs over the stacked rows as one sequence (rows whose window straddles
+//           two reads are garbage nothing valid consumes), conv3 + ReLU + MaxPool: stem_conv3_pool.
 //   sum     reads of an allele are contiguous, so the group adds its reads per allele in order and
 //           writes one partial [36][64] slot per (group, allele) incidence; a tiny finalize kernel adds
 //           an allele's slots in order.  No atomics: results are bit-reproducible.
@@ -93,7 +91,6 @@ struct Cfg {
     static constexpr int SB = G_;                      // the stem runs over all reads of the group at once
     static constexpr int SROWS = 150 * SB;
     static constexpr int ST12 = ((SROWS + 15) / 16 + 3) / 4 * 4;   // tiles of stem conv1 / conv2 (4 position groups)
-    static constexpr int ST3 = ((SROWS + 13) / 14 + 3) / 4 * 4;    // tiles of stem conv3: 16 positions, stride 14
     static constexpr int BUF_FLOATS = cmax(cmax(ROWS2 * 64, ROWS1 * 32), SROWS * 16);
     static constexpr int U8_BYTES = ((ST12 * 16 + 8) * 7 + 15) / 16 * 16;   // every conv1 tile reads in bounds
 
@@ -181,7 +178,7 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3, MODE_POOL = 4 };
+enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3 };
 enum { GEOM_TRUNK = 0, GEOM_STEM = 1, GEOM_WPAIR = 2 };   // WPAIR: tile 2t / 2t+1 = even / odd rows of the pairs of Winograd tile t
 
 // value of lane+n of the same 16-lane row (DPP row_shl); lanes shifted in from outside keep their own value
@@ -199,7 +196,7 @@ __device__ __forceinline__ float row_shl(float v, int n) {
 //   dump     16 spare LDS bytes: stores of rows past the group are redirected there instead of branching
 //   GEOM     GEOM_TRUNK: images with a leading zero row and RS_IN / RS_OUT rows per read;  GEOM_STEM: the stem's
 //            flat stacks (150 rows per read, no leading row): tile t starts at row TS*t, valid convolution
-//   VROWS    output rows >= VROWS are discarded;  `aux` = reads present in the group (MODE_POOL only)
+//   VROWS    output rows >= VROWS are discarded
 template <class CF, int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE,
           bool ROLL, int GEOM = GEOM_TRUNK, int TS = 16, int VROWS = RS_OUT * CF::G, bool BMASK = false,
           int SIN = SW_OLD, int SOUT = SW_OLD>
@@ -207,7 +204,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
                                            f32x4 (&w)[KT * CIN / 16], const float* __restrict__ next_w,
                                            const float* __restrict__ bias, f32x4 (&sreg)[CF::NSREG],
                                            unsigned padmask, float* __restrict__ dump, int wave, int lane,
-                                           int aux = 0) {
+                                           int = 0) {
     constexpr int M = CIN / 16, NCB = COUT / 16, NPG = CF::NW / NCB, ITER = T / NPG;
     static_assert(NPG >= 1 && NCB * NPG == CF::NW && T % NPG == 0, "waves must tile channel blocks x position groups");
     const int cb = wave % NCB, pg = wave / NCB;
@@ -249,24 +246,6 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     };
     auto epilogue = [&](int k, f32x4 acc, f32x4 res) {
         f32x4 v;
-        if (MODE == MODE_POOL) {
-            // stem conv3: ReLU, MaxPool1d(3, 2) over positions j, j+1, j+2 of the lane row, then scatter the
-            // even lanes' result into the trunk's 32-channel image (row 1 + read*72 + p)
-            f32x4 m;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x0 = fmaxf(acc[e] + b4[e], 0.f);
-                m[e] = fmaxf(fmaxf(x0, row_shl(x0, 1)), row_shl(x0, 2));
-            }
-            const int r = TS * (pg + NPG * k) + j;
-            const int rd = r / 150;
-            const int p = (r - rd * 150) >> 1;
-            const int row = 1 + rd * rc::RS1 + p;
-            float* ptr = out + img_off<32, SOUT>(row, 4 * cb + q);
-            const bool ok = ((j & 1) == 0) && (j <= 12) && (p < rc::L1) && (rd < aux);
-            *(f32x4*)(ok ? ptr : dump) = m;
-            return;
-        }
         if (MODE == MODE_TO_REGS) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[e] + b4[e];
@@ -748,12 +727,8 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         f32x4 ws2[3];
         load_weights<3>(ws2, W + OFF_S2, 0, lane);
         __syncthreads();
-#ifndef RC_STEM
-#define RC_STEM 7
-#endif
-        if (RC_STEM & 1) stem_conv1<CF>(s_u8, bufB, W + OFF_S1, ch, dump, wave, lane);
+        stem_conv1<CF>(s_u8, bufB, W + OFF_S1, ch, dump, wave, lane);
         __syncthreads();
-        if (RC_STEM & 2)
         conv_layer<CF, 16, 16, 3, 1, 0, 1, 1, 0, CF::ST12, MODE_PLAIN, false, GEOM_STEM, 16, CF::SROWS>(
             bufB, bufA, ws2, nullptr, W + OFF_S2 + 3 * 256, sreg, 0u, dump, wave, lane);
         __syncthreads();
@@ -761,7 +736,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             const int row = (tid >> 3) * RS1;
             *(f32x4*)(X + row * 32 + 4 * (tid & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (RC_STEM & 4) stem_conv3_pool<CF, SWX>(bufA, X, W + OFF_S3, dump, wave, lane, n_here);
+        stem_conv3_pool<CF, SWX>(bufA, X, W + OFF_S3, dump, wave, lane, n_here);
         __syncthreads();
         if (tid < 8) ((f32x4*)H)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};        // row 0 of the 32-channel image
     } else {
@@ -783,11 +758,8 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
 
     // ---- 3 x ResidualBlock(32): x -> relu(conv) -> relu(conv) + x --------------------------------
     __syncthreads();
-#ifndef RC_PHASES
-#define RC_PHASES 7
-#endif
 #pragma unroll
-    for (int blk = 0; blk < ((RC_PHASES & 1) ? 3 : 0); ++blk) {
+    for (int blk = 0; blk < 3; ++blk) {
         const int off_a = OFF_B + (2 * blk) * (W3232 + 32), off_b = off_a + (W3232 + 32);
         // the block's second conv rolls in the next block's first conv, or the strided conv (4 channel blocks;
         // its 6 registers are the first 6 of the 8 a Winograd layer refills)
@@ -807,7 +779,6 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
 
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
-    if (RC_PHASES & 2) {
     load_weights<2>(w2, W + OFF_SC, cb4, lane);
     load_weights<NVB>(wB, W + OFF_C2, cb4, lane);
     if (tid < 32) ((f32x4*)H)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};   // rows 0 and 36G+1
@@ -832,10 +803,9 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
     __syncthreads();
 
-    }
     // ---- NB64 x ResidualBlock(64) (3 in the canonical read convolver) ------------------------------
 #pragma unroll
-    for (int blk = 0; blk < ((RC_PHASES & 4) ? NB64 : 0); ++blk) {
+    for (int blk = 0; blk < NB64; ++blk) {
         const int off_a = O::off_d(blk), off_b = off_a + (W6464 + 64);
         if constexpr (WINO) {
             wino_layer<CF, 64, MODE_PLAIN, true>(X, H, wB, slice(off_b, cb4, NVB), W + off_a + W6464, 0u, dump, wave, lane);

@@ -73,9 +73,10 @@ class _BatchedOperator:
 class ScoringNetwork:
     """Counterpart of ``MoEMergedWrapperAdvanced`` backed by the HIP engine."""
 
-    def __init__(self, spec: ns.ModelSpec, state, device: int = 0, providePredictions: bool = False, fused: bool = True):
+    def __init__(self, spec: ns.ModelSpec, state, device: int = 0, providePredictions: bool = False, fused: bool = True,
+                 winograd: bool = True):
         self.spec = spec
-        self.engine = Engine(spec, state, device=device, fused=fused)
+        self.engine = Engine(spec, state, device=device, fused=fused, winograd=winograd)
         self.moeMerged = _BatchedOperator(self.engine, spec)
         self.providePredictions = providePredictions
         self.training = False

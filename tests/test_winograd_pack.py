@@ -1,0 +1,66 @@
+"""Host side of the Winograd F(2,3) form: the filter transform, the two weight layouts the kernels read, the
+executed-MAC accounting bench.py reports."""
+import numpy as np
+
+from hello_amd import compiler, netspec as ns, readconv_pack as rp, weights
+
+
+def _direct(x, w):                     # x [cin, L] zero padded by 1, w [cout, cin, 3] -> [cout, L]
+    L = x.shape[1]
+    xp = np.pad(x, ((0, 0), (1, 1)))
+    return sum(w[:, :, t] @ xp[:, t:t + L] for t in range(3))
+
+
+def test_filter_transform_reproduces_the_direct_convolution():
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((8, 16, 3)).astype(np.float32)
+    x = rng.standard_normal((16, 18)).astype(np.float32)
+    u = rp.winograd_taps(w).astype(np.float64)                      # [cout, cin, 4]
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 2)))
+    out = np.empty((8, 18))
+    for p in range(9):                                              # pairs of positions (2p, 2p+1)
+        d = [xp[:, 2 * p + i] for i in range(4)]
+        v = [d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]]
+        m = [u[:, :, c] @ v[c] for c in range(4)]
+        out[:, 2 * p] = m[0] + m[1] + m[2]
+        out[:, 2 * p + 1] = m[1] - m[2] - m[3]
+    np.testing.assert_allclose(out, _direct(x.astype(np.float64), w.astype(np.float64)), rtol=1e-6, atol=1e-6)
+
+
+def test_generic_winograd_weight_layout():
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal((64, 24, 3)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    packed, bias = compiler.pack_conv_winograd(w, b)
+    assert packed.shape == (64, 4 * 24) and np.array_equal(bias, b)
+    u = rp.winograd_taps(w)
+    for o, c, comp in [(0, 0, 0), (5, 9, 2), (63, 23, 3), (17, 16, 1)]:
+        assert packed[o, (c // 8) * 32 + comp * 8 + c % 8] == u[o, c, comp]     # [cin/8][component][8]
+
+
+def test_fused_blob_sizes_and_flags():
+    for cfg, extra in (("single_tech", 0), ("single_tech_addendum", 2)):
+        spec = ns.build(cfg)
+        state = weights.synth_state(spec, seed=1)
+        for wino in (True, False):
+            prog = compiler.compile_model(spec, state, winograd=wino)
+            op = next(o for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED)
+            assert bool(op.flags & compiler.FLAG_WINOGRAD) == wino and op.k == extra and prog.winograd == wino
+            kt = 4 if wino else 3
+            n64 = 7 + 2 * extra                                     # strided block's second conv + the blocks' convs
+            want = (6 * (2 * kt * 2 * 256 + 32) + (6144 + 64) + (2048 + 64) + n64 * (4 * kt * 4 * 256 + 64)
+                    + (384 + 16) + (768 + 16) + (1536 + 32))
+            nodes = spec.nets["read_convolver0"]
+            assert rp.pack(nodes, weights.fold(spec, state), 6, winograd=wino).size == want
+            convs = [o for o in prog.ops if o.kind == compiler.OP_CONV1D]
+            assert any(o.flags & compiler.FLAG_WINOGRAD for o in convs) == wino
+            for o in convs:                                         # only k3/s1/p1 convs with cout % 64 == 0 qualify
+                if o.flags & compiler.FLAG_WINOGRAD:
+                    assert (o.k, o.stride, o.pad) == (3, 1, 1) and o.cout % 64 == 0 and o.cin % 8 == 0
+                    assert o.exec_macs_per_row == ((o.lout + 1) // 2) * 4 * o.cin * o.cout < o.macs_per_row
+
+
+def test_executed_macs_match_the_kernel_schedule():
+    assert rp.executed_macs_per_read(False) == 5052 * 1024          # MFMAs per wave and group of 4 reads (ISA count)
+    assert rp.executed_macs_per_read(True) == (444 + 6 * 144 + 216 + 80 + 320 + 6 * 320) * 1024
+    assert rp.executed_macs_per_read(True, 2) - rp.executed_macs_per_read(True) == 4 * 320 * 1024
