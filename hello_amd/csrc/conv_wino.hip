@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_wino_kernel(ConvArgs a) {
         }
     }
 
-    // epilogue: accumulator register r of lane (lj, lh) is channel (r&3) + 8*(r>>2) + 4*lh, pair lj
+    // epilogue: accumulator register r of lane (lj, lh) is channel (r&3) + 8*(r>>2) + 4*lh, pair lj.
+    // The residual rows of a tile are all requested before the first is used (their latency overlaps the
+    // output transform instead of being paid once per 16-byte piece).
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp) {
         const long long mg = m0 + ptile0 + tp * 32 + lj;
@@ -143,11 +145,19 @@ __global__ __launch_bounds__(256, 2) void conv1d_wino_kernel(ConvArgs a) {
         const long long item = mg / PP;
         const int p = (int)(mg - item * PP);
         const bool second = 2 * p + 1 < L;
+        const int ch0 = cb0 + wn * 32 + 4 * lh;
+        const long long o = (item * L + 2 * p) * a.cout + ch0;
+        f32x4 r0[4], r1[4];
+        if (a.res) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                r0[q] = *(const f32x4*)(a.res + o + 8 * q);
+                r1[q] = second ? *(const f32x4*)(a.res + o + a.cout + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int ch = cb0 + wn * 32 + 8 * q + 4 * lh;
-            if (ch >= a.cout) continue;
-            const f32x4 b4 = *(const f32x4*)(a.bias + ch);
+            const f32x4 b4 = *(const f32x4*)(a.bias + ch0 + 8 * q);
             f32x4 y0, y1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -157,19 +167,15 @@ __global__ __launch_bounds__(256, 2) void conv1d_wino_kernel(ConvArgs a) {
                 y0[e] = a.relu == 1 ? fmaxf(x0, 0.f) : (a.relu == 2 ? (x0 > 20.f ? x0 : log1pf(expf(x0))) : x0);
                 y1[e] = a.relu == 1 ? fmaxf(x1, 0.f) : (a.relu == 2 ? (x1 > 20.f ? x1 : log1pf(expf(x1))) : x1);
             }
-            const long long o = (item * L + 2 * p) * a.cout + ch;
             if (a.res) {
-                const f32x4 r0 = *(const f32x4*)(a.res + o);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y0[e] += r0[e];
-                if (second) {
-                    const f32x4 r1 = *(const f32x4*)(a.res + o + a.cout);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y1[e] += r1[e];
+                for (int e = 0; e < 4; ++e) {
+                    y0[e] += r0[q][e];
+                    y1[e] += r1[q][e];
                 }
             }
-            *(f32x4*)(a.dst + o) = y0;
-            if (second) *(f32x4*)(a.dst + o + a.cout) = y1;
+            *(f32x4*)(a.dst + o + 8 * q) = y0;
+            if (second) *(f32x4*)(a.dst + o + a.cout + 8 * q) = y1;
         }
     }
 }
