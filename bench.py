@@ -167,10 +167,23 @@ def main():
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at world size 1)
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout is reserved for the one
+        # JSON line, so the process's fd 1 points at stderr until the first collective has completed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
+            if backend == "nccl":
+                torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     spec = ns.build("single_tech")
     state = weights.synth_state(spec, seed=args.seed)
