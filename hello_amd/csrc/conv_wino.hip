@@ -9,8 +9,8 @@
 // re-association only.  Used for the allele- / site-level residual convolutions (compressor, experts, meta,
 // combiners) and for the layer-by-layer read convolvers; everything else stays in conv_generic.hip.
 //
-// Tiling (wave64, v_mfma_f32_32x32x2_f32): workgroup = 4 waves = 128 PAIRS of positions x 64 channels; a wave
-// owns 64 pairs x 32 channels x 4 Winograd components (8 accumulator tiles).  The gather is that of a
+// Tiling (wave64, v_mfma_f32_32x32x2_f32): workgroup = 4 waves = 64 PAIRS of positions x 64 channels; a wave
+// owns 32 pairs x 32 channels x 4 Winograd components (4 accumulator tiles; three waves per SIMD).  The gather is that of a
 // kernel-4 / stride-2 / padding-1 convolution whose K index is ordered (channel group, tap, channel): a chunk
 // of KC floats per pair holds taps d0..d3 of KC/4 channels, so a lane reads its four taps with four
 // ds_read_b128, forms V in registers (8 packed VALU operations per 16 MFMAs) and never stores V.  The weights
@@ -23,12 +23,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int BMP = 128;   // pairs per workgroup
+constexpr int TPW = 1;          // 32-pair tiles per wave
+constexpr int BMP = 64 * TPW;   // pairs per workgroup
 constexpr int BN = 64;     // channels per workgroup
 }  // namespace
 
 template <int KC>
-__global__ __launch_bounds__(256, 2) void conv1d_wino_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     constexpr int CPC = KC / 4;               // input channels per chunk
     constexpr int LD = KC + 4;                // LDS row stride (floats): ds_read_b128 of 16 consecutive rows is conflict-free
     constexpr int QPR = KC / 4;               // float4 per row of a chunk
@@ -91,12 +92,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_wino_kernel(ConvArgs a) {
     const int wave = t >> 6, lane = t & 63;
     const int lj = lane & 31, lh = lane >> 5;
     const int wn = wave & 1;                   // 32-channel block of this wave
-    const int ptile0 = (wave >> 1) * 64;       // first pair of this wave
-    f32x16 acc[4][2];
+    const int ptile0 = (wave >> 1) * 32 * TPW;       // first pair of this wave
+    f32x16 acc[4][TPW];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int tp = 0; tp < 2; ++tp)
+        for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][tp][r] = 0.f;
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wino_kernel(ConvArgs a) {
             // the host packs the taps per 8-channel group ([cin/8][4 components][8]) whatever the chunk size is
             for (int c = 0; c < 4; ++c) wa[c] = *(const f32x4*)&s_w[(wn * 32 + lj) * LD + (g * 4 + c) * 8 + lh * 4];
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
+            for (int tp = 0; tp < TPW; ++tp) {
                 const float* row = &s_act[(ptile0 + tp * 32 + lj) * LD + g * 8 + lh * 4];
                 const f32x4 d0 = *(const f32x4*)(row), d1 = *(const f32x4*)(row + CPC);
                 const f32x4 d2 = *(const f32x4*)(row + 2 * CPC), d3 = *(const f32x4*)(row + 3 * CPC);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wino_kernel(ConvArgs a) {
     // The residual rows of a tile are all requested before the first is used (their latency overlaps the
     // output transform instead of being paid once per 16-byte piece).
 #pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {
+    for (int tp = 0; tp < TPW; ++tp) {
         const long long mg = m0 + ptile0 + tp * 32 + lj;
         if (mg >= mp_total) continue;
         const long long item = mg / PP;
@@ -191,11 +192,10 @@ hipError_t launch_conv1d_wino(const ConvArgs& a, hipStream_t stream) {
     const long long pairs = (a.m_total / a.lin) * ((a.lin + 1) / 2);
     const long long mtiles8 = ((pairs + BMP - 1) / BMP + 7) / 8 * 8;       // tiles of pairs, a multiple of the XCD count
     const dim3 grid((unsigned)(mtiles8 * (a.cout / BN)));
-    // 16 input channels per LDS chunk (64 MFMAs per wave between barrier pairs) measured 3 % faster than 8
-    if ((a.cin % 16) == 0)
-        hipLaunchKernelGGL((conv1d_wino_kernel<64>), grid, dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((conv1d_wino_kernel<32>), grid, dim3(256), 0, stream, a);
+    // measured on the allele stage (8 192 sites): 64 pairs x 64 channels per workgroup at three waves per SIMD
+    // (4 accumulator tiles per wave, 132 VGPRs) 3.41 ms; 128 pairs (8 tiles, two waves per SIMD) 3.60 ms with
+    // 16-channel chunks and 3.84 ms with 8-channel chunks; 8 waves x 128 channels with double-buffered LDS 4.26 ms
+    hipLaunchKernelGGL((conv1d_wino_kernel<32>), grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
