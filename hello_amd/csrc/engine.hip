@@ -161,6 +161,11 @@ int validate_model(const hello_model_desc* d) {
         if ((o.kind == HELLO_OP_SEGSUM || o.kind == HELLO_OP_MIX || o.kind == HELLO_OP_READCONV_FUSED) &&
             (o.seg < 0 || o.seg > 2))
             return fail(HELLO_ERR_MODEL, "op %d: bad segment kind", i);
+        if (o.kind == HELLO_OP_CONV1D && (o.flags & HELLO_FLAG_WINOGRAD) &&
+            !(o.k == 3 && o.stride == 1 && o.pad == 1 && o.lin == o.lout && !(o.flags & HELLO_FLAG_SRC_U8) &&
+              o.cin % 8 == 0 && o.cout % 64 == 0))
+            return fail(HELLO_ERR_MODEL, "op %d: this convolution has no Winograd form (needs k 3, stride 1, pad 1, "
+                                         "cin %% 8 == 0, cout %% 64 == 0, float input)", i);
         if (o.kind == HELLO_OP_READCONV_FUSED && !hello::readconv_supports_extra_blocks(o.k))
             return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver takes 0 or 2 extra blocks (k), got %d", i, o.k);
     }
@@ -207,10 +212,24 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
     e->desc.buffers = e->buffers.data();
     e->n_weight_floats = nbytes / 4;
     for (const hello_op& o : e->ops) {
-        if ((o.kind == HELLO_OP_CONV1D || o.kind == HELLO_OP_HEAD || o.kind == HELLO_OP_READCONV_FUSED) &&
-            ((size_t)o.w_off >= e->n_weight_floats || (size_t)o.b_off >= e->n_weight_floats)) {
+        // every weight block must lie inside the blob, in the layout its op (and arithmetic form) reads
+        size_t w_end = 0, b_end = 0;
+        if (o.kind == HELLO_OP_CONV1D) {
+            const bool wino = (o.flags & HELLO_FLAG_WINOGRAD) != 0;
+            const size_t cpad = wino ? (size_t)o.cout : (size_t)((o.cout + 31) / 32) * 32;
+            const size_t kpad = wino ? (size_t)4 * o.cin : (size_t)((o.k * o.cin + 31) / 32) * 32;
+            w_end = (size_t)o.w_off + cpad * kpad;
+            b_end = (size_t)o.b_off + cpad;
+        } else if (o.kind == HELLO_OP_HEAD) {
+            w_end = (size_t)o.w_off + (size_t)o.cout * o.cin;
+            b_end = (size_t)o.b_off + o.cout;
+        } else if (o.kind == HELLO_OP_READCONV_FUSED) {
+            w_end = (size_t)o.w_off + hello::readconv_weight_floats(o.k, (o.flags & HELLO_FLAG_WINOGRAD) != 0);
+            b_end = (size_t)o.b_off;
+        }
+        if (w_end > e->n_weight_floats || b_end > e->n_weight_floats) {
             delete e;
-            return fail(HELLO_ERR_MODEL, "weight offset outside the blob");
+            return fail(HELLO_ERR_MODEL, "a weight block runs past the end of the blob");
         }
     }
     e->scratch.resize(desc->n_buffers);

@@ -100,10 +100,13 @@ def n_pairs(alleles_per_site) -> int:
 class Engine:
     """One compiled model resident on one GPU (one instance per process and device)."""
 
-    def __init__(self, spec: ns.ModelSpec, state, device: int = 0, fused: bool = True, winograd: bool = True):
+    def __init__(self, spec: ns.ModelSpec, state, device: int = 0, fused: bool = True, winograd: bool = True,
+                 program: Optional["compiler.Program"] = None):
+        """``program``: an already compiled (or deliberately edited) program to load instead of compiling."""
         self.lib = load_library()
         self.spec = spec
-        self.program = compiler.compile_model(spec, state, fused=fused, winograd=winograd)
+        self.program = program if program is not None else compiler.compile_model(spec, state, fused=fused,
+                                                                                  winograd=winograd)
         p = self.program
         self._ops = (HelloOp * len(p.ops))()
         for dst, o in zip(self._ops, p.ops):

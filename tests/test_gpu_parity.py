@@ -145,6 +145,27 @@ def test_error_paths(engines):
     eng.forward_batch(batch)      # the engine stays usable after a rejected call
 
 
+def test_malformed_programs_are_rejected_at_creation():
+    """hello_engine_create checks what a forward would otherwise read out of bounds or misinterpret."""
+    from hello_amd import compiler
+    from hello_amd.engine import Engine
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=21)
+    prog = compiler.compile_model(spec, state)
+    prog.weights = prog.weights[:-64]                                   # the last weight block is cut short
+    with pytest.raises(RuntimeError, match="past the end of the blob"):
+        Engine(spec, state, program=prog)
+    prog = compiler.compile_model(spec, state)
+    strided = next(o for o in prog.ops if o.kind == compiler.OP_CONV1D and o.stride == 2 and o.k == 3)
+    strided.flags |= compiler.FLAG_WINOGRAD                             # a stride-2 conv has no Winograd form
+    with pytest.raises(RuntimeError, match="no Winograd form"):
+        Engine(spec, state, program=prog)
+    prog = compiler.compile_model(spec, state)
+    next(o for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED).k = 1   # only 0 or 2 extra blocks exist
+    with pytest.raises(RuntimeError, match="extra blocks"):
+        Engine(spec, state, program=prog)
+
+
 def test_wide_model_runs_layer_by_layer_and_matches_oracle(engines):
     """The *_wide configuration (2x channels) is outside the fused kernel's shape: it must take the generic
     conv path (including the 128-channel workgroup tile) and still agree with the oracle."""
