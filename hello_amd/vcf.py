@@ -104,3 +104,56 @@ def call_from_prediction(prediction, chromosome: str, start: int, length: int, g
         return call_site(prediction, chromosome, start, length, genome)
     _, e0, e1, e2, meta = prediction
     return call_site(mean_posteriors((e0, e1, e2), meta), chromosome, start, length, genome)
+
+
+# --------------------------------------------------------------------------------------------
+# the per-shard ``.features`` records and what prepareVcf makes of them
+# --------------------------------------------------------------------------------------------
+def feature_record(prediction, chromosome: str, start: int, length: int) -> dict:
+    """The dict the per-shard caller appends to its ``.features`` list for one site (reference
+    python/caller_calling.py:743-754): chromosome, position (0-based site start), length of the reference
+    allele, the meta-expert weights and the three experts' pair posteriors.  ``prediction`` is the network's
+    5-tuple (mix, e0, e1, e2, meta).  Values are stored as plain floats / a float32 NumPy array, which is
+    what prepareVcf.py:138-163 converts them to anyway, so the reference's own tool reads the file."""
+    import numpy as np
+    _, e0, e1, e2, meta = prediction
+    plain = lambda d: {pair: float(v) for pair, v in d.items()}          # noqa: E731
+    meta = np.asarray(meta.detach().cpu().numpy() if hasattr(meta, "detach") else meta, dtype=np.float32)
+    return {"chromosome": chromosome, "position": int(start), "length": int(length), "meta": meta,
+            "expertPredictions": (plain(e0), plain(e1), plain(e2))}
+
+
+def write_features(path: str, records: Sequence[dict]) -> str:
+    """``<prefix>.features``: one pickled list per shard (caller_calling.py:895-898)."""
+    import pickle
+    with open(path, "wb") as fh:
+        pickle.dump(list(records), fh)
+    return path
+
+
+@dataclass
+class ShardCalls:
+    """prepareVcf.py:126-176 for one shard: per-expert calls, the call of the expert the meta-expert trusts
+    most, the call on the meta-weighted mean (the one the final VCF is built from), and the choices BED rows."""
+    expert: Tuple[List[Optional[Call]], List[Optional[Call]], List[Optional[Call]]]
+    best: List[Optional[Call]]
+    mean: List[Optional[Call]]
+    choices: List[Tuple[str, int, int, int]]
+
+
+def calls_from_features(records: Sequence[dict], genomes: Dict[str, str]) -> ShardCalls:
+    """``genomes``: chromosome -> reference sequence (the reference reads it through its ReferenceCache)."""
+    expert: Tuple[List, List, List] = ([], [], [])
+    best, mean, choices = [], [], []
+    for rec in records:
+        chrom, pos, length = rec["chromosome"], rec["position"], rec["length"]
+        genome = genomes[chrom]
+        per_expert = [call_site(p, chrom, pos, length, genome) for p in rec["expertPredictions"]]
+        for lst, c in zip(expert, per_expert):
+            lst.append(c)
+        meta = [float(m) for m in rec["meta"]]
+        choice = max(range(3), key=lambda i: (meta[i], -i))              # np.argmax: first maximum
+        best.append(per_expert[choice])
+        mean.append(call_site(mean_posteriors(rec["expertPredictions"], meta), chrom, pos, length, genome))
+        choices.append((chrom, pos, pos + length, choice))
+    return ShardCalls(expert, best, mean, choices)

@@ -82,3 +82,21 @@ def mean_of_experts(expert_predictions: Sequence[Dict], meta: Sequence[float]) -
     """prepareVcf.py:154-163: per pair, sum_i expert_i * meta_i in float64."""
     return {pair: sum(float(expert_predictions[i][pair]) * float(meta[i]) for i in range(3))
             for pair in expert_predictions[0]}
+
+
+def prepare_shard(items: Sequence[dict], genomes: Dict[str, str]):
+    """prepareVcf.py:126-176 for one ``.features`` shard: -> (expert0 lines, expert1 lines, expert2 lines,
+    best lines, mean lines, choices rows).  A site without an alternative allele contributes None."""
+    import numpy as np
+    e0, e1, e2, best, mean, choices = [], [], [], [], [], []
+    for site in items:
+        genome = genomes[site["chromosome"]]
+        records = [call_alleles(d, site["chromosome"], site["position"], site["length"], genome)
+                   for d in site["expertPredictions"]]
+        e0.append(records[0]); e1.append(records[1]); e2.append(records[2])          # noqa: E702
+        best.append(records[int(np.argmax(site["meta"]))])
+        mean_dict = mean_of_experts(site["expertPredictions"], site["meta"])
+        mean.append(call_alleles(mean_dict, site["chromosome"], site["position"], site["length"], genome))
+        choices.append("\t".join([site["chromosome"], str(site["position"]), str(site["position"] + site["length"]),
+                                  str(int(np.argmax(site["meta"])))]))
+    return e0, e1, e2, best, mean, choices

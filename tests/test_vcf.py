@@ -110,3 +110,33 @@ def test_ensemble_mean_rule():
     assert mean[("A", "T")] == pytest.approx(0.46)
     call = vcf.call_from_prediction((None, e[0], e[1], e[2], meta), "c", 0, 1, "ACGT")
     assert call.genotype == (0, 1) and call.line() == vo.call_alleles(mean, "c", 0, 1, "ACGT")
+
+
+def test_features_records_round_trip_and_shard_calls_match_oracle(tmp_path):
+    """The .features schema (caller_calling.py:743-754,895-898) and prepareVcf's use of it (:126-176)."""
+    import pickle
+    rng = random.Random(11)
+    genomes = {"chr1": "".join(rng.choice("ACGT") for _ in range(300)), "chr2": "".join(rng.choice("ACGT") for _ in range(300))}
+    records = []
+    for i in range(60):
+        chrom = rng.choice(sorted(genomes))
+        start = rng.randrange(5, 280)
+        ref = genomes[chrom][start]
+        alleles = [ref] + rng.sample([b for b in "ACGT" if b != ref], rng.choice([0, 1, 2])) + rng.choice([[], [ref + "G"]])
+        pairs = [(alleles[a], alleles[b]) for a in range(len(alleles)) for b in range(a, len(alleles))]
+        experts = [dict(zip(pairs, np.random.default_rng(100 * i + k).dirichlet(np.ones(len(pairs)) * 0.4).astype(np.float32)))
+                   for k in range(3)]
+        meta = np.random.default_rng(i).dirichlet(np.ones(3)).astype(np.float32)
+        rec = vcf.feature_record((None, experts[0], experts[1], experts[2], meta), chrom, start, 1)
+        assert set(rec) == {"chromosome", "position", "length", "meta", "expertPredictions"}
+        assert rec["meta"].dtype == np.float32 and all(isinstance(v, float) for v in rec["expertPredictions"][2].values())
+        records.append(rec)
+    path = vcf.write_features(str(tmp_path / "shard0.features"), records)
+    loaded = pickle.load(open(path, "rb"))                           # what prepareVcf.py:125 does
+    got = vcf.calls_from_features(loaded, genomes)
+    want = vo.prepare_shard(loaded, genomes)
+    line = lambda c: None if c is None else c.line()                 # noqa: E731
+    for g, w in zip(list(got.expert) + [got.best, got.mean], want[:5]):
+        assert [line(c) for c in g] == w
+    assert ["\t".join(map(str, row)) for row in got.choices] == want[5]
+    assert sum(c is not None for c in got.mean) > 30
