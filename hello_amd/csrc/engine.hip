@@ -328,8 +328,10 @@ int hello_engine_op_times_ms(hello_engine* e, float* ms_sum, int32_t capacity, i
 static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32_t* rpa1,
                                const int32_t* aps, int32_t S, int32_t A, int64_t R0, int64_t R1,
                                bool two_tech, hipStream_t stream) {
-    const int G = hello::readconv_reads_per_group();
-    const int64_t n_groups0 = (R0 + G - 1) / G, n_groups1 = two_tech ? (R1 + G - 1) / G : 0;
+    // reads one workgroup of the fused read convolver walks (per technology: it depends on the batch size)
+    const int GW0 = hello::readconv_reads_per_group() * hello::readconv_groups_per_workgroup(R0);
+    const int GW1 = hello::readconv_reads_per_group() * hello::readconv_groups_per_workgroup(R1);
+    const int64_t n_groups0 = (R0 + GW0 - 1) / GW0, n_groups1 = two_tech ? (R1 + GW1 - 1) / GW1 : 0;
     size_t bytes = 0;
     auto add = [&](size_t count, size_t elem) { bytes += (count * elem + 15) & ~size_t(15); };
     add(A + 1, 4); add(A + 1, 4); add(S + 1, 4); add(A, 4);          // roff0 roff1 aoff site_of_allele
@@ -361,7 +363,7 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
     int64_t* h_poff = carve<int64_t>(hc, S + 1);
 
     auto build_reads = [&](const int32_t* rpa, int64_t R, int32_t* roff, int32_t* aor, int32_t* gslot,
-                           int32_t* soff, int64_t n_groups, const char* which) -> int {
+                           int32_t* soff, int64_t n_groups, int G, const char* which) -> int {
         int64_t acc = 0;
         for (int32_t a = 0; a < A; ++a) {
             if (rpa[a] <= 0)
@@ -377,8 +379,9 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
         roff[A] = (int32_t)acc;
         if (acc != R)
             return fail(HELLO_ERR_SHAPE, "sum(%s) = %lld != n_reads = %lld", which, (long long)acc, (long long)R);
-        // partial-sum slots of the fused read convolver: one slot per (read group, allele) incidence,
-        // numbered in (group, allele) order == (allele, group) order because both are monotone in the read index
+        // partial-sum slots of the fused read convolver: one slot per (workgroup, allele) incidence (G = reads
+        // per workgroup), numbered in (workgroup, allele) order == (allele, workgroup) order because both are
+        // monotone in the read index
         int64_t slot = 0;
         int32_t a_lo = 0;
         // slot_off[a] = first slot of allele a; group_slot[g] = first slot of group g
@@ -402,9 +405,9 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
         if (s != slot) return fail(HELLO_ERR_ARG, "internal: slot accounting mismatch");
         return 0;
     };
-    if (int rc = build_reads(rpa0, R0, h_roff0, h_aor0, h_gs0, h_so0, n_groups0, "reads_per_allele0")) return rc;
+    if (int rc = build_reads(rpa0, R0, h_roff0, h_aor0, h_gs0, h_so0, n_groups0, GW0, "reads_per_allele0")) return rc;
     if (two_tech) {
-        if (int rc = build_reads(rpa1, R1, h_roff1, h_aor1, h_gs1, h_so1, n_groups1, "reads_per_allele1")) return rc;
+        if (int rc = build_reads(rpa1, R1, h_roff1, h_aor1, h_gs1, h_so1, n_groups1, GW1, "reads_per_allele1")) return rc;
     } else {
         h_gs1[0] = 0;
     }
@@ -628,6 +631,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.allele_of_read = t1 ? e->allele_of_read1 : e->allele_of_read0;
                 a.slot_of_group = t1 ? e->group_slot1 : e->group_slot0;
                 a.n_reads = t1 ? R1 : R0;
+                a.groups_per_wg = hello::readconv_groups_per_workgroup(a.n_reads);
                 a.extra_blocks = o.k;
                 a.winograd = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
                 if ((size_t)o.w_off + hello::readconv_weight_floats(o.k, a.winograd) > e->n_weight_floats)

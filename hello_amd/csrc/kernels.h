@@ -61,14 +61,16 @@ struct ReadConvArgs {
     const float* pooled;       // [R][71][32] output of a layer-by-layer stem (3 valid convs + MaxPool1d(3,2))
     int channels;              // 6 | 7 (only with `reads`)
     const float* w;            // packed block, see hello_amd/readconv_pack.py
-    float* partial;            // [n_slots][36][64]: one slot per (read group, allele) incidence
+    float* partial;            // [n_slots][36][64]: one slot per (workgroup, allele) incidence
     const int32_t* allele_of_read;   // [R]
-    const int32_t* slot_of_group;    // [n_groups + 1] first partial slot of each read group
+    const int32_t* slot_of_group;    // [n_workgroups + 1] first partial slot of each workgroup
+    int groups_per_wg;         // consecutive groups of readconv_reads_per_group() reads one workgroup walks
     long long n_reads;
     int extra_blocks;          // identity-shortcut 64-channel blocks after the canonical three: 0 | 2
     int winograd;              // residual-block convolutions in Winograd F(2,3) form (weights packed accordingly)
 };
 int readconv_reads_per_group();
+int readconv_groups_per_workgroup(long long n_reads);
 int readconv_weight_floats(int extra_blocks, bool winograd);
 bool readconv_supports_extra_blocks(int extra_blocks);
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);

@@ -112,6 +112,13 @@ bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0
 
 using Geometry = rc::Cfg<4, 4>;    // 4 reads x 4 waves per workgroup, two workgroups per CU
 int readconv_reads_per_group() { return Geometry::G; }
+// Groups a workgroup walks: enough to cut the partial-sum slots several-fold on a large batch, never so many
+// that a small batch no longer fills the chip (>= 2048 workgroups wherever the batch allows it)
+int readconv_groups_per_workgroup(long long n_reads) {
+    const long long groups = (n_reads + Geometry::G - 1) / Geometry::G;
+    const long long n = groups / 2048;
+    return n < 1 ? 1 : (n > 8 ? 8 : (int)n);
+}
 
 // chunk swizzles: 16-byte chunk index of a row XORed with a function of the row
 template <int C>
@@ -658,19 +665,16 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     float* dump = smem + 2 * BUF_FLOATS + 12;                 // 16 spare bytes of the same 64-byte block
     unsigned char* s_u8 = (unsigned char*)(smem + 2 * BUF_FLOATS + 16);
 
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int j = lane & 15;
-    const long long read0 = (long long)blockIdx.x * G;
-    const int n_here = (int)((a.n_reads - read0) < G ? (a.n_reads - read0) : G);
+    const int tid0 = threadIdx.x;
+    const int wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const float* __restrict__ W = a.w;
 
     // which of a lane's rows are shared zero rows: bit k = the wave's k-th tile, per image geometry
     unsigned pad1 = 0, pad1f = 0;                             // pad1f: the same for a FLIPped Winograd layer
     const unsigned pad2 = 0;                                  // the 64-channel images hold no zero rows between reads
     {
-        const int pg1 = wave / 2;                              // 32-channel layers: 2 blocks x 2 position groups
+        const int j = tid0 & 15;
+        const int pg1 = wave0 / 2;                             // 32-channel layers: 2 blocks x 2 position groups
         if (WINO) {                                            // tile = 16 pairs of rows; the odd row of pair P = 35 mod 36
 #pragma unroll
             for (int k = 0; k < (T1 / 2 + 1) / 2; ++k) {
@@ -690,7 +694,40 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     f32x4 wA[NVA], wB[NVB], w2[2];
     f32x4 (&w6)[6] = reinterpret_cast<f32x4 (&)[6]>(wA);       // the direct-form views of the same registers
     f32x4 (&w12)[12] = reinterpret_cast<f32x4 (&)[12]>(wB);
+
+    // A workgroup walks `groups_per_wg` consecutive groups of G reads and carries the running per-allele sum
+    // of its reads in registers across them: a partial slot is written only when the allele changes (or at
+    // the workgroup's end), i.e. one slot per (workgroup, allele) incidence instead of per (group, allele).
+    const long long wg_read0 = (long long)blockIdx.x * G * a.groups_per_wg;
+    const int slot0 = a.slot_of_group[blockIdx.x];
+    const int first_allele = a.allele_of_read[wg_read0];
+    int cur = first_allele;                                   // allele whose reads `carry` holds (uniform)
+    constexpr int NF = (L2 * 16 + THREADS - 1) / THREADS;     // float4 elements of a [36][64] frame per thread
+    f32x4 carry[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) carry[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto flush = [&]() {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = tid0 + THREADS * i;
+            if (f < L2 * 16)
+                *(f32x4*)(a.partial + ((long long)(slot0 + cur - first_allele) * L2 + (f >> 4)) * 64 + 4 * (f & 15)) = carry[i];
+            carry[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    for (int grp = 0; grp < a.groups_per_wg; ++grp) {
+    // Every per-lane address of the body derives from these three; an opaque zero ties them to the iteration, so
+    // the compiler recomputes them per group instead of keeping every layer's pointers alive across the loop
+    int opaque_zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
+    const int tid = tid0 + opaque_zero;
+    const int wave = __builtin_amdgcn_readfirstlane(wave0 + opaque_zero);
+    const int lane = tid & 63;
     const int cb2 = wave % 2, cb4 = wave;
+    const long long read0 = wg_read0 + (long long)grp * G;
+    if (read0 >= a.n_reads) break;                            // uniform: the last workgroup may hold fewer groups
+    const int n_here = (int)((a.n_reads - read0) < G ? (a.n_reads - read0) : G);
     load_weights<NVA>(wA, W + OFF_B, cb2, lane);    // first trunk layer: requested before anything else waits
     if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
     if (STEM) {
@@ -829,29 +866,26 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         __syncthreads();
     }
 
-    // ---- per-allele sums of the group's reads, in read order; one slot per (group, allele) ---------
-    {
-        const int slot0 = a.slot_of_group[blockIdx.x];
-        const int first_allele = s_allele[0];
-        for (int f = tid; f < L2 * 16; f += THREADS) {
-            const int p = f >> 4, c = f & 15;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            int cur = first_allele;
-            for (int rd = 0; rd < n_here; ++rd) {
-                const int al = s_allele[rd];
-                if (al != cur) {
-                    *(f32x4*)(a.partial + ((long long)(slot0 + cur - first_allele) * L2 + p) * 64 + 4 * c) = acc;
-                    acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    cur = al;
-                }
-                const int row = 1 + rd * RS2 + p;
-                const f32x4 v = *(const f32x4*)(X + img_off<64, SWX>(row, c));
+    // ---- the group's reads join the running per-allele sum, in read order ---------------------------
+    for (int rd = 0; rd < n_here; ++rd) {
+        const int al = s_allele[rd];
+        if (al != cur) {                                      // uniform
+            flush();
+            cur = al;
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        for (int i = 0; i < NF; ++i) {
+            const int f = tid + THREADS * i;
+            if (f < L2 * 16) {
+                const f32x4 v = *(const f32x4*)(X + img_off<64, SWX>(1 + rd * RS2 + (f >> 4), f & 15));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) carry[i][e] += v[e];
             }
-            *(f32x4*)(a.partial + ((long long)(slot0 + cur - first_allele) * L2 + p) * 64 + 4 * c) = acc;
         }
     }
+    __syncthreads();                                          // the next group's stem overwrites the images
+    }   // groups of this workgroup
+    flush();
 }
 
 template <class CF, int NB64, bool WINO>
@@ -866,7 +900,9 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         configured = true;
     }
-    const unsigned groups = (unsigned)((a.n_reads + CF::G - 1) / CF::G);
+    const long long per_wg = (long long)CF::G * a.groups_per_wg;
+    const unsigned groups = (unsigned)((a.n_reads + per_wg - 1) / per_wg);       // workgroups
+    if (a.groups_per_wg < 1) return hipErrorInvalidValue;
     if (a.reads) {
         if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
         hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
