@@ -419,11 +419,22 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
     f32x4 acc[2][4];                                                         // accumulator sets of even / odd tiles
     f32x4 res0 = zero4, res1 = zero4, y0 = zero4, y1 = zero4;
     constexpr int NU = ITER * M;
+    // At 64 channels the reads are stacked without zero rows: the row before a read's first and the row after
+    // its last must read as zero.  The one lane of a tile that sits on such a boundary fetches its d0 (d3) from
+    // the image's leading zero row instead: one address select per read instead of four value selects.
+    const float* const zrow = in + 4 * q;
     auto issue = [&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int k = u / M, m = u % M;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ring[u & 1][i] = *(const f32x4*)(opb[(i / 2) * M + m] + (i & 1) * ODD + k * TOFF);
+        constexpr int lo = ((16 * k + 17) / 18) * 18;            // first pair >= 16 k that starts a read
+        constexpr int hi = ((16 * k + 18) / 18) * 18 - 1;        // first pair >= 16 k that ends a read
+        static_for<0, 4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const float* ptr = opb[(i / 2) * M + m] + (i & 1) * ODD + k * TOFF;
+            if constexpr (C == 64 && i == 0 && lo > 0 && lo <= 16 * k + 15) ptr = (j == lo - 16 * k) ? zrow : ptr;
+            if constexpr (C == 64 && i == 3 && hi <= 16 * k + 15 && hi < PAIRS - 1) ptr = (j == hi - 16 * k) ? zrow : ptr;
+            ring[u & 1][i] = *(const f32x4*)ptr;
+        });
     };
     // output transform, bias, ReLU, residual of element e of tile kk (its accumulators are complete)
     auto epi_store = [&](auto kc) {
@@ -470,14 +481,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
         // the previous tile's epilogue: one block of VALU work + two stores ahead of this step's MFMAs
         if constexpr (pending) epi_store(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
         if (!tail || last_tile_here) {
-            f32x4 d0 = ring[u & 1][0], d1 = ring[u & 1][1], d2 = ring[u & 1][2], d3 = ring[u & 1][3];
-            if constexpr (C == 64) {
-                // reads are stacked without zero rows: the row before a read's first and after its last is zero
-                constexpr int lo = ((16 * k + 17) / 18) * 18;                // first pair >= 16 k that starts a read
-                constexpr int hi = ((16 * k + 18) / 18) * 18 - 1;            // first pair >= 16 k that ends a read
-                if constexpr (lo > 0 && lo <= 16 * k + 15) d0 = (j == lo - 16 * k) ? zero4 : d0;
-                if constexpr (hi <= 16 * k + 15 && hi < PAIRS - 1) d3 = (j == hi - 16 * k) ? zero4 : d3;
-            }
+            const f32x4 d0 = ring[u & 1][0], d1 = ring[u & 1][1], d2 = ring[u & 1][2], d3 = ring[u & 1][3];
             f32x4(&a)[4] = acc[k & 1];
             // The input transform runs as ONE block of (packed) VALU operations ahead of the step's MFMAs: VALU
             // and MFMA instructions share the SIMD's issue port, and a VALU operation in front of every MFMA
