@@ -441,8 +441,8 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
         constexpr int kk = decltype(kc)::value;
         {
             const f32x4(&a)[4] = acc[kk & 1];
-            y0 = ((a[0] + a[1]) + a[2]) + b4;
-            y1 = ((a[1] - a[2]) - a[3]) + b4;
+            y0 = (a[0] + a[1]) + a[2];               // the bias rides in a[1]: its chain started from b4
+            y1 = (a[1] - a[2]) - a[3];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 y0[e] = fmaxf(y0[e], 0.f);
@@ -493,7 +493,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
             for (int e = 0; e < 4; ++e) {
                 const bool first = (m == 0) && (e == 0);
                 a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0 * M + m][e], t0[e], first ? zero4 : a[0], 0, 0, 0);
-                a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1 * M + m][e], t1[e], first ? zero4 : a[1], 0, 0, 0);
+                a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1 * M + m][e], t1[e], first ? b4 : a[1], 0, 0, 0);
                 a[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * M + m][e], t2[e], first ? zero4 : a[2], 0, 0, 0);
                 a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3 * M + m][e], t3[e], first ? zero4 : a[3], 0, 0, 0);
             }
