@@ -112,12 +112,30 @@ bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0
 
 using Geometry = rc::Cfg<4, 4>;    // 4 reads x 4 waves per workgroup, two workgroups per CU
 int readconv_reads_per_group() { return Geometry::G; }
-// Groups a workgroup walks: enough to cut the partial-sum slots several-fold on a large batch, never so many
-// that a small batch no longer fills the chip (>= 2048 workgroups wherever the batch allows it)
+// Groups a workgroup walks.  More groups per workgroup = fewer partial-sum slots and one prologue per several
+// groups (measured 1.2 %), but fewer, longer workgroups = a coarser tail when the last wave of workgroups does
+// not fill the chip (two workgroups per CU run at a time).  Pick the count in 1..8 that minimises
+// ceil(workgroups / resident slots) x groups, largest count on ties.
 int readconv_groups_per_workgroup(long long n_reads) {
+    static const long long slots = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return 2LL * cus;
+    }();
     const long long groups = (n_reads + Geometry::G - 1) / Geometry::G;
-    const long long n = groups / 2048;
-    return n < 1 ? 1 : (n > 8 ? 8 : (int)n);
+    int best = 1;
+    double best_cost = 1e300;
+    for (int n = 1; n <= 8; ++n) {
+        const long long wgs = (groups + n - 1) / n;
+        const double cost = (double)((wgs + slots - 1) / slots) * n * (n > 1 ? 0.988 : 1.0);
+        if (cost <= best_cost) {
+            best_cost = cost;
+            best = n;
+        }
+    }
+    return best;
 }
 
 // chunk swizzles: 16-byte chunk index of a row XORed with a function of the row
