@@ -206,11 +206,12 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
 enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3 };
 enum { GEOM_TRUNK = 0, GEOM_STEM = 1, GEOM_WPAIR = 2 };   // WPAIR: tile 2t / 2t+1 = even / odd rows of the pairs of Winograd tile t
 
-// value of lane+n of the same 16-lane row (DPP row_shl); lanes shifted in from outside keep their own value
+// value of lane+n of the same 16-lane row (DPP row_shl); lanes whose source falls outside the row read 0
+// (bound_ctrl: no preload of the destination, and the shift can fold into the consuming instruction)
 __device__ __forceinline__ float row_shl(float v, int n) {
     const int vi = __float_as_int(v);
-    return __int_as_float(n == 1 ? __builtin_amdgcn_update_dpp(vi, vi, 0x101, 0xf, 0xf, false)
-                                 : __builtin_amdgcn_update_dpp(vi, vi, 0x102, 0xf, 0xf, false));
+    return __int_as_float(n == 1 ? __builtin_amdgcn_update_dpp(0, vi, 0x101, 0xf, 0xf, true)
+                                 : __builtin_amdgcn_update_dpp(0, vi, 0x102, 0xf, 0xf, true));
 }
 
 // One convolution over the whole group.  `in`/`out` are LDS images with CIN / COUT floats per row.
@@ -594,7 +595,7 @@ __device__ __forceinline__ void stem_conv1(const unsigned char* __restrict__ s_u
 // the three operand reads of a tile feed 24 MFMAs (4 chains), and one output-row computation serves both
 // blocks.  Everything a tile adds to the lane's addresses is a compile-time constant: the 16-channel image's
 // swizzle bit depends on (row + c) mod 8 only, so 8 per-lane base pointers cover every (tile, tap).
-// Bias and ReLU are applied AFTER the max: x -> fl(x + b) and ReLU are monotone, so the bits are the same.
+// The bias starts one accumulation chain and ReLU is applied AFTER the max (monotone, so the same value).
 template <class CF, int SOUT>
 __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, float* __restrict__ out,
                                                 const float* __restrict__ W3, float* __restrict__ dump, int wave,
@@ -635,12 +636,12 @@ __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, fl
         const bool ok = lane_ok && (7 * tt + 6 < rc::L1 || (j >> 1) < rc::L1 - 7 * tt);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            const f32x4 sum = acc[tt & 1][blk][0] + acc[tt & 1][blk][1];
+            const f32x4 sum = acc[tt & 1][blk][0] + acc[tt & 1][blk][1];      // bias included: chain 0 started from b4
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float m = fmaxf(fmaxf(sum[e], row_shl(sum[e], 1)), row_shl(sum[e], 2));
-                v[e] = fmaxf(m + b4[blk][e], 0.f);
+                // lanes 14 / 15 of a row see zeros shifted in; their results are never stored (even lanes <= 12 are)
+                v[e] = fmaxf(fmaxf(fmaxf(sum[e], row_shl(sum[e], 1)), row_shl(sum[e], 2)), 0.f);
             }
             float* ptr = out + img_off<32, SOUT>(row, 4 * blk + q);
             *(f32x4*)(ok ? ptr : dump) = v;
@@ -662,7 +663,7 @@ __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, fl
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
                     acc[tt & 1][blk][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                        w[blk][tap][e], x[e], first ? zero4 : acc[tt & 1][blk][e & 1], 0, 0, 0);
+                        w[blk][tap][e], x[e], first ? (e == 0 ? b4[blk] : zero4) : acc[tt & 1][blk][e & 1], 0, 0, 0);
             }
         }
     });
