@@ -22,7 +22,7 @@
 //           -> bias / ReLU / residual / store are float4.  k is ordered so that lane-quarter q supplies
 //           channels 16m+4q+t at step (tap, m, t) for BOTH operands: one ds_read_b128 feeds four MFMAs.
 //   form    WINO (default): the k=3 / stride-1 / pad-1 convolutions of the residual blocks (13 of the 18
-//           convs, 96 % of the MACs outside the stem) run in Winograd F(2,3) form, 4 instead of 6 channel
+//           convs, 94 % of the MACs outside the stem) run in Winograd F(2,3) form, 4 instead of 6 channel
 //           contractions per pair of positions: wino_layer.  Everything else, and the whole kernel with
 //           WINO = false, runs the direct form: conv_layer (tile pairs, two accumulation chains per tile,
 //           operands two steps ahead, deferred epilogue).
