@@ -316,25 +316,31 @@ class _Lowering:
         x = self.input(buf, dom, spec.window, cin)
         from . import readconv_pack
         extras = _canonical_read_convolver_extras(nodes, cin)
-        if (self.fused and readconv_pack.AVAILABLE and spec.window == 150
-                and extras in readconv_pack.EXTRA_BLOCKS):
-            y = self.new(ROWS_ALLELES, 36, 64)
+        fusable = (self.fused and readconv_pack.AVAILABLE and extras in readconv_pack.EXTRA_BLOCKS
+                   and spec.window in readconv_pack.WINDOWS)
+        if fusable and spec.window != 150:
+            # the 250 bp geometry exists as the whole kernel (stem included) in Winograd form only
+            fusable = self.fused is True and self.winograd and extras == 0
+        if fusable:
+            _, l1, _, l2, _, _ = readconv_pack.geometry(spec.window)
+            y = self.new(ROWS_ALLELES, l2, 64)
             w_off = self.blob.add(readconv_pack.pack(nodes, self.folded, cin, winograd=self.winograd))
             wflag = FLAG_WINOGRAD if self.winograd else 0
             if self.fused == "trunk":
                 # stem layer by layer (3 valid convs + max pool), fused residual trunk + segment sum
                 pooled = self.net(nodes[:readconv_pack.TRUNK_FIRST_NODE], x)
-                assert (pooled.length, pooled.channels) == (71, 32)
+                assert (pooled.length, pooled.channels) == (l1, 32)
                 self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=pooled.vid, dst=y.vid, cin=32, cout=64,
-                                   k=extras, lin=71, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name + ".trunk",
+                                   k=extras, lin=l1, lout=l2, seg=seg, w_off=w_off, b_off=w_off, name=name + ".trunk",
                                    flags=wflag,
-                                   macs_per_row=ns.macs(nodes[readconv_pack.TRUNK_FIRST_NODE:], 71)))
+                                   macs_per_row=ns.macs(nodes[readconv_pack.TRUNK_FIRST_NODE:], l1)))
             else:
                 # the whole read convolver (stem included) + segment sum in one kernel, straight from the bytes
                 self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=buf, dst=y.vid, cin=cin, cout=64,
-                                   k=extras, lin=150, lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name,
-                                   flags=FLAG_SRC_U8 | wflag, macs_per_row=ns.macs(nodes, 150),
-                                   exec_macs_per_row=readconv_pack.executed_macs_per_read(self.winograd, extras)))
+                                   k=extras, lin=spec.window, lout=l2, seg=seg, w_off=w_off, b_off=w_off, name=name,
+                                   flags=FLAG_SRC_U8 | wflag, macs_per_row=ns.macs(nodes, spec.window),
+                                   exec_macs_per_row=readconv_pack.executed_macs_per_read(self.winograd, extras,
+                                                                                          spec.window)))
             self.used_fused = True
             return y
         return self.segsum(self.net(nodes, x), seg)

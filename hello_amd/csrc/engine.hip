@@ -166,6 +166,16 @@ int validate_model(const hello_model_desc* d) {
               o.cin % 8 == 0 && o.cout % 64 == 0))
             return fail(HELLO_ERR_MODEL, "op %d: this convolution has no Winograd form (needs k 3, stride 1, pad 1, "
                                          "cin %% 8 == 0, cout %% 64 == 0, float input)", i);
+        if (o.kind == HELLO_OP_READCONV_FUSED) {
+            if (!hello::readconv_supports_window(d->window))
+                return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver takes 150 or 250 bp windows, not %d", i, d->window);
+            if (o.lout != hello::readconv_frame_rows(d->window) || o.cout != 64)
+                return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver yields [%d][64] frames", i,
+                            hello::readconv_frame_rows(d->window));
+            if (d->window == 250 && !((o.flags & HELLO_FLAG_WINOGRAD) && (o.flags & HELLO_FLAG_SRC_U8) && o.k == 0))
+                return fail(HELLO_ERR_MODEL, "op %d: 250 bp windows run whole (from the bytes), in Winograd form, "
+                                             "without extra blocks", i);
+        }
         if (o.kind == HELLO_OP_READCONV_FUSED && !hello::readconv_supports_extra_blocks(o.k))
             return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver takes 0 or 2 extra blocks (k), got %d", i, o.k);
     }
@@ -329,8 +339,9 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
                                const int32_t* aps, int32_t S, int32_t A, int64_t R0, int64_t R1,
                                bool two_tech, hipStream_t stream) {
     // reads one workgroup of the fused read convolver walks (per technology: it depends on the batch size)
-    const int GW0 = hello::readconv_reads_per_group() * hello::readconv_groups_per_workgroup(R0);
-    const int GW1 = hello::readconv_reads_per_group() * hello::readconv_groups_per_workgroup(R1);
+    const int win = hello::readconv_supports_window(e->desc.window) ? e->desc.window : 150;
+    const int GW0 = hello::readconv_reads_per_group(win) * hello::readconv_groups_per_workgroup(R0, win);
+    const int GW1 = hello::readconv_reads_per_group(win) * hello::readconv_groups_per_workgroup(R1, win);
     const int64_t n_groups0 = (R0 + GW0 - 1) / GW0, n_groups1 = two_tech ? (R1 + GW1 - 1) / GW1 : 0;
     size_t bytes = 0;
     auto add = [&](size_t count, size_t elem) { bytes += (count * elem + 15) & ~size_t(15); };
@@ -531,10 +542,10 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     bool has_fused = false;
     for (const hello_op& o : e->ops) has_fused |= (o.kind == HELLO_OP_READCONV_FUSED);
     if (has_fused) {
-        const int G = hello::readconv_reads_per_group();
+        const int G = hello::readconv_reads_per_group(d.window);
         const int64_t Rmax = R0 > R1 ? R0 : R1;
         const size_t slots = (size_t)A + (size_t)((Rmax + G - 1) / G) + 1;
-        if (int rc = ensure(e->d_partial, slots * 36 * 64 * sizeof(float))) return rc;
+        if (int rc = ensure(e->d_partial, slots * hello::readconv_frame_rows(d.window) * 64 * sizeof(float))) return rc;
     }
     // experts without a head (ensemble of two: third expert is all-zero logits, :244) stay zero
     if (d.n_experts == 3) HIP_TRY(hipMemsetAsync(d_logits, 0, logit_bytes, stream));
@@ -631,14 +642,15 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.allele_of_read = t1 ? e->allele_of_read1 : e->allele_of_read0;
                 a.slot_of_group = t1 ? e->group_slot1 : e->group_slot0;
                 a.n_reads = t1 ? R1 : R0;
-                a.groups_per_wg = hello::readconv_groups_per_workgroup(a.n_reads);
+                a.window = d.window;
+                a.groups_per_wg = hello::readconv_groups_per_workgroup(a.n_reads, d.window);
                 a.extra_blocks = o.k;
                 a.winograd = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
                 if ((size_t)o.w_off + hello::readconv_weight_floats(o.k, a.winograd) > e->n_weight_floats)
                     return fail(HELLO_ERR_MODEL, "op %d: fused read-convolver weight block truncated", op_index);
                 HIP_TRY(hello::launch_readconv_fused(a, stream));
                 HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,
-                                                        (float*)ptr(o.dst), A, stream));
+                                                        (float*)ptr(o.dst), A, hello::readconv_frame_rows(d.window), stream));
                 break;
             }
         }

@@ -68,15 +68,18 @@ struct ReadConvArgs {
     long long n_reads;
     int extra_blocks;          // identity-shortcut 64-channel blocks after the canonical three: 0 | 2
     int winograd;              // residual-block convolutions in Winograd F(2,3) form (weights packed accordingly)
+    int window;                // pileup window: 150 | 250 (250: `reads` + Winograd form only)
 };
-int readconv_reads_per_group();
-int readconv_groups_per_workgroup(long long n_reads);
+bool readconv_supports_window(int window);
+int readconv_reads_per_group(int window);
+int readconv_frame_rows(int window);       // positions per read after the read convolver: 36 | 61
+int readconv_groups_per_workgroup(long long n_reads, int window);
 int readconv_weight_floats(int extra_blocks, bool winograd);
 bool readconv_supports_extra_blocks(int extra_blocks);
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
 // frames[a] = sum of the partial slots of allele a, in slot order
-hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames,
-                                    int n_alleles, hipStream_t stream);
+hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames, int n_alleles,
+                                    int frame_rows, hipStream_t stream);
 
 // ---- pileup-tensor producer (featurize.hip) ----------------------------------------------------------
 struct FeaturizeArgs {

@@ -46,10 +46,6 @@ namespace hello {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace rc {
-constexpr int L1 = 71, RS1 = 72;     // positions / row stride per read at 32 channels
-constexpr int L2 = 36, RS2 = 36;     // ... at 64 channels: reads stacked WITHOUT zero rows between them, so the
-                                     // 36*G rows tile exactly; the taps that would cross a read boundary are
-                                     // zeroed in registers instead (BMASK)
 
 // packed weight block (floats): per conv [COUT/16][KT][CIN/16][64 lanes][4], then bias [COUT].  With WINO the
 // convolutions of the identity-shortcut residual blocks are stored in their Winograd F(2,3) form: KT = 4
@@ -79,17 +75,30 @@ struct Offs {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int G_, int NW_>
+// Geometry of a pileup window of WIN_ positions (150 in every shipped model, 250 in the feature-map variant):
+//   window -> 3 valid k=3 convs (WIN-6) -> MaxPool(3,2): L1 -> strided block: L2
+template <int G_, int NW_, int WIN_ = 150>
 struct Cfg {
     static constexpr int G = G_;                       // reads per workgroup
     static constexpr int NW = NW_;                     // waves per workgroup
     static constexpr int THREADS = 64 * NW_;
+    static constexpr int WINDOW = WIN_;
+    static constexpr int L1 = (WIN_ - 6 - 3) / 2 + 1;  // positions per read at 32 channels (71 | 121)
+    static constexpr int RS1 = L1 + 1;                 // row stride: ONE shared zero row between reads (even)
+    static constexpr int L2 = (L1 - 1) / 2 + 1;        // positions per read at 64 channels (36 | 61)
+    // 64 channels: an even L2 stacks the reads WITHOUT rows between them (the taps that would cross a read
+    // boundary are zeroed at the source instead); an odd L2 takes one shared zero row, like the 32-channel image
+    static constexpr bool COMPACT = (L2 % 2) == 0;
+    static constexpr int RS2 = COMPACT ? L2 : L2 + 1;
+    static constexpr int NTT = (L1 + 6) / 7;           // stem pool tiles per read (7 pooled outputs each)
+    static constexpr int WPR = NW_ / G_;               // waves sharing a read in the stem pool
+    static_assert(RS1 % 2 == 0 && RS2 % 2 == 0 && NW_ % G_ == 0, "pairs of rows must not straddle reads");
     static constexpr int T1 = (RS1 * G_ + 15) / 16;    // position tiles at 32 channels
     static constexpr int T2 = (RS2 * G_ + 15) / 16;    // ... at 64 channels
     static constexpr int ROWS1 = RS1 * G_ + 1;         // rows of the 32-channel image (row 0 = leading zero row)
     static constexpr int ROWS2 = RS2 * G_ + 2;         // leading and trailing zero row
     static constexpr int SB = G_;                      // the stem runs over all reads of the group at once
-    static constexpr int SROWS = 150 * SB;
+    static constexpr int SROWS = WIN_ * SB;
     static constexpr int ST12 = ((SROWS + 15) / 16 + 3) / 4 * 4;   // tiles of stem conv1 / conv2 (4 position groups)
     static constexpr int BUF_FLOATS = cmax(cmax(ROWS2 * 64, ROWS1 * 32), SROWS * 16);
     static constexpr int U8_BYTES = ((ST12 * 16 + 8) * 7 + 15) / 16 * 16;   // every conv1 tile reads in bounds
@@ -110,13 +119,16 @@ int readconv_weight_floats(int extra_blocks, bool winograd) {
 }
 bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0 || extra_blocks == 2; }
 
-using Geometry = rc::Cfg<4, 4>;    // 4 reads x 4 waves per workgroup, two workgroups per CU
-int readconv_reads_per_group() { return Geometry::G; }
+using Geometry = rc::Cfg<4, 4, 150>;      // 4 reads x 4 waves per workgroup, two workgroups per CU
+using Geometry250 = rc::Cfg<2, 4, 250>;   // 250 bp windows: 2 reads per workgroup fill the same LDS
+bool readconv_supports_window(int window) { return window == 150 || window == 250; }
+int readconv_reads_per_group(int window) { return window == 250 ? Geometry250::G : Geometry::G; }
+int readconv_frame_rows(int window) { return window == 250 ? Geometry250::L2 : Geometry::L2; }
 // Groups a workgroup walks.  More groups per workgroup = fewer partial-sum slots and one prologue per several
 // groups (measured 1.2 %), but fewer, longer workgroups = a coarser tail when the last wave of workgroups does
 // not fill the chip (two workgroups per CU run at a time).  Pick the count in 1..8 that minimises
 // ceil(workgroups / resident slots) x groups, largest count on ties.
-int readconv_groups_per_workgroup(long long n_reads) {
+int readconv_groups_per_workgroup(long long n_reads, int window) {
     static const long long slots = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -124,7 +136,8 @@ int readconv_groups_per_workgroup(long long n_reads) {
             cus = 256;
         return 2LL * cus;
     }();
-    const long long groups = (n_reads + Geometry::G - 1) / Geometry::G;
+    const int G = readconv_reads_per_group(window);
+    const long long groups = (n_reads + G - 1) / G;
     int best = 1;
     double best_cost = 1e300;
     for (int n = 1; n <= 8; ++n) {
@@ -412,7 +425,9 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
     // MODE_ADD_REGS: the block's shortcut waits in `sreg` (GEOM_WPAIR layout: 2k = even rows, 2k+1 = odd rows)
     static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE || MODE == MODE_ADD_REGS, "block convolutions only");
     constexpr int M = C / 16, NCB = C / 16, NPG = CF::NW / NCB;
-    constexpr int PAIRS = (C == 64 ? rc::RS2 : rc::RS1) * CF::G / 2;       // 72 | 144 pairs of rows in the group
+    constexpr int PAIRS = (C == 64 ? CF::RS2 : CF::RS1) * CF::G / 2;       // 72 | 144 pairs of rows in the group
+    constexpr bool EDGE = (C == 64) && CF::COMPACT;                          // reads stacked without zero rows
+    constexpr int PPR = (C == 64 ? CF::RS2 : CF::RS1) / 2;                   // pairs per read
     constexpr int NT = (PAIRS + 15) / 16;                                    // 5 | 9 tiles
     constexpr int ITER = (NT + NPG - 1) / NPG;                               // tiles of position group 0
     constexpr int TOFF = NPG * 32 * C;                                       // floats between a wave's tiles
@@ -445,13 +460,13 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
     auto issue = [&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int k = u / M, m = u % M;
-        constexpr int lo = ((16 * k + 17) / 18) * 18;            // first pair >= 16 k that starts a read
-        constexpr int hi = ((16 * k + 18) / 18) * 18 - 1;        // first pair >= 16 k that ends a read
+        constexpr int lo = ((16 * k + PPR - 1) / PPR) * PPR;     // first pair >= 16 k that starts a read
+        constexpr int hi = ((16 * k + PPR) / PPR) * PPR - 1;     // first pair >= 16 k that ends a read
         static_for<0, 4>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const float* ptr = opb[(i / 2) * M + m] + (i & 1) * ODD + k * TOFF;
-            if constexpr (C == 64 && i == 0 && lo > 0 && lo <= 16 * k + 15) ptr = (j == lo - 16 * k) ? zrow : ptr;
-            if constexpr (C == 64 && i == 3 && hi <= 16 * k + 15 && hi < PAIRS - 1) ptr = (j == hi - 16 * k) ? zrow : ptr;
+            if constexpr (EDGE && i == 0 && lo > 0 && lo <= 16 * k + 15) ptr = (j == lo - 16 * k) ? zrow : ptr;
+            if constexpr (EDGE && i == 3 && hi <= 16 * k + 15 && hi < PAIRS - 1) ptr = (j == hi - 16 * k) ? zrow : ptr;
             ring[u & 1][i] = *(const f32x4*)ptr;
         });
     };
@@ -476,7 +491,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
                 y1 = y1 + sreg[2 * kk + 1];
             }
         }
-        if constexpr (C == 32) {
+        if constexpr (!EDGE) {
             if ((zmask >> kk) & 1u) y1 = zero4;                               // the shared zero row between reads
         }
         float* p0 = o0 + kk * TOFF;
@@ -589,7 +604,7 @@ __device__ __forceinline__ void stem_conv1(const unsigned char* __restrict__ s_u
 }
 
 // ---- stem conv3 (16 -> 32, valid) + ReLU + MaxPool1d(3, 2), one read per wave ------------------------------
-// A tile is 16 conv3 positions of ONE read, tiles 14 apart (11 per read): lane row j holds position 14 t + j, so
+// A tile is 16 conv3 positions of ONE read, tiles 14 apart (11 per 150 bp read): lane row j holds position 14 t + j, so
 // the pooled outputs 7 t .. 7 t + 6 = max over positions (2p, 2p+1, 2p+2) are two DPP row shifts away and only
 // pooled values reach LDS (image row 1 + read*72 + p).  The wave computes BOTH 16-channel blocks of its tiles:
 // the three operand reads of a tile feed 24 MFMAs (4 chains), and one output-row computation serves both
@@ -600,10 +615,11 @@ template <class CF, int SOUT>
 __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, float* __restrict__ out,
                                                 const float* __restrict__ W3, float* __restrict__ dump, int wave,
                                                 int lane, int n_here) {
-    static_assert(CF::NW == CF::G, "one read per wave");
-    constexpr int NTT = 11;                                   // ceil(71 / 7) tiles per read
+    constexpr int WPR = CF::WPR;                              // waves per read: wave (rd, half) takes tiles half + WPR k
+    constexpr int NTT = CF::NTT / WPR;                        // tiles of this wave
+    static_assert(CF::NTT % WPR == 0, "the pool tiles of a read must split evenly over its waves");
     const int j = lane & 15, q = lane >> 4;
-    const int rd = wave;
+    const int rd = wave / WPR, half = wave % WPR;
     f32x4 w[2][3];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
@@ -612,11 +628,11 @@ __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, fl
     f32x4 b4[2];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) b4[blk] = *(const f32x4*)(W3 + 2 * 3 * 256 + blk * 16 + 4 * q);
-    const int lrow = rd * 150 + j;
+    const int lrow = rd * CF::WINDOW + 14 * half + j;
     const float* pin[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) pin[k] = in + lrow * 16 + 4 * (q ^ (2 * (((lrow + k) >> 2) & 1)));
-    const int orow = 1 + rd * rc::RS1 + (j >> 1);
+    const int orow = 1 + rd * CF::RS1 + 7 * half + (j >> 1);   // pooled position 7 * (half + WPR k) + (j >> 1)
     const bool lane_ok = ((j & 1) == 0) && (j <= 12) && (rd < n_here);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -626,14 +642,14 @@ __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, fl
         constexpr int tt = decltype(tc)::value;
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
-            constexpr int c0 = 14 * tt;
+            constexpr int c0 = 14 * WPR * tt;
             ring[tt & 1][tap] = *(const f32x4*)(pin[(c0 + tap) & 7] + (c0 + tap) * 16);
         }
     };
     auto epilogue = [&](auto tc) {
         constexpr int tt = decltype(tc)::value;
-        const int row = orow + 7 * tt;
-        const bool ok = lane_ok && (7 * tt + 6 < rc::L1 || (j >> 1) < rc::L1 - 7 * tt);
+        const int row = orow + 7 * WPR * tt;
+        const bool ok = lane_ok && (row - 1 - rd * CF::RS1 < CF::L1);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const f32x4 sum = acc[tt & 1][blk][0] + acc[tt & 1][blk][1];      // bias included: chain 0 started from b4
@@ -674,6 +690,8 @@ template <class CF, bool STEM, int NB64, bool WINO>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
     using O = Offs<WINO>;
+    constexpr int L1 = CF::L1, RS1 = CF::RS1, L2 = CF::L2, RS2 = CF::RS2;
+    static_assert(CF::COMPACT || WINO, "the zero-row 64-channel geometry is implemented for the Winograd form only");
     constexpr int W3232 = O::W3232, W3264 = O::W3264, W3264S = O::W3264S, W6464 = O::W6464;
     constexpr int OFF_B = O::OFF_B, OFF_C1 = O::OFF_C1, OFF_SC = O::OFF_SC, OFF_C2 = O::OFF_C2;
     constexpr int OFF_S1 = O::OFF_S1, OFF_S2 = O::OFF_S2, OFF_S3 = O::OFF_S3;
@@ -694,7 +712,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
 
     // which of a lane's rows are shared zero rows: bit k = the wave's k-th tile, per image geometry
     unsigned pad1 = 0, pad1f = 0;                             // pad1f: the same for a FLIPped Winograd layer
-    const unsigned pad2 = 0;                                  // the 64-channel images hold no zero rows between reads
+    unsigned pad2 = 0, pad2w = 0;                             // 64 channels: direct 16-row tiles / Winograd tiles
+    if (!CF::COMPACT) {                                       // (a compact image holds no zero rows between reads)
+        const int j = tid0 & 15;
+#pragma unroll
+        for (int k = 0; k < T2; ++k) pad2 |= (((k * 16 + j) % RS2) >= L2 ? 1u : 0u) << k;
+#pragma unroll
+        for (int k = 0; k < (RS2 * G / 2 + 15) / 16; ++k) pad2w |= (((k * 16 + j) % (RS2 / 2)) == RS2 / 2 - 1 ? 1u : 0u) << k;
+    }
     {
         const int j = tid0 & 15;
         const int pg1 = wave0 / 2;                             // 32-channel layers: 2 blocks x 2 position groups
@@ -757,8 +782,8 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         // the stem, from the uint8 pileups: conv1 bytes -> bufB, conv2 bufB -> bufA, conv3 + max pool
         // bufA -> X (= bufB again, now as the 32-channel image)
         const int ch = a.channels;
-        const int n_bytes = n_here * 150 * ch;
-        const unsigned char* src = a.reads + read0 * 150 * ch;
+        const int n_bytes = n_here * CF::WINDOW * ch;
+        const unsigned char* src = a.reads + read0 * CF::WINDOW * ch;
         // The group's bytes in ONE round trip to memory: every thread requests all its dwords first and
         // stores them afterwards (a load-store loop would pay the memory latency once per iteration and
         // leave the workgroup memory-bound for longer than all its MFMAs take).
@@ -794,7 +819,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         __syncthreads();
         if (tid < 8 * (G + 1)) {                      // the image's shared zero rows: 0, 72, 144, ...
             const int row = (tid >> 3) * RS1;
-            *(f32x4*)(X + row * 32 + 4 * (tid & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(X + img_off<32, SWX>(row, tid & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};   // a whole row, chunk by chunk
         }
         stem_conv3_pool<CF, SWX>(bufA, X, W + OFF_S3, dump, wave, lane, n_here);
         __syncthreads();
@@ -855,7 +880,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     __syncthreads();
     if (tid < 32) ((f32x4*)X)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (WINO) {
-        wino_layer<CF, 64, MODE_ADD_REGS, true>(H, X, wB, slice(O::off_d(0), cb4, NVB), W + OFF_C2 + W6464, 0u, dump, wave,
+        wino_layer<CF, 64, MODE_ADD_REGS, true>(H, X, wB, slice(O::off_d(0), cb4, NVB), W + OFF_C2 + W6464, pad2w, dump, wave,
                                                 lane, sreg);
     } else {
         conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true, GEOM_TRUNK, 16, RS2 * CF::G, true, SWX, SWX>(
@@ -868,13 +893,13 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     for (int blk = 0; blk < NB64; ++blk) {
         const int off_a = O::off_d(blk), off_b = off_a + (W6464 + 64);
         if constexpr (WINO) {
-            wino_layer<CF, 64, MODE_PLAIN, true>(X, H, wB, slice(off_b, cb4, NVB), W + off_a + W6464, 0u, dump, wave, lane);
+            wino_layer<CF, 64, MODE_PLAIN, true>(X, H, wB, slice(off_b, cb4, NVB), W + off_a + W6464, pad2w, dump, wave, lane);
             __syncthreads();
             if (blk < NB64 - 1)
                 wino_layer<CF, 64, MODE_RESID_INPLACE, true>(H, X, wB, slice(O::off_d(blk + 1), cb4, NVB), W + off_b + W6464,
-                                                             0u, dump, wave, lane);
+                                                             pad2w, dump, wave, lane);
             else
-                wino_layer<CF, 64, MODE_RESID_INPLACE, false>(H, X, wB, nullptr, W + off_b + W6464, 0u, dump, wave, lane);
+                wino_layer<CF, 64, MODE_RESID_INPLACE, false>(H, X, wB, nullptr, W + off_b + W6464, pad2w, dump, wave, lane);
         } else {
             conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
                 X, H, w12, slice(off_b, cb4, 12), W + off_a + W6464, sreg, pad2, dump, wave, lane);
@@ -911,12 +936,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     flush();
 }
 
-template <class CF, int NB64, bool WINO>
+template <class CF, int NB64, bool WINO, bool STEM_ONLY = false>
 static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false, NB64, WINO>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
+        hipError_t e = hipSuccess;
+        if constexpr (!STEM_ONLY)
+            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false, NB64, WINO>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64, WINO>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
@@ -929,14 +956,21 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     if (a.reads) {
         if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
         hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
-    } else {
+    } else if constexpr (!STEM_ONLY) {
         hipLaunchKernelGGL((readconv_kernel<CF, false, NB64, WINO>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
+    } else {
+        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
     if (a.n_reads <= 0) return hipSuccess;
+    if (a.window == 250) {         // the feature-map variant: whole read convolver from the bytes, Winograd form
+        if (!a.reads || !a.winograd || a.extra_blocks != 0) return hipErrorInvalidValue;
+        return launch_cfg<Geometry250, 3, true, true>(a, stream);
+    }
+    if (a.window != 150) return hipErrorInvalidValue;
     if (a.extra_blocks == 0) return a.winograd ? launch_cfg<Geometry, 3, true>(a, stream) : launch_cfg<Geometry, 3, false>(a, stream);
     if (a.extra_blocks == 2) return a.winograd ? launch_cfg<Geometry, 5, true>(a, stream) : launch_cfg<Geometry, 5, false>(a, stream);
     return hipErrorInvalidValue;
@@ -944,24 +978,25 @@ hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
 
 // frames[a] = sum over the allele's partial slots, in slot (= read) order
 __global__ void readconv_finalize_kernel(const float* __restrict__ partial, const int32_t* __restrict__ slot_off,
-                                         float* __restrict__ frames) {
+                                         float* __restrict__ frames, int frame_f4) {      // frame_f4 = positions * 16
     const int al = blockIdx.x;
     const int lo = slot_off[al], hi = slot_off[al + 1];
-    for (int f = threadIdx.x; f < rc::L2 * 16; f += blockDim.x) {
-        f32x4 acc = *(const f32x4*)(partial + ((long long)lo * rc::L2 * 16 + f) * 4);
+    for (int f = threadIdx.x; f < frame_f4; f += blockDim.x) {
+        f32x4 acc = *(const f32x4*)(partial + ((long long)lo * frame_f4 + f) * 4);
         for (int s = lo + 1; s < hi; ++s) {
-            const f32x4 v = *(const f32x4*)(partial + ((long long)s * rc::L2 * 16 + f) * 4);
+            const f32x4 v = *(const f32x4*)(partial + ((long long)s * frame_f4 + f) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += v[e];
         }
-        *(f32x4*)(frames + ((long long)al * rc::L2 * 16 + f) * 4) = acc;
+        *(f32x4*)(frames + ((long long)al * frame_f4 + f) * 4) = acc;
     }
 }
 
 hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames, int n_alleles,
-                                    hipStream_t stream) {
+                                    int frame_rows, hipStream_t stream) {
     if (n_alleles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(readconv_finalize_kernel, dim3(n_alleles), dim3(192), 0, stream, partial, slot_off, frames);
+    hipLaunchKernelGGL(readconv_finalize_kernel, dim3(n_alleles), dim3(192), 0, stream, partial, slot_off, frames,
+                       frame_rows * 16);
     return hipGetLastError();
 }
 

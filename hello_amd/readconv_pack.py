@@ -55,19 +55,28 @@ def _pack_first_conv(w: np.ndarray, b: np.ndarray, steps: int = 6) -> np.ndarray
     return np.concatenate([packed.ravel(), b.astype(np.float32).ravel()])
 
 
-def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, reads_per_group: int = 4) -> float:
+WINDOWS = (150, 250)          # pileup windows the fused kernel is instantiated for (250: Winograd form, whole kernel)
+
+
+def geometry(window: int):
+    """(reads per group, L1, RS1, L2, RS2, pool tiles per read) of readconv_fused.hip's Cfg for ``window``."""
+    l1 = (window - 9) // 2 + 1
+    l2 = (l1 - 1) // 2 + 1
+    return (4 if window == 150 else 2), l1, l1 + 1, l2, (l2 if l2 % 2 == 0 else l2 + 1), (l1 + 6) // 7
+
+
+def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, window: int = 150) -> float:
     """MACs the fused kernel's MFMA instructions really execute per read (tile padding included), from its
     tile schedule in readconv_fused.hip: v_mfma_f32_16x16x4_f32 = 16*16*4 MACs.  Direct form: 5 052 MFMAs per
     wave and group of 4 reads; Winograd form: 3 948 on average (the residual blocks need 4 instead of 6
     contractions per pair of positions, minus what their half-empty last tile gives back)."""
-    g = reads_per_group
-    t_stem12 = -(-(-(-150 * g // 16)) // 4) * 4                  # 16-row tiles of conv1 / conv2, 4 position groups
-    t_stem3 = -(-(-(-150 * g // 14)) // 4) * 4                   # stride-14 tiles of conv3
-    stem = t_stem12 * 6 + t_stem12 * 3 * 4 + t_stem3 * 2 * 3 * 4
-    t1, t2 = -(-72 * g // 16), -(-36 * g // 16)                  # direct tiles at 32 / 64 channels
+    g, _, rs1, _, rs2, ntt = geometry(window)
+    t_stem12 = -(-(-(-window * g // 16)) // 4) * 4               # 16-row tiles of conv1 / conv2, 4 position groups
+    stem = t_stem12 * 6 + t_stem12 * 3 * 4 + g * ntt * 2 * 3 * 4  # conv3: `ntt` stride-14 tiles per read, 2 blocks
+    t1, t2 = -(-rs1 * g // 16), -(-rs2 * g // 16)                # direct tiles at 32 / 64 channels
     n64 = 6 + 2 * extra_blocks
     if winograd:
-        w1, w2 = -(-36 * g // 16), -(-18 * g // 16)              # tiles of 16 pairs
+        w1, w2 = -(-(rs1 // 2) * g // 16), -(-(rs2 // 2) * g // 16)   # tiles of 16 pairs
         strided = t2 * 4 * 6 * 4 + 2 * w2 * 4 * 2 * 4 + w2 * 4 * 4 * 16
         blocks = 6 * (w1 * 2 * 2 * 16) + n64 * (w2 * 4 * 4 * 16)
     else:

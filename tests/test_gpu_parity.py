@@ -73,6 +73,7 @@ def test_golden_posteriors(engines, name):
     ("hybrid_no_ensemble", dict(coverage=30, hybrid_coverage=15)),
     ("merged_hybrid", dict(coverage=25, hybrid_coverage=10)),
     ("single_tech_addendum", dict(coverage=30)),
+    ("merged_hybrid_250", dict(coverage=(1, 40), hybrid_coverage=7, window=250)),   # the 250 bp fused geometry, odd group tails
 ])
 def test_fresh_batches_match_oracle(engines, cfg, kw):
     from oracle import moe_oracle as mo

@@ -99,6 +99,17 @@ def test_canonical_models_use_the_fused_trunk_and_small_scratch():
         assert prog.weights.dtype == np.float32 and prog.weights.size % 4 == 0 or True
 
 
+def test_250bp_model_uses_the_fused_kernel_in_winograd_form_only():
+    spec = ns.build("merged_hybrid_250")
+    state = weights.synth_state(spec, seed=1)
+    prog = compiler.compile_model(spec, state)
+    fused = [o for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED]
+    assert len(fused) == 2 and all((o.lin, o.lout, o.k) == (250, 61, 0) for o in fused)
+    assert all(o.flags & compiler.FLAG_WINOGRAD and o.flags & compiler.FLAG_SRC_U8 for o in fused)
+    for kw in (dict(winograd=False), dict(fused="trunk"), dict(fused=False)):
+        assert not compiler.compile_model(spec, state, **kw).fused_read_convolver
+
+
 def test_wide_model_falls_back_to_layer_by_layer():
     spec = ns.build("hybrid_no_ensemble_wide")
     prog = compiler.compile_model(spec, weights.synth_state(spec, seed=1))
