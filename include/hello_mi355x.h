@@ -75,7 +75,11 @@ typedef enum hello_op_kind {
                              /* writes output slot `dst`: 0..2 expert logits, 3 meta (+softmax)       */
     HELLO_OP_CONCAT = 6,     /* channel concat of src0 (cin ch) and src1 (c1 ch)                      */
     HELLO_OP_ADD = 7,        /* dst = src0 + src1                                                     */
-    HELLO_OP_READCONV_FUSED = 8 /* whole read convolver + reads->alleles segment sum in one kernel    */
+    HELLO_OP_READCONV_FUSED = 8 /* whole read convolver + reads->alleles segment sum in one kernel:
+                                 * canonical architecture (architectures/read_convolver.py) on 150 bp windows
+                                 * (+0 | 2 extra blocks in k; from the bytes with FLAG_SRC_U8, else from the
+                                 * pooled stem output), or on 250 bp windows (from the bytes, Winograd form);
+                                 * dst rows are [36 | 61][64] per allele                                   */
 } hello_op_kind;
 
 #define HELLO_FLAG_RELU     1
