@@ -24,6 +24,7 @@ CASES = [
     ("hybrid ensemble2 (meta on reference)", "hybrid_ensemble2", {}, dict(coverage=30, hybrid_coverage=15), 1),
     ("hybrid no-ensemble wide (2x channels)", "hybrid_no_ensemble", dict(w=2), dict(coverage=30, hybrid_coverage=15), 4),
     ("single-tech + transfer-learning addendum", "single_tech_addendum", {}, dict(coverage=30), 1),
+    ("single-tech, Softplus / no normalisation (layer by layer)", "single_tech_softplus", {}, dict(coverage=30), 4),
     ("MoEMergedAdvanced hybrid (older family)", "merged_hybrid", {}, dict(coverage=30, hybrid_coverage=15), 1),
     ("MoEMergedAdvanced 250 bp feature map", "merged_hybrid_250", {}, dict(coverage=30, hybrid_coverage=15, window=250), 4),
 ]
@@ -40,7 +41,7 @@ def main():
     ap.add_argument("--op-times", action="store_true", help="per-op device time and TFLOP/s of each configuration")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    print(f"{'configuration':52s} {'sites':>6s} {'reads/site':>10s} {'ms/step':>8s} {'sites/s':>10s} {'TFLOP/s':>8s} {'of peak':>7s} fused")
+    print(f"{'configuration':58s} {'sites':>6s} {'reads/site':>10s} {'ms/step':>8s} {'sites/s':>10s} {'TFLOP/s':>8s} {'of peak':>7s} fused")
     for label, cfg, bkw, skw, div in CASES:
         if args.only and args.only not in label and args.only != cfg:
             continue
@@ -82,7 +83,7 @@ def main():
                 print(f"    {kind:14s} {ms:8.4f} ms {tf:7.1f} TF/s  cin={o.cin:4d} cout={o.cout:4d} k={o.k} s={o.stride} "
                       f"L {o.lin}->{o.lout} rows={r}  {name}")
         reads = (rows[compiler.ROWS_READS0] + rows[compiler.ROWS_READS1]) / n
-        print(f"{label:52s} {n:6d} {reads:10.1f} {dt * 1e3:8.2f} {n / dt:10.0f} {flops / dt / 1e12:8.1f} "
+        print(f"{label:58s} {n:6d} {reads:10.1f} {dt * 1e3:8.2f} {n / dt:10.0f} {flops / dt / 1e12:8.1f} "
               f"{flops / dt / PEAK:7.1%} {eng.program.fused_read_convolver}", flush=True)
         eng.close()
         del r0, r1
