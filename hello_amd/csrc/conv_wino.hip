@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
                 const float m0v = acc[0][tp][4 * q + e], m1v = acc[1][tp][4 * q + e];
                 const float m2v = acc[2][tp][4 * q + e], m3v = acc[3][tp][4 * q + e];
                 const float x0 = ((m0v + m1v) + m2v) + b4[e], x1 = ((m1v - m2v) - m3v) + b4[e];
-                y0[e] = a.relu == 1 ? fmaxf(x0, 0.f) : (a.relu == 2 ? (x0 > 20.f ? x0 : log1pf(expf(x0))) : x0);
-                y1[e] = a.relu == 1 ? fmaxf(x1, 0.f) : (a.relu == 2 ? (x1 > 20.f ? x1 : log1pf(expf(x1))) : x1);
+                y0[e] = a.relu == 1 ? fmaxf(x0, 0.f) : (a.relu == 2 ? (x0 > 20.f ? x0 : __logf(1.f + __expf(x0))) : x0);
+                y1[e] = a.relu == 1 ? fmaxf(x1, 0.f) : (a.relu == 2 ? (x1 > 20.f ? x1 : __logf(1.f + __expf(x1))) : x1);
             }
             if (a.res) {
 #pragma unroll
