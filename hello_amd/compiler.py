@@ -151,11 +151,12 @@ def pack_conv_winograd(w: np.ndarray, b: np.ndarray):
 
 
 # canonical read-convolver shape the fused kernel implements (architectures/read_convolver.py)
-def _canonical_read_convolver_extras(nodes, cin) -> int:
-    """-1 if ``nodes`` is not the canonical read convolver; otherwise the number of extra identity-shortcut
-    64-channel residual blocks appended to it (transfer-learning models add 2, read_convolver_addendum.py)."""
+def _canonical_read_convolver_extras(nodes, cin, act="relu") -> int:
+    """-1 if ``nodes`` is not the canonical read convolver (with activation ``act`` throughout); otherwise the
+    number of extra identity-shortcut 64-channel residual blocks appended to it (transfer-learning models add
+    2, read_convolver_addendum.py)."""
     try:
-        ref = ns.read_convolver("x", in_channels=cin)
+        ref = ns.read_convolver("x", in_channels=cin, act=act)
     except Exception:
         return -1
 
@@ -316,11 +317,15 @@ class _Lowering:
         x = self.input(buf, dom, spec.window, cin)
         from . import readconv_pack
         extras = _canonical_read_convolver_extras(nodes, cin)
+        softplus = False
+        if extras < 0 and _canonical_read_convolver_extras(nodes, cin, "softplus") == 0:
+            extras, softplus = 0, True            # moe_attention_config_single_tech_old_equivalent_layer_norm.py
         fusable = (self.fused and readconv_pack.AVAILABLE and extras in readconv_pack.EXTRA_BLOCKS
                    and spec.window in readconv_pack.WINDOWS)
-        if fusable and spec.window != 150:
-            # the 250 bp geometry exists as the whole kernel (stem included) in Winograd form only
-            fusable = self.fused is True and self.winograd and extras == 0
+        if fusable and (spec.window != 150 or softplus):
+            # the 250 bp geometry and the Softplus activation exist as the whole kernel (stem included) in
+            # Winograd form only
+            fusable = self.fused is True and self.winograd and extras == 0 and not (softplus and spec.window != 150)
         if fusable:
             _, l1, _, l2, _, _ = readconv_pack.geometry(spec.window)
             y = self.new(ROWS_ALLELES, l2, 64)
@@ -338,7 +343,8 @@ class _Lowering:
                 # the whole read convolver (stem included) + segment sum in one kernel, straight from the bytes
                 self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=buf, dst=y.vid, cin=cin, cout=64,
                                    k=extras, lin=spec.window, lout=l2, seg=seg, w_off=w_off, b_off=w_off, name=name,
-                                   flags=FLAG_SRC_U8 | wflag, macs_per_row=ns.macs(nodes, spec.window),
+                                   flags=FLAG_SRC_U8 | wflag | (FLAG_SOFTPLUS if softplus else 0),
+                                   macs_per_row=ns.macs(nodes, spec.window),
                                    exec_macs_per_row=readconv_pack.executed_macs_per_read(self.winograd, extras,
                                                                                           spec.window)))
             self.used_fused = True

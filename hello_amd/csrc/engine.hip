@@ -172,6 +172,10 @@ int validate_model(const hello_model_desc* d) {
             if (o.lout != hello::readconv_frame_rows(d->window) || o.cout != 64)
                 return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver yields [%d][64] frames", i,
                             hello::readconv_frame_rows(d->window));
+            if ((o.flags & HELLO_FLAG_SOFTPLUS) &&
+                !(d->window == 150 && (o.flags & HELLO_FLAG_WINOGRAD) && (o.flags & HELLO_FLAG_SRC_U8) && o.k == 0))
+                return fail(HELLO_ERR_MODEL, "op %d: the Softplus read convolver runs whole (from the bytes), in Winograd "
+                                             "form, on 150 bp windows, without extra blocks", i);
             if (d->window == 250 && !((o.flags & HELLO_FLAG_WINOGRAD) && (o.flags & HELLO_FLAG_SRC_U8) && o.k == 0))
                 return fail(HELLO_ERR_MODEL, "op %d: 250 bp windows run whole (from the bytes), in Winograd form, "
                                              "without extra blocks", i);
@@ -643,6 +647,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.slot_of_group = t1 ? e->group_slot1 : e->group_slot0;
                 a.n_reads = t1 ? R1 : R0;
                 a.window = d.window;
+                a.softplus = (o.flags & HELLO_FLAG_SOFTPLUS) ? 1 : 0;
                 a.groups_per_wg = hello::readconv_groups_per_workgroup(a.n_reads, d.window);
                 a.extra_blocks = o.k;
                 a.winograd = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;

@@ -69,6 +69,7 @@ struct ReadConvArgs {
     int extra_blocks;          // identity-shortcut 64-channel blocks after the canonical three: 0 | 2
     int winograd;              // residual-block convolutions in Winograd F(2,3) form (weights packed accordingly)
     int window;                // pileup window: 150 | 250 (250: `reads` + Winograd form only)
+    int softplus;              // Softplus instead of ReLU (`reads` + Winograd form, 150 bp only)
 };
 bool readconv_supports_window(int window);
 int readconv_reads_per_group(int window);

@@ -77,8 +77,16 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // Geometry of a pileup window of WIN_ positions (150 in every shipped model, 250 in the feature-map variant):
 //   window -> 3 valid k=3 convs (WIN-6) -> MaxPool(3,2): L1 -> strided block: L2
-template <int G_, int NW_, int WIN_ = 150>
+enum { ACT_RELU = 0, ACT_SOFTPLUS = 1 };
+template <int G_, int NW_, int WIN_ = 150, int ACT_ = ACT_RELU>
 struct Cfg {
+    static constexpr int ACT = ACT_;                   // the network's activation (ReLU; Softplus in ..._layer_norm.py)
+    // torch.nn.Softplus(beta 1, threshold 20) with the hardware exp / log (see conv_generic.hip); monotone like
+    // ReLU, so it commutes with the stem's max pool
+    static __device__ __forceinline__ float act(float x) {
+        if constexpr (ACT_ == ACT_RELU) return fmaxf(x, 0.f);
+        else return x > 20.f ? x : __logf(1.f + __expf(x));
+    }
     static constexpr int G = G_;                       // reads per workgroup
     static constexpr int NW = NW_;                     // waves per workgroup
     static constexpr int THREADS = 64 * NW_;
@@ -121,6 +129,7 @@ bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0
 
 using Geometry = rc::Cfg<4, 4, 150>;      // 4 reads x 4 waves per workgroup, two workgroups per CU
 using Geometry250 = rc::Cfg<2, 4, 250>;   // 250 bp windows: 2 reads per workgroup fill the same LDS
+using GeometrySoftplus = rc::Cfg<4, 4, 150, rc::ACT_SOFTPLUS>;
 bool readconv_supports_window(int window) { return window == 150 || window == 250; }
 int readconv_reads_per_group(int window) { return window == 250 ? Geometry250::G : Geometry::G; }
 int readconv_frame_rows(int window) { return window == 250 ? Geometry250::L2 : Geometry::L2; }
@@ -292,7 +301,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
             return;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[e] + b4[e], 0.f);
+        for (int e = 0; e < 4; ++e) v[e] = CF::act(acc[e] + b4[e]);
         if (MODE == MODE_RESID_INPLACE) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += res[e];
@@ -479,8 +488,8 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
             y1 = (a[1] - a[2]) - a[3];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                y0[e] = fmaxf(y0[e], 0.f);
-                y1[e] = fmaxf(y1[e], 0.f);
+                y0[e] = CF::act(y0[e]);
+                y1[e] = CF::act(y1[e]);
             }
             if constexpr (MODE == MODE_RESID_INPLACE) {
                 y0 = y0 + res0;
@@ -590,8 +599,8 @@ __device__ __forceinline__ void stem_conv1(const unsigned char* __restrict__ s_u
         f32x4 v0, v1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v0[e] = fmaxf(a0[e] + b4[e], 0.f);
-            v1[e] = fmaxf(a1[e] + b4[e], 0.f);
+            v0[e] = CF::act(a0[e] + b4[e]);
+            v1[e] = CF::act(a1[e] + b4[e]);
         }
         *(f32x4*)(r0 < CF::SROWS ? c1 + r0 * 16 + 4 * (q ^ swz<16>(r0)) : dump) = v0;
         *(f32x4*)(r1 < CF::SROWS ? c1 + r1 * 16 + 4 * (q ^ swz<16>(r1)) : dump) = v1;
@@ -657,7 +666,7 @@ __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, fl
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 // lanes 14 / 15 of a row see zeros shifted in; their results are never stored (even lanes <= 12 are)
-                v[e] = fmaxf(fmaxf(fmaxf(sum[e], row_shl(sum[e], 1)), row_shl(sum[e], 2)), 0.f);
+                v[e] = CF::act(fmaxf(fmaxf(sum[e], row_shl(sum[e], 1)), row_shl(sum[e], 2)));
             }
             float* ptr = out + img_off<32, SOUT>(row, 4 * blk + q);
             *(f32x4*)(ok ? ptr : dump) = v;
@@ -971,6 +980,10 @@ hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
         return launch_cfg<Geometry250, 3, true, true>(a, stream);
     }
     if (a.window != 150) return hipErrorInvalidValue;
+    if (a.softplus) {              // the Softplus configuration: whole kernel, Winograd form
+        if (!a.reads || !a.winograd || a.extra_blocks != 0) return hipErrorInvalidValue;
+        return launch_cfg<GeometrySoftplus, 3, true, true>(a, stream);
+    }
     if (a.extra_blocks == 0) return a.winograd ? launch_cfg<Geometry, 3, true>(a, stream) : launch_cfg<Geometry, 3, false>(a, stream);
     if (a.extra_blocks == 2) return a.winograd ? launch_cfg<Geometry, 5, true>(a, stream) : launch_cfg<Geometry, 5, false>(a, stream);
     return hipErrorInvalidValue;

@@ -99,6 +99,15 @@ def test_canonical_models_use_the_fused_trunk_and_small_scratch():
         assert prog.weights.dtype == np.float32 and prog.weights.size % 4 == 0 or True
 
 
+def test_softplus_model_uses_the_fused_kernel_in_winograd_form_only():
+    spec = ns.build("single_tech_softplus")
+    state = weights.synth_state(spec, seed=1)
+    op = next(o for o in compiler.compile_model(spec, state).ops if o.kind == compiler.OP_READCONV_FUSED)
+    assert op.flags & compiler.FLAG_SOFTPLUS and op.flags & compiler.FLAG_WINOGRAD and op.flags & compiler.FLAG_SRC_U8
+    for kw in (dict(winograd=False), dict(fused="trunk"), dict(fused=False)):
+        assert not compiler.compile_model(spec, state, **kw).fused_read_convolver
+
+
 def test_250bp_model_uses_the_fused_kernel_in_winograd_form_only():
     spec = ns.build("merged_hybrid_250")
     state = weights.synth_state(spec, seed=1)

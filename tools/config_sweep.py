@@ -24,7 +24,7 @@ CASES = [
     ("hybrid ensemble2 (meta on reference)", "hybrid_ensemble2", {}, dict(coverage=30, hybrid_coverage=15), 1),
     ("hybrid no-ensemble wide (2x channels)", "hybrid_no_ensemble", dict(w=2), dict(coverage=30, hybrid_coverage=15), 4),
     ("single-tech + transfer-learning addendum", "single_tech_addendum", {}, dict(coverage=30), 1),
-    ("single-tech, Softplus / no normalisation (layer by layer)", "single_tech_softplus", {}, dict(coverage=30), 4),
+    ("single-tech, Softplus / no normalisation", "single_tech_softplus", {}, dict(coverage=30), 1),
     ("MoEMergedAdvanced hybrid (older family)", "merged_hybrid", {}, dict(coverage=30, hybrid_coverage=15), 1),
     ("MoEMergedAdvanced 250 bp feature map", "merged_hybrid_250", {}, dict(coverage=30, hybrid_coverage=15, window=250), 4),
 ]
