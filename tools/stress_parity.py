@@ -24,7 +24,7 @@ def main():
     cases = [("single_tech", dict()), ("single_tech_hp", dict(channels=7, tech="pacbio")),
              ("hybrid_no_ensemble", dict(hybrid_coverage=12)), ("hybrid_full", dict(hybrid_coverage=9)),
              ("single_tech_addendum", dict()), ("merged_hybrid", dict(hybrid_coverage=10)),
-             ("merged_hybrid_250", dict(hybrid_coverage=8, window=250))]
+             ("merged_hybrid_250", dict(hybrid_coverage=8, window=250)), ("single_tech_softplus", dict())]
     engines = {}
     worst, t0 = 0.0, time.time()
     for r in range(args.rounds):
