@@ -265,14 +265,33 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     // every tile through the ds_read offset field.
     constexpr bool IDENT = (GEOM == GEOM_STEM) ? (TS == 16) : ((RS_IN == RS_OUT) && (STRIDE == 1));
     constexpr int LEAD = (GEOM == GEOM_STEM) ? 0 : 1;
-    const float* opbase[KT * M];
+    // Stride-2 layers over images whose input row stride is exactly twice the output row stride (the compact
+    // 150 bp geometry: 72 = 2 x 36): the read index cancels, output row r reads input row 2 r + 1 - PAD + tap,
+    // so here too a tile only adds a constant (two pointer sets for the even / odd tiles of GEOM_WPAIR).
+    constexpr bool S2LIN = (GEOM != GEOM_STEM) && (STRIDE == 2) && (RS_IN == 2 * RS_OUT);
+    static_assert(!S2LIN || GEOM != GEOM_WPAIR || NPG == 1, "paired-row tiles assume one position group");
+    const float* opbase[(S2LIN && GEOM == GEOM_WPAIR) ? 2 * KT * M : KT * M];
+    if constexpr (S2LIN && GEOM == GEOM_WPAIR) {
 #pragma unroll
-    for (int s = 0; s < KT * M; ++s) {
-        const int x = j + LEAD - PAD + s / M;
-        opbase[s] = in + 16 * pg * CIN + img_off<CIN, SIN>(x, 4 * (s % M) + q);
+        for (int s = 0; s < 2 * KT * M; ++s) {           // rows 64 (t/2) + 4 j + 2 (t&1) + 1 - PAD + tap
+            const int par = s / (KT * M), ss = s % (KT * M);
+            opbase[s] = in + img_off<CIN, SIN>(4 * j + 2 * par + 1 - PAD + ss / M, 4 * (ss % M) + q);
+        }
+    } else if constexpr (S2LIN) {
+#pragma unroll
+        for (int s = 0; s < KT * M; ++s)                  // rows 32 t + 2 j + 1 - PAD + tap
+            opbase[s] = in + 32 * pg * CIN + img_off<CIN, SIN>(2 * j + 1 - PAD + s / M, 4 * (s % M) + q);
+    } else {
+#pragma unroll
+        for (int s = 0; s < KT * M; ++s) {
+            const int x = j + LEAD - PAD + s / M;
+            opbase[s] = in + 16 * pg * CIN + img_off<CIN, SIN>(x, 4 * (s % M) + q);
+        }
     }
     auto tile_operand = [&](int k, int s) -> f32x4 {     // k-th tile of this wave, step s = tap*M + m
         if (IDENT) return *(const f32x4*)(opbase[s] + k * NPG * 16 * CIN);
+        if constexpr (S2LIN && GEOM == GEOM_WPAIR) return *(const f32x4*)(opbase[(k & 1) * KT * M + s] + (k / 2) * 64 * CIN);
+        if constexpr (S2LIN && GEOM != GEOM_WPAIR) return *(const f32x4*)(opbase[s] + k * NPG * 32 * CIN);
         int row;
         if (GEOM == GEOM_STEM) {
             row = TS * (pg + NPG * k) + j + s / M;
