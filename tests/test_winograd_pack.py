@@ -64,3 +64,15 @@ def test_executed_macs_match_the_kernel_schedule():
     assert rp.executed_macs_per_read(False) == 5052 * 1024          # MFMAs per wave and group of 4 reads (ISA count)
     assert rp.executed_macs_per_read(True) == (444 + 6 * 144 + 216 + 80 + 320 + 6 * 320) * 1024
     assert rp.executed_macs_per_read(True, 2) - rp.executed_macs_per_read(True) == 4 * 320 * 1024
+
+
+def test_window_geometry_matches_the_reference_layer_arithmetic():
+    """readconv_pack.geometry mirrors Cfg<G, NW, WINDOW> of readconv_fused.hip; the lengths are what the
+    reference's layer lists produce (3 valid k3 convs, MaxPool(3,2), one stride-2 block)."""
+    for window, want in ((150, (4, 71, 72, 36, 36, 11)), (250, (2, 121, 122, 61, 62, 18))):
+        assert rp.geometry(window) == want
+        nodes = ns.read_convolver("x")
+        assert ns.out_length(nodes[:4], window) == want[1] and ns.out_length(nodes, window) == want[3]
+    # executed MACs of the 250 bp kernel: fewer than the direct-form algorithmic count, more than 2/3 of it
+    algo = ns.macs(ns.read_convolver("x"), 250)
+    assert 0.67 * algo < rp.executed_macs_per_read(True, 0, 250) < algo
