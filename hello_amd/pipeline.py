@@ -14,6 +14,11 @@ Only torch's memory/stream plumbing is used; all arithmetic is the engine's.
     for tag, logits, meta, post in pipe.flush():
         ...
 
+Small batches (a few hundred sites) cannot fill the chip on their own: the allele-stage kernels of a 256-site
+batch occupy a fraction of the CUs.  Pass several engines of the same model (``engines=[...]``, each with its
+own scratch and compute stream) and consecutive batches run concurrently: 260 k -> 360 k sites/s at 256 sites
+per batch with four engines, 356 k -> 400 k at 1 024 (at 8 192 sites one engine already fills the GPU).
+
 Results come back in submission order.  A producer that can write straight into pinned memory (the GPU box's
 featurizer output, a memory-mapped shard) should pass pinned ``torch.uint8`` tensors: pageable NumPy arrays
 are first copied into the slot's pinned staging buffer by the CPU, which costs about as much as scoring them.
@@ -46,14 +51,25 @@ def _grow(t, n, **kw):
 
 
 class HostPipeline:
-    def __init__(self, engine: Engine, depth: int = 2, posteriors: bool = True):
+    def __init__(self, engine: Optional[Engine] = None, depth: int = 2, posteriors: bool = True,
+                 engines: Optional[List[Engine]] = None):
         import torch
+        self.engines = list(engines) if engines else [engine]
+        if not self.engines or self.engines[0] is None:
+            raise ValueError("an engine is required")
+        engine = self.engines[0]
+        if any((e.device, e.n_experts, e.has_meta, e.program.window) !=
+               (engine.device, engine.n_experts, engine.has_meta, engine.program.window) for e in self.engines):
+            raise ValueError("all engines of a pipeline must hold the same model on the same device")
         if depth < 2:
             raise ValueError("depth >= 2 is needed to overlap the copy of one batch with the scoring of another")
+        n = len(self.engines)
+        depth = -(-max(depth, 2 * n if n > 1 else depth) // n) * n      # a slot always maps to the same engine
         self.engine = engine
         self.posteriors = posteriors
         self.device = torch.device(f"cuda:{engine.device}")
-        self.compute = torch.cuda.Stream(self.device)
+        self.computes = [torch.cuda.Stream(self.device) for _ in self.engines]
+        self.compute = self.computes[0]
         self.copy = torch.cuda.Stream(self.device)
         self.slots = [_Slot() for _ in range(depth)]
         for s in self.slots:
@@ -95,8 +111,10 @@ class HostPipeline:
     def submit(self, batch, tag=None) -> List[Tuple]:
         """Queue one batch; returns the batches that finished meanwhile (possibly none), oldest first."""
         import torch
-        e = self.engine
-        slot = self.slots[self.count % len(self.slots)]
+        index = self.count % len(self.slots)
+        e = self.engines[index % len(self.engines)]
+        compute = self.computes[index % len(self.engines)]
+        slot = self.slots[index]
         self.count += 1
         finished = [self._harvest(slot)] if slot.pending is not None else []
 
@@ -122,19 +140,19 @@ class HostPipeline:
             if n:
                 slot.dev_out[i] = _grow(slot.dev_out[i], n, device=self.device, **f32)
                 slot.pinned_out[i] = _grow(slot.pinned_out[i], n, pin_memory=True, **f32)
-        with torch.cuda.stream(self.compute):
-            self.compute.wait_event(slot.copied)
+        with torch.cuda.stream(compute):
+            compute.wait_event(slot.copied)
             dev = [None if st is None else slot.dev_in[i][:st.numel()].view(shapes[i]) for i, st in enumerate(staged)]
             out = (slot.dev_out[0][:sizes[0]].view(e.n_experts, A),
                    slot.dev_out[1][:sizes[1]].view(S, 3) if sizes[1] else None,
                    slot.dev_out[2][:sizes[2]].view(4, P) if sizes[2] else None)
             e.forward(dev[0], batch.reads_per_allele0, aps, dev[1],
                       batch.reads_per_allele1 if dev[1] is not None else None, dev[2],
-                      stream=self.compute.cuda_stream, out=out, posteriors=self.posteriors)
+                      stream=compute.cuda_stream, out=out, posteriors=self.posteriors)
             for i, n in enumerate(sizes):
                 if n:
                     slot.pinned_out[i][:n].copy_(slot.dev_out[i][:n], non_blocking=True)
-            slot.done.record(self.compute)
+            slot.done.record(compute)
         slot.pending = (tag, A, S, P)
         return finished
 

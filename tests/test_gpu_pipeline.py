@@ -33,4 +33,15 @@ def test_pipeline_matches_direct_calls_in_order(cfg, kw):
         assert np.array_equal(logits, dl) and np.array_equal(post, dp)
         assert (meta is None and dm is None) or np.array_equal(meta, dm)
     assert pipe.flush() == []
+    # several engines: consecutive batches run concurrently on their own compute streams, same answers, same order
+    eng2 = Engine(spec, state, device=0)
+    pipe = HostPipeline(engines=[eng, eng2])
+    got = []
+    for i, b in enumerate(batches * 2):
+        got += pipe.submit(b, tag=i)
+    got += pipe.flush()
+    assert [g[0] for g in got] == list(range(2 * len(batches)))
+    for (tag, logits, meta, post), (dl, dm, dp) in zip(got, direct * 2):
+        assert np.array_equal(logits, dl) and np.array_equal(post, dp)
+    eng2.close()
     eng.close()

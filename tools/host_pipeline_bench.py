@@ -24,9 +24,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--pool", type=int, default=3)
+    ap.add_argument("--engines", type=int, default=1, help="engines (compute streams) the pipeline alternates over")
     args = ap.parse_args()
     spec = ns.build("single_tech")
-    eng = Engine(spec, weights.synth_state(spec, seed=1), device=0)
+    state = weights.synth_state(spec, seed=1)
+    eng = Engine(spec, state, device=0)
+    engines = [eng] + [Engine(spec, state, device=0) for _ in range(args.engines - 1)]
     pool = []
     for i in range(args.pool):
         b = synth.make_sites(args.sites, seed=2000 + i, coverage=30)
@@ -36,7 +39,7 @@ def main():
     mb = pool[0][0].reads0.nbytes / 1e6
 
     def run(kind):
-        pipe = HostPipeline(eng, depth=args.depth)
+        pipe = HostPipeline(depth=args.depth, engines=engines)
         done = 0
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -60,7 +63,7 @@ def main():
         "sites_per_step": args.sites, "steps": args.steps, "input_MB_per_step": round(mb, 1),
         "engine_forward_on_host_arrays": round(res["serial"], 1),
         "pipeline_pageable_inputs": round(res["pageable"], 1),
-        "pipeline_pinned_inputs": round(res["pinned"], 1), "depth": args.depth}))
+        "pipeline_pinned_inputs": round(res["pinned"], 1), "depth": args.depth, "engines": args.engines}))
 
 
 if __name__ == "__main__":
