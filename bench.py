@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--sites", type=int, default=8192, help="candidate sites per step per GPU")
     ap.add_argument("--pool", type=int, default=2, help="distinct resident batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the 256-sites-per-launch leg")
     ap.add_argument("--fused", choices=["full", "trunk", "none"], default="full",
                     help="read convolver: one fused kernel from the bytes / layer-by-layer stem + fused trunk / "
                          "layer by layer")
@@ -299,6 +300,39 @@ def main():
         "hbm_algorithmic_gbs": round((900.0 * reads_step) / (dt / args.steps) / 1e9, 3),
     }
 
+    # BASELINE.json's config 2 names launches of 256 sites: such a launch cannot fill the chip alone, so small
+    # batches are alternated over four engines (own scratch and stream each); reported beside the headline value
+    small = None
+    if world == 1 and not args.no_small_batch:
+        try:
+            small_engines = [eng] + [Engine(spec, state, device=dev_index) for _ in range(3)]
+            streams = [torch.cuda.Stream(dev) for _ in small_engines]
+            sb = synth.make_sites(256, seed=args.seed + 77, coverage=30)
+            sreads = torch.from_numpy(sb.reads0).to(dev)
+            torch.cuda.synchronize(dev)
+
+            def small_step(i):
+                k = i % len(small_engines)
+                with torch.cuda.stream(streams[k]):
+                    small_engines[k].forward(sreads, sb.reads_per_allele0, sb.alleles_per_site,
+                                             stream=streams[k].cuda_stream, posteriors=True)
+            for i in range(8):
+                small_step(i)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            n_small = 400
+            for i in range(n_small):
+                small_step(i)
+            torch.cuda.synchronize(dev)
+            dt_small = time.perf_counter() - t1
+            small = {"sites_per_launch": 256, "engines": len(small_engines), "launches": n_small,
+                     "value": round(256 * n_small / dt_small, 1), "unit": "sites/s",
+                     "ms_per_launch": round(1e3 * dt_small / n_small, 4)}
+            for e in small_engines[1:]:
+                e.close()
+        except Exception as exc:
+            print(f"small-batch leg failed: {exc!r}", file=sys.stderr)
+
     parity = None
     if cpu is not None and getattr(cpu_baseline, "reference_answers", None) is not None:
         check, want_probs, want_post = cpu_baseline.reference_answers
@@ -326,6 +360,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": parity,
+            "small_batch": small,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
