@@ -64,8 +64,8 @@ struct Offs {
     static constexpr int W_TRUNK = OFF_D + 6 * (W6464 + 64);
     static constexpr int OFF_S1 = W_TRUNK;                            // [6 steps][64 lanes], bias[16]
     static constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps][64 lanes][4], bias[16]
-    static constexpr int OFF_S3 = OFF_S2 + 3 * 256 + 16;              // [2 blocks][3 taps][64 lanes][4], bias[32]
-    static constexpr int W_TOTAL = OFF_S3 + 2 * 3 * 256 + 32;
+    static constexpr int OFF_S3 = OFF_S2 + 3 * 256 + 16;              // [2 blocks][3 taps | 4 Winograd taps][64 lanes][4], bias[32]
+    static constexpr int W_TOTAL = OFF_S3 + 2 * KT * 256 + 32;
     // transfer-learning models append identity-shortcut 64-channel blocks (read_convolver_addendum.py); their
     // weights follow the canonical blob.  First conv of 64-channel block `blk`:
     static constexpr int off_d(int blk) {
@@ -714,6 +714,93 @@ __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, fl
     epilogue(std::integral_constant<int, NTT - 1>{});
 }
 
+// ---- the same in Winograd F(2,3) form --------------------------------------------------------------------
+// Lane row j of a tile holds the PAIR of conv3 positions (2P, 2P+1), P = 15 t + j: y0 = conv(2P), y1 = conv(2P+1)
+// come out of four contractions of d0..d3 = rows 2P..2P+3 (valid convolution: no padding), and the pooled
+// output P = max(conv(2P), conv(2P+1), conv(2P+2)) = max(y0, y1, y0 of lane j+1) needs ONE lane shift.  Tiles
+// are 15 pairs apart (lane 15's pair is recomputed as lane 0 of the next tile): 5 tiles of 32 MFMAs per 150 bp
+// read instead of 11 tiles of 24, and 15 of 16 lane rows store a pooled row instead of 7.
+template <class CF, int SOUT>
+__device__ __forceinline__ void stem_conv3_pool_wino(const float* __restrict__ in, float* __restrict__ out,
+                                                     const float* __restrict__ W3, float* __restrict__ dump, int wave,
+                                                     int lane, int n_here) {
+    constexpr int WPR = CF::WPR;                              // waves per read: wave (rd, half) takes tiles half + WPR k
+    constexpr int NTR = (CF::L1 + 14) / 15;                   // tiles per read
+    constexpr int NK = (NTR + WPR - 1) / WPR;                 // tiles of the first wave of a read
+    const int j = lane & 15, q = lane >> 4;
+    const int rd = wave / WPR, half = wave % WPR;
+    f32x4 w[2][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[blk][c] = *(const f32x4*)(W3 + ((blk * 4 + c) * 64 + lane) * 4);
+    f32x4 b4[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) b4[blk] = *(const f32x4*)(W3 + 2 * 4 * 256 + blk * 16 + 4 * q);
+    const int lrow = rd * CF::WINDOW + 30 * half + 2 * j;     // row of d0 in the wave's first tile
+    const float* pin[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pin[k] = in + lrow * 16 + 4 * (q ^ (2 * (((lrow + k) >> 2) & 1)));
+    const int opos = 15 * half + j;                            // pooled position in the wave's first tile
+    const bool lane_ok = (j <= 14) && (rd < n_here);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool last_here = half + WPR * (NK - 1) < NTR;        // wave-uniform: the last tile exists for this wave
+
+    f32x4 ring[2][4];
+    f32x4 acc[2][2][4];                                       // [tile parity][block][component]
+    auto issue = [&](auto tc) {
+        constexpr int k = decltype(tc)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            constexpr int c0 = 30 * WPR * k;
+            ring[k & 1][i] = *(const f32x4*)(pin[(c0 + i) & 7] + (c0 + i) * 16);
+        }
+    };
+    auto epilogue = [&](auto tc) {
+        constexpr int k = decltype(tc)::value;
+        const int pos = opos + 15 * WPR * k;
+        const bool ok = lane_ok && (pos < CF::L1);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const f32x4(&a)[4] = acc[k & 1][blk];
+            const f32x4 y0 = (a[0] + a[1]) + a[2];             // the bias rides in a[1]
+            const f32x4 y1 = (a[1] - a[2]) - a[3];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = CF::act(fmaxf(fmaxf(y0[e], y1[e]), row_shl(y0[e], 1)));
+            float* ptr = out + img_off<32, SOUT>(1 + rd * CF::RS1 + pos, 4 * blk + q);
+            *(f32x4*)(ok ? ptr : dump) = v;
+        }
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NK>([&](auto tc) {
+        constexpr int k = decltype(tc)::value;
+        constexpr bool tail = (k == NK - 1) && (NTR % WPR != 0);
+        if constexpr (k + 1 < NK) issue(std::integral_constant<int, k + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (k >= 1) epilogue(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
+        if (!tail || last_here) {
+            const f32x4 d0 = ring[k & 1][0], d1 = ring[k & 1][1], d2 = ring[k & 1][2], d3 = ring[k & 1][3];
+            const f32x4 t0 = pk_sub(d0, d2), t1 = pk_add(d1, d2), t2 = pk_sub(d2, d1), t3 = pk_sub(d1, d3);
+            asm volatile("s_nop 1");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    f32x4(&a)[4] = acc[k & 1][blk];
+                    a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[blk][0][e], t0[e], e == 0 ? zero4 : a[0], 0, 0, 0);
+                    a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[blk][1][e], t1[e], e == 0 ? b4[blk] : a[1], 0, 0, 0);
+                    a[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[blk][2][e], t2[e], e == 0 ? zero4 : a[2], 0, 0, 0);
+                    a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[blk][3][e], t3[e], e == 0 ? zero4 : a[3], 0, 0, 0);
+                }
+        }
+        if constexpr (k == NK - 1) {
+            if (!tail || last_here) epilogue(std::integral_constant<int, NK - 1>{});
+        }
+    });
+}
+
 template <class CF, bool STEM, int NB64, bool WINO>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
@@ -849,7 +936,8 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             const int row = (tid >> 3) * RS1;
             *(f32x4*)(X + img_off<32, SWX>(row, tid & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};   // a whole row, chunk by chunk
         }
-        stem_conv3_pool<CF, SWX>(bufA, X, W + OFF_S3, dump, wave, lane, n_here);
+        if constexpr (WINO) stem_conv3_pool_wino<CF, SWX>(bufA, X, W + OFF_S3, dump, wave, lane, n_here);
+        else stem_conv3_pool<CF, SWX>(bufA, X, W + OFF_S3, dump, wave, lane, n_here);
         __syncthreads();
         if (tid < 8) ((f32x4*)H)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};        // row 0 of the 32-channel image
     } else {

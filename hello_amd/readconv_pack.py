@@ -70,9 +70,11 @@ def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, window: int = 
     tile schedule in readconv_fused.hip: v_mfma_f32_16x16x4_f32 = 16*16*4 MACs.  Direct form: 5 052 MFMAs per
     wave and group of 4 reads; Winograd form: 3 948 on average (the residual blocks need 4 instead of 6
     contractions per pair of positions, minus what their half-empty last tile gives back)."""
-    g, _, rs1, _, rs2, ntt = geometry(window)
+    g, l1, rs1, _, rs2, ntt = geometry(window)
     t_stem12 = -(-(-(-window * g // 16)) // 4) * 4               # 16-row tiles of conv1 / conv2, 4 position groups
-    stem = t_stem12 * 6 + t_stem12 * 3 * 4 + g * ntt * 2 * 3 * 4  # conv3: `ntt` stride-14 tiles per read, 2 blocks
+    # conv3 + pool: `ntt` stride-14 tiles of 24 MFMAs per read (2 blocks), or ceil(L1/15) Winograd tiles of 32
+    conv3 = g * (-(-l1 // 15)) * 2 * 4 * 4 if winograd else g * ntt * 2 * 3 * 4
+    stem = t_stem12 * 6 + t_stem12 * 3 * 4 + conv3
     t1, t2 = -(-rs1 * g // 16), -(-rs2 * g // 16)                # direct tiles at 32 / 64 channels
     n64 = 6 + 2 * extra_blocks
     if winograd:
@@ -110,7 +112,8 @@ def pack(nodes, folded, cin=None, winograd: bool = False) -> np.ndarray:
     stem = nodes[:3]
     parts.append(_pack_first_conv(*folded[stem[0].key]))
     parts.append(_pack_conv(*folded[stem[1].key]))
-    parts.append(_pack_conv(*folded[stem[2].key]))
+    w3, b3 = folded[stem[2].key]                        # conv3 + pool runs in Winograd form with the rest
+    parts.append(_pack_conv(winograd_taps(w3), b3) if winograd else _pack_conv(w3, b3))
     extras = nodes[TRUNK_FIRST_NODE + 7:]               # transfer-learning blocks follow the canonical blob
     assert len(extras) in EXTRA_BLOCKS
     for blk in extras:
@@ -119,5 +122,5 @@ def pack(nodes, folded, cin=None, winograd: bool = False) -> np.ndarray:
     kt = 4 if winograd else 3
     w32, w64 = 2 * kt * 2 * 256, 4 * kt * 4 * 256
     trunk = 6 * (w32 + 32) + (6144 + 64) + (2048 + 64) + (w64 + 64) + 6 * (w64 + 64)
-    assert blob.size == trunk + (384 + 16) + (768 + 16) + (1536 + 32) + 2 * len(extras) * (w64 + 64), blob.size
+    assert blob.size == trunk + (384 + 16) + (768 + 16) + (2 * kt * 256 + 32) + 2 * len(extras) * (w64 + 64), blob.size
     return blob
