@@ -63,8 +63,8 @@ struct Offs {
     static constexpr int OFF_D = OFF_C2 + W6464 + 64;                 // 6 convs 64->64 (residual blocks)
     static constexpr int W_TRUNK = OFF_D + 6 * (W6464 + 64);
     static constexpr int OFF_S1 = W_TRUNK;                            // [6 steps][64 lanes], bias[16]
-    static constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps][64 lanes][4], bias[16]
-    static constexpr int OFF_S3 = OFF_S2 + 3 * 256 + 16;              // [2 blocks][3 taps | 4 Winograd taps][64 lanes][4], bias[32]
+    static constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps | 4 Winograd taps][64 lanes][4], bias[16]
+    static constexpr int OFF_S3 = OFF_S2 + KT * 256 + 16;             // [2 blocks][3 taps | 4 Winograd taps][64 lanes][4], bias[32]
     static constexpr int W_TOTAL = OFF_S3 + 2 * KT * 256 + 32;
     // transfer-learning models append identity-shortcut 64-channel blocks (read_convolver_addendum.py); their
     // weights follow the canonical blob.  First conv of 64-channel block `blk`:
@@ -714,7 +714,76 @@ __device__ __forceinline__ void stem_conv3_pool(const float* __restrict__ in, fl
     epilogue(std::integral_constant<int, NTT - 1>{});
 }
 
-// ---- the same in Winograd F(2,3) form --------------------------------------------------------------------
+// ---- stem conv2 (16 -> 16, valid) in Winograd F(2,3) form over the stacked reads ----------------------------
+// Tile T = 16 pairs of rows 32 T + 2 j (+1); wave w takes tiles w, w + NW, ...  Pairs whose window straddles two
+// reads produce rows nothing valid consumes, exactly as in the direct form.
+template <class CF>
+__device__ __forceinline__ void stem_conv2_wino(const float* __restrict__ in, float* __restrict__ out,
+                                                const float* __restrict__ W2, float* __restrict__ dump, int wave,
+                                                int lane) {
+    constexpr int NT = (CF::SROWS / 2 + 15) / 16;             // tiles of 16 pairs
+    constexpr int NK = (NT + CF::NW - 1) / CF::NW;            // tiles of wave 0
+    const int j = lane & 15, q = lane >> 4;
+    f32x4 w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = *(const f32x4*)(W2 + (c * 64 + lane) * 4);
+    const f32x4 b4 = *(const f32x4*)(W2 + 4 * 256 + 4 * q);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float* pin[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pin[i] = in + 32 * wave * 16 + img_off<16, SW_OLD>(2 * j + i, q);
+    float* const o0 = out + 32 * wave * 16 + img_off<16, SW_OLD>(2 * j, q);
+    float* const o1 = out + 32 * wave * 16 + img_off<16, SW_OLD>(2 * j + 1, q);
+    constexpr int TOFF = CF::NW * 32 * 16;                    // floats between a wave's tiles
+    const bool last_here = wave + CF::NW * (NK - 1) < NT;     // wave-uniform
+
+    f32x4 ring[2][4], acc[2][4];
+    auto issue = [&](auto tc) {
+        constexpr int k = decltype(tc)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[k & 1][i] = *(const f32x4*)(pin[i] + k * TOFF);
+    };
+    auto epilogue = [&](auto tc) {
+        constexpr int k = decltype(tc)::value;
+        const f32x4(&a)[4] = acc[k & 1];
+        f32x4 y0 = (a[0] + a[1]) + a[2], y1 = (a[1] - a[2]) - a[3];       // the bias rides in a[1]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y0[e] = CF::act(y0[e]);
+            y1[e] = CF::act(y1[e]);
+        }
+        const int row = 32 * (wave + CF::NW * k) + 2 * j;
+        *(f32x4*)(row < CF::SROWS ? o0 + k * TOFF : dump) = y0;
+        *(f32x4*)(row + 1 < CF::SROWS ? o1 + k * TOFF : dump) = y1;
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NK>([&](auto tc) {
+        constexpr int k = decltype(tc)::value;
+        constexpr bool tail = (k == NK - 1) && (NT % CF::NW != 0);
+        if constexpr (k + 1 < NK) issue(std::integral_constant<int, k + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (k >= 1) epilogue(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
+        if (!tail || last_here) {
+            const f32x4 d0 = ring[k & 1][0], d1 = ring[k & 1][1], d2 = ring[k & 1][2], d3 = ring[k & 1][3];
+            const f32x4 t0 = pk_sub(d0, d2), t1 = pk_add(d1, d2), t2 = pk_sub(d2, d1), t3 = pk_sub(d1, d3);
+            asm volatile("s_nop 1");
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4(&a)[4] = acc[k & 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0][e], t0[e], e == 0 ? zero4 : a[0], 0, 0, 0);
+                a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1][e], t1[e], e == 0 ? b4 : a[1], 0, 0, 0);
+                a[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2][e], t2[e], e == 0 ? zero4 : a[2], 0, 0, 0);
+                a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3][e], t3[e], e == 0 ? zero4 : a[3], 0, 0, 0);
+            }
+        }
+        if constexpr (k == NK - 1) {
+            if (!tail || last_here) epilogue(std::integral_constant<int, NK - 1>{});
+        }
+    });
+}
+
+// ---- stem conv3 + pool in Winograd F(2,3) form -------------------------------------------------------------
 // Lane row j of a tile holds the PAIR of conv3 positions (2P, 2P+1), P = 15 t + j: y0 = conv(2P), y1 = conv(2P+1)
 // come out of four contractions of d0..d3 = rows 2P..2P+3 (valid convolution: no padding), and the pooled
 // output P = max(conv(2P), conv(2P+1), conv(2P+2)) = max(y0, y1, y0 of lane j+1) needs ONE lane shift.  Tiles
@@ -925,11 +994,12 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             for (int i = tid; i < CF::U8_BYTES; i += THREADS) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
         }
         f32x4 ws2[3];
-        load_weights<3>(ws2, W + OFF_S2, 0, lane);
+        if constexpr (!WINO) load_weights<3>(ws2, W + OFF_S2, 0, lane);
         __syncthreads();
         stem_conv1<CF>(s_u8, bufB, W + OFF_S1, ch, dump, wave, lane);
         __syncthreads();
-        conv_layer<CF, 16, 16, 3, 1, 0, 1, 1, 0, CF::ST12, MODE_PLAIN, false, GEOM_STEM, 16, CF::SROWS>(
+        if constexpr (WINO) stem_conv2_wino<CF>(bufB, bufA, W + OFF_S2, dump, wave, lane);
+        else conv_layer<CF, 16, 16, 3, 1, 0, 1, 1, 0, CF::ST12, MODE_PLAIN, false, GEOM_STEM, 16, CF::SROWS>(
             bufB, bufA, ws2, nullptr, W + OFF_S2 + 3 * 256, sreg, 0u, dump, wave, lane);
         __syncthreads();
         if (tid < 8 * (G + 1)) {                      // the image's shared zero rows: 0, 72, 144, ...

@@ -74,7 +74,8 @@ def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, window: int = 
     t_stem12 = -(-(-(-window * g // 16)) // 4) * 4               # 16-row tiles of conv1 / conv2, 4 position groups
     # conv3 + pool: `ntt` stride-14 tiles of 24 MFMAs per read (2 blocks), or ceil(L1/15) Winograd tiles of 32
     conv3 = g * (-(-l1 // 15)) * 2 * 4 * 4 if winograd else g * ntt * 2 * 3 * 4
-    stem = t_stem12 * 6 + t_stem12 * 3 * 4 + conv3
+    conv2 = -(-(window * g // 2) // 16) * 16 if winograd else t_stem12 * 3 * 4      # tiles of 16 pairs, 16 MFMAs each
+    stem = t_stem12 * 6 + conv2 + conv3
     t1, t2 = -(-rs1 * g // 16), -(-rs2 * g // 16)                # direct tiles at 32 / 64 channels
     n64 = 6 + 2 * extra_blocks
     if winograd:
@@ -111,7 +112,8 @@ def pack(nodes, folded, cin=None, winograd: bool = False) -> np.ndarray:
     parts = [one(i, c) for i, c in enumerate(convs)]
     stem = nodes[:3]
     parts.append(_pack_first_conv(*folded[stem[0].key]))
-    parts.append(_pack_conv(*folded[stem[1].key]))
+    w2, b2 = folded[stem[1].key]                        # conv2 too
+    parts.append(_pack_conv(winograd_taps(w2), b2) if winograd else _pack_conv(w2, b2))
     w3, b3 = folded[stem[2].key]                        # conv3 + pool runs in Winograd form with the rest
     parts.append(_pack_conv(winograd_taps(w3), b3) if winograd else _pack_conv(w3, b3))
     extras = nodes[TRUNK_FIRST_NODE + 7:]               # transfer-learning blocks follow the canonical blob
@@ -122,5 +124,5 @@ def pack(nodes, folded, cin=None, winograd: bool = False) -> np.ndarray:
     kt = 4 if winograd else 3
     w32, w64 = 2 * kt * 2 * 256, 4 * kt * 4 * 256
     trunk = 6 * (w32 + 32) + (6144 + 64) + (2048 + 64) + (w64 + 64) + 6 * (w64 + 64)
-    assert blob.size == trunk + (384 + 16) + (768 + 16) + (2 * kt * 256 + 32) + 2 * len(extras) * (w64 + 64), blob.size
+    assert blob.size == trunk + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32) + 2 * len(extras) * (w64 + 64), blob.size
     return blob

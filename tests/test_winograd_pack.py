@@ -49,7 +49,7 @@ def test_fused_blob_sizes_and_flags():
             kt = 4 if wino else 3
             n64 = 7 + 2 * extra                                     # strided block's second conv + the blocks' convs
             want = (6 * (2 * kt * 2 * 256 + 32) + (6144 + 64) + (2048 + 64) + n64 * (4 * kt * 4 * 256 + 64)
-                    + (384 + 16) + (768 + 16) + (2 * kt * 256 + 32))
+                    + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32))
             nodes = spec.nets["read_convolver0"]
             assert rp.pack(nodes, weights.fold(spec, state), 6, winograd=wino).size == want
             convs = [o for o in prog.ops if o.kind == compiler.OP_CONV1D]
@@ -62,8 +62,8 @@ def test_fused_blob_sizes_and_flags():
 
 def test_executed_macs_match_the_kernel_schedule():
     assert rp.executed_macs_per_read(False) == 5052 * 1024          # MFMAs per wave and group of 4 reads (ISA count)
-    # stem: conv1 60 + conv2 120 + conv3/pool 5 tiles x 32 per read = 160 (Winograd; 264 in direct form)
-    assert rp.executed_macs_per_read(True) == (340 + 6 * 144 + 216 + 80 + 320 + 6 * 320) * 1024
+    # stem: conv1 60 + conv2 19 tiles x 16 / 4 waves = 76 (120 direct) + conv3/pool 5 tiles x 32 per read = 160 (264)
+    assert rp.executed_macs_per_read(True) == (296 + 6 * 144 + 216 + 80 + 320 + 6 * 320) * 1024
     assert rp.executed_macs_per_read(True, 2) - rp.executed_macs_per_read(True) == 4 * 320 * 1024
 
 
