@@ -140,13 +140,30 @@ def pack_conv(w: np.ndarray, b: np.ndarray, groups: int = 1):
     return packed, bias
 
 
-def pack_conv_winograd(w: np.ndarray, b: np.ndarray):
-    """[cout, cin, 3] -> [cout][cin/8][4 Winograd taps][8 channels] (hello_amd/csrc/conv_wino.hip), bias [cout]."""
+def winograd_outputs_per_tile(length: int) -> int:
+    """F(3,3) (5 contractions per 3 positions) when the row length is a multiple of 3, else F(2,3) (4 per 2): the
+    rule of ``conv1d_wino_outputs_per_tile`` in hello_amd/csrc/conv_wino.hip."""
+    return 3 if length % 3 == 0 else 2
+
+
+def winograd_taps_f33(w: np.ndarray) -> np.ndarray:
+    """[cout, cin, 3] -> [cout, cin, 5]: the F(3,3) filter transform for the points 0, 1, -1, 2, inf, evaluated in
+    float64 and rounded once: g0/2, -(g0+g1+g2)/2, (-g0+g1-g2)/6, (g0+2g1+4g2)/6, g2."""
+    g = w.astype(np.float64)
+    g0, g1, g2 = g[..., 0], g[..., 1], g[..., 2]
+    u = np.stack([g0 / 2, -(g0 + g1 + g2) / 2, (-g0 + g1 - g2) / 6, (g0 + 2 * g1 + 4 * g2) / 6, g2], axis=-1)
+    return u.astype(np.float32)
+
+
+def pack_conv_winograd(w: np.ndarray, b: np.ndarray, length: int):
+    """[cout, cin, 3] -> [cout][cin/8][T Winograd taps][8 channels] (hello_amd/csrc/conv_wino.hip), bias [cout];
+    T = 5 for rows whose length is a multiple of 3, else 4."""
     from .readconv_pack import winograd_taps
     cout, cin, k = w.shape
     assert k == 3 and cin % 8 == 0
-    u = winograd_taps(w)                                   # [cout, cin, 4]
-    packed = u.reshape(cout, cin // 8, 8, 4).transpose(0, 1, 3, 2).reshape(cout, 4 * cin)
+    u = winograd_taps_f33(w) if winograd_outputs_per_tile(length) == 3 else winograd_taps(w)   # [cout, cin, T]
+    t = u.shape[-1]
+    packed = u.reshape(cout, cin // 8, 8, t).transpose(0, 1, 3, 2).reshape(cout, t * cin)
     return np.ascontiguousarray(packed, dtype=np.float32), b.astype(np.float32)
 
 
@@ -222,8 +239,9 @@ class _Lowering:
         assert x.channels == node.cin, (node.key, x.channels, node.cin)
         w, b = self.folded[node.key]
         wino = self.winograd and self._winograd_ok(node, x)
-        packed, bias = pack_conv_winograd(w, b) if wino else pack_conv(w, b, node.groups)
+        packed, bias = pack_conv_winograd(w, b, x.length) if wino else pack_conv(w, b, node.groups)
         lout = ns.out_length([node], x.length)
+        m = winograd_outputs_per_tile(lout)
         y = self.new(x.domain, lout, node.cout)
         self.ops.append(Op(
             OP_CONV1D, x.domain, src0=x.vid, dst=y.vid, res=res.vid if res is not None else BUF_NONE,
@@ -233,7 +251,7 @@ class _Lowering:
                    | (FLAG_WINOGRAD if wino else 0)),
             w_off=self.blob.add(packed), b_off=self.blob.add(bias), name=node.key,
             macs_per_row=lout * node.cout * (node.cin // node.groups) * node.k,
-            exec_macs_per_row=float(((lout + 1) // 2) * 4 * node.cout * node.cin) if wino else 0.0))
+            exec_macs_per_row=float(-(-lout // m) * (m + 2) * node.cout * node.cin) if wino else 0.0))
         return y
 
     def net(self, nodes, x, head_slot: Optional[int] = None, softmax=False):

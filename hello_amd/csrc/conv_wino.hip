@@ -23,26 +23,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int TPW = 1;          // 32-pair tiles per wave
-constexpr int BMP = 64 * TPW;   // pairs per workgroup
+constexpr int BMP = 64;    // Winograd tiles (pairs or triples of positions) per workgroup
 constexpr int BN = 64;     // channels per workgroup
 }  // namespace
 
-template <int KC>
+// M = outputs per Winograd tile: 2 -> F(2,3), 4 components; 3 -> F(3,3), 5 components (points 0, 1, -1, 2, inf):
+//     V0 = 2(d0-d2) + (d3-d1), V1 = (d3-d1) - (d1+d2), V2 = (d3-d1) + 3(d1-d2), V3 = d3-d1, V4 = (d4-d2) - 2(d3-d1)
+//     y(3p) = M0+M1+M2+M3,  y(3p+1) = M1 - M2 + 2 M3,  y(3p+2) = M1 + M2 + 4 M3 + M4
+// with U = (g0/2, -(g0+g1+g2)/2, (-g0+g1-g2)/6, (g0+2g1+4g2)/6, g2) from the host: 5 contractions per 3
+// positions instead of 9 (1.8x fewer MFMAs; F(2,3) needs 20 for a 9-position row, this 15).  Chosen by the
+// launcher whenever the row length is a multiple of 3 (9, 18, 36, 150), and the weights are packed to match.
+template <int M>
 __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
-    constexpr int CPC = KC / 4;               // input channels per chunk
+    constexpr int NT = M + 2;                 // taps per tile == Winograd components
+    constexpr int CPC = 8;                    // input channels per chunk
+    constexpr int KC = NT * CPC;              // floats per chunk row: [tap][channel]
     constexpr int LD = KC + 4;                // LDS row stride (floats): ds_read_b128 of 16 consecutive rows is conflict-free
     constexpr int QPR = KC / 4;               // float4 per row of a chunk
-    constexpr int RPP = 256 / QPR;            // rows covered per pass of the 256 threads
-    constexpr int NA = BMP / RPP;             // activation float4 per thread per chunk
-    constexpr int NWV = BN / RPP;             // weight float4 per thread per chunk
-    __shared__ __attribute__((aligned(16))) float s_act[BMP * LD];
-    __shared__ __attribute__((aligned(16))) float s_w[BN * LD];
+    constexpr int NQ = (BMP * QPR + 255) / 256;   // float4 per thread per chunk (activations; same for the weights)
+    constexpr int ROWS = (NQ * 256 + QPR - 1) / QPR;   // staged rows incl. the overhang of the last pass (never read)
+    static_assert(BMP == BN, "one staging loop shape for both operands");
+    __shared__ __attribute__((aligned(16))) float s_act[ROWS * LD];
+    __shared__ __attribute__((aligned(16))) float s_w[ROWS * LD];
 
     const int t = threadIdx.x;
-    const int kq = t % QPR, lrow = t / QPR;
     const int L = a.lin;                       // == a.lout
-    const int PP = (L + 1) / 2;                // pairs per row
+    const int PP = (L + M - 1) / M;            // tiles per row
     const long long items = a.m_total / L;
     const long long mp_total = items * PP;
     // One-dimensional grid, XCD-aware: workgroup ids round-robin over the 8 XCDs (each with its own L2), so
@@ -55,128 +61,142 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     const long long m0 = mtile * BMP;
     const int cb0 = (int)(slot % gy) * BN;
     if (m0 >= mp_total) return;
-    const float* src = (const float*)a.src;
+    // Operand staging goes through buffer descriptors (32-bit per-lane byte offsets, the chunk offset in an
+    // SGPR, out-of-range lanes read zeros): the 64 tiles of a workgroup span few rows, so the activation
+    // descriptor starts at the first of them and an offset of 2 GiB marks "zero padding / row past the tile".
+    const long long item0 = m0 / PP;
+    const long long left = (items - item0) * L * a.cin * 4;
+    const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const float*)a.src + item0 * L * a.cin), 0, (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.w + (long long)cb0 * a.kpad), 0, BN * a.kpad * 4, 0x00020000);
 
-    long long row_base[NA];
-    int pos_base[NA];
+    // float4 number i = t + 256 j of a chunk is (row i / QPR, tap (i % QPR) / 2, channel half i & 1); the last pass
+    // overhangs the tile (rows >= 64): those lanes load zeros into LDS rows nobody reads
+    unsigned act_off[NQ], w_off[NQ];
+    int lds_off[NQ];
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        const long long mg = m0 + lrow + RPP * j;
-        if (mg < mp_total) {
+    for (int j = 0; j < NQ; ++j) {
+        const int i = t + 256 * j;
+        const int row = i / QPR, q = i - row * QPR;
+        const int tap = q >> 1, csub = (q & 1) * 4;
+        lds_off[j] = row * LD + q * 4;
+        w_off[j] = (unsigned)(row * a.kpad + q * 4) * 4u;
+        const long long mg = m0 + row;
+        act_off[j] = 0x80000000u;
+        if (row < BMP && mg < mp_total) {
             const long long item = mg / PP;
-            const int p = (int)(mg - item * PP);
-            row_base[j] = item * L;
-            pos_base[j] = 2 * p - 1;
-        } else {
-            row_base[j] = 0;
-            pos_base[j] = -(1 << 28);
+            const int pos = M * (int)(mg - item * PP) - 1 + tap;
+            if (pos >= 0 && pos < L) act_off[j] = (unsigned)(((int)(item - item0) * L + pos) * a.cin + csub) * 4u;
         }
     }
 
-    f32x4 ra[NA], rw[NWV];
-    const int tap = kq / (CPC / 4), csub = (kq % (CPC / 4)) * 4;
+    f32x4 ra[NQ], rw[NQ];
     auto prefetch = [&](int kb) {
-        const int c = kb * CPC + csub;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int pos = pos_base[j] + tap;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pos >= 0 && pos < L) v = *(const f32x4*)(src + ((row_base[j] + pos) * a.cin + c));
-            ra[j] = v;
+        for (int j = 0; j < NQ; ++j) {
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc, act_off[j], kb * CPC * 4, 0));
+            rw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off[j], kb * KC * 4, 0));
         }
-#pragma unroll
-        for (int j = 0; j < NWV; ++j)
-            rw[j] = *(const f32x4*)(a.w + (long long)(cb0 + lrow + RPP * j) * a.kpad + kb * KC + kq * 4);
     };
 
     const int wave = t >> 6, lane = t & 63;
     const int lj = lane & 31, lh = lane >> 5;
     const int wn = wave & 1;                   // 32-channel block of this wave
-    const int ptile0 = (wave >> 1) * 32 * TPW;       // first pair of this wave
-    f32x16 acc[4][TPW];
+    const int ptile0 = (wave >> 1) * 32;       // first tile of this wave
+    f32x16 acc[NT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NT; ++c)
 #pragma unroll
-        for (int tp = 0; tp < TPW; ++tp)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][tp][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
     const int nchunks = a.cin / CPC;
     prefetch(0);
     for (int kb = 0; kb < nchunks; ++kb) {
         __syncthreads();   // previous chunk's operand reads are done
 #pragma unroll
-        for (int j = 0; j < NA; ++j) *(f32x4*)&s_act[(lrow + RPP * j) * LD + kq * 4] = ra[j];
-#pragma unroll
-        for (int j = 0; j < NWV; ++j) *(f32x4*)&s_w[(lrow + RPP * j) * LD + kq * 4] = rw[j];
+        for (int j = 0; j < NQ; ++j) {
+            *(f32x4*)&s_act[lds_off[j]] = ra[j];
+            *(f32x4*)&s_w[lds_off[j]] = rw[j];
+        }
         __syncthreads();
         if (kb + 1 < nchunks) prefetch(kb + 1);
+        f32x4 wa[NT], d[NT], v[NT];
+        // the host packs the taps per 8-channel group ([cin/8][components][8])
 #pragma unroll
-        for (int g = 0; g < CPC / 8; ++g) {
-            f32x4 wa[4];
+        for (int c = 0; c < NT; ++c) wa[c] = *(const f32x4*)&s_w[(wn * 32 + lj) * LD + c * CPC + lh * 4];
+        const float* row = &s_act[(ptile0 + lj) * LD + lh * 4];
 #pragma unroll
-            // the host packs the taps per 8-channel group ([cin/8][4 components][8]) whatever the chunk size is
-            for (int c = 0; c < 4; ++c) wa[c] = *(const f32x4*)&s_w[(wn * 32 + lj) * LD + (g * 4 + c) * 8 + lh * 4];
-#pragma unroll
-            for (int tp = 0; tp < TPW; ++tp) {
-                const float* row = &s_act[(ptile0 + tp * 32 + lj) * LD + g * 8 + lh * 4];
-                const f32x4 d0 = *(const f32x4*)(row), d1 = *(const f32x4*)(row + CPC);
-                const f32x4 d2 = *(const f32x4*)(row + 2 * CPC), d3 = *(const f32x4*)(row + 3 * CPC);
-                f32x4 v[4];
-                v[0] = d0 - d2;
-                v[1] = d1 + d2;
-                v[2] = d2 - d1;
-                v[3] = d1 - d3;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[c][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][e], v[c][e], acc[c][tp], 0, 0, 0);
-            }
+        for (int c = 0; c < NT; ++c) d[c] = *(const f32x4*)(row + c * CPC);
+        if constexpr (M == 2) {
+            v[0] = d[0] - d[2];
+            v[1] = d[1] + d[2];
+            v[2] = d[2] - d[1];
+            v[3] = d[1] - d[3];
+        } else {
+            const f32x4 s31 = d[3] - d[1];
+            v[0] = 2.f * (d[0] - d[2]) + s31;
+            v[1] = s31 - (d[1] + d[2]);
+            v[2] = 3.f * (d[1] - d[2]) + s31;
+            v[3] = s31;
+            v[4] = (d[4] - d[2]) - 2.f * s31;
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][e], v[c][e], acc[c], 0, 0, 0);
     }
 
-    // epilogue: accumulator register r of lane (lj, lh) is channel (r&3) + 8*(r>>2) + 4*lh, pair lj.
+    // epilogue: accumulator register r of lane (lj, lh) is channel (r&3) + 8*(r>>2) + 4*lh, tile lj.
     // The residual rows of a tile are all requested before the first is used (their latency overlaps the
     // output transform instead of being paid once per 16-byte piece).
+    const long long mg = m0 + ptile0 + lj;
+    if (mg >= mp_total) return;
+    const long long item = mg / PP;
+    const int p = (int)(mg - item * PP);
+    bool live[M];                              // F(3,3) rows are whole triples
 #pragma unroll
-    for (int tp = 0; tp < TPW; ++tp) {
-        const long long mg = m0 + ptile0 + tp * 32 + lj;
-        if (mg >= mp_total) continue;
-        const long long item = mg / PP;
-        const int p = (int)(mg - item * PP);
-        const bool second = 2 * p + 1 < L;
-        const int ch0 = cb0 + wn * 32 + 4 * lh;
-        const long long o = (item * L + 2 * p) * a.cout + ch0;
-        f32x4 r0[4], r1[4];
-        if (a.res) {
+    for (int u = 0; u < M; ++u) live[u] = M == 3 || M * p + u < L;
+    const int ch0 = cb0 + wn * 32 + 4 * lh;
+    const long long o = (item * L + M * p) * a.cout + ch0;
+    f32x4 res[M][4];
+    if (a.res) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                r0[q] = *(const f32x4*)(a.res + o + 8 * q);
-                r1[q] = second ? *(const f32x4*)(a.res + o + a.cout + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < M; ++u)
+                res[u][q] = live[u] ? *(const f32x4*)(a.res + o + u * a.cout + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *(const f32x4*)(a.bias + ch0 + 8 * q);
+        f32x4 y[M];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x[M];
+            if constexpr (M == 2) {
+                const float m0v = acc[0][4 * q + e], m1v = acc[1][4 * q + e];
+                const float m2v = acc[2][4 * q + e], m3v = acc[3][4 * q + e];
+                x[0] = ((m0v + m1v) + m2v) + b4[e];
+                x[1] = ((m1v - m2v) - m3v) + b4[e];
+            } else {
+                const float m0v = acc[0][4 * q + e], m1v = acc[1][4 * q + e], m2v = acc[2][4 * q + e];
+                const float m3v = acc[3][4 * q + e], m4v = acc[4][4 * q + e];
+                const float sum = m1v + m2v, dif = m1v - m2v;
+                x[0] = ((m0v + sum) + m3v) + b4[e];
+                x[1] = (dif + 2.f * m3v) + b4[e];
+                x[2] = ((sum + 4.f * m3v) + m4v) + b4[e];
             }
+#pragma unroll
+            for (int u = 0; u < M; ++u)
+                y[u][e] = a.relu == 1 ? fmaxf(x[u], 0.f)
+                                      : (a.relu == 2 ? (x[u] > 20.f ? x[u] : __logf(1.f + __expf(x[u]))) : x[u]);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = *(const f32x4*)(a.bias + ch0 + 8 * q);
-            f32x4 y0, y1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float m0v = acc[0][tp][4 * q + e], m1v = acc[1][tp][4 * q + e];
-                const float m2v = acc[2][tp][4 * q + e], m3v = acc[3][tp][4 * q + e];
-                const float x0 = ((m0v + m1v) + m2v) + b4[e], x1 = ((m1v - m2v) - m3v) + b4[e];
-                y0[e] = a.relu == 1 ? fmaxf(x0, 0.f) : (a.relu == 2 ? (x0 > 20.f ? x0 : __logf(1.f + __expf(x0))) : x0);
-                y1[e] = a.relu == 1 ? fmaxf(x1, 0.f) : (a.relu == 2 ? (x1 > 20.f ? x1 : __logf(1.f + __expf(x1))) : x1);
-            }
-            if (a.res) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    y0[e] += r0[q][e];
-                    y1[e] += r1[q][e];
-                }
-            }
-            *(f32x4*)(a.dst + o + 8 * q) = y0;
-            if (second) *(f32x4*)(a.dst + o + a.cout + 8 * q) = y1;
+        for (int u = 0; u < M; ++u) {
+            if (a.res) y[u] += res[u][q];
+            if (live[u]) *(f32x4*)(a.dst + o + u * a.cout + 8 * q) = y[u];
         }
     }
 }
@@ -186,16 +206,22 @@ bool conv1d_wino_supported(const ConvArgs& a) {
            (a.cout % BN) == 0;
 }
 
+int conv1d_wino_outputs_per_tile(int length) { return length % 3 == 0 ? 3 : 2; }
+
 hipError_t launch_conv1d_wino(const ConvArgs& a, hipStream_t stream) {
     if (a.m_total <= 0) return hipSuccess;
-    if (!conv1d_wino_supported(a) || a.kpad != 4 * a.cin) return hipErrorInvalidValue;
-    const long long pairs = (a.m_total / a.lin) * ((a.lin + 1) / 2);
-    const long long mtiles8 = ((pairs + BMP - 1) / BMP + 7) / 8 * 8;       // tiles of pairs, a multiple of the XCD count
+    const int m = conv1d_wino_outputs_per_tile(a.lin);
+    if (!conv1d_wino_supported(a) || a.kpad != (m + 2) * a.cin) return hipErrorInvalidValue;
+    const long long tiles = (a.m_total / a.lin) * ((a.lin + m - 1) / m);
+    const long long mtiles8 = ((tiles + BMP - 1) / BMP + 7) / 8 * 8;       // workgroup rows, a multiple of the XCD count
     const dim3 grid((unsigned)(mtiles8 * (a.cout / BN)));
-    // measured on the allele stage (8 192 sites): 64 pairs x 64 channels per workgroup at three waves per SIMD
-    // (4 accumulator tiles per wave, 132 VGPRs) 3.41 ms; 128 pairs (8 tiles, two waves per SIMD) 3.60 ms with
+    // measured on the allele stage (8 192 sites), F(2,3): 64 pairs x 64 channels per workgroup at three waves per
+    // SIMD (4 accumulator tiles per wave, 132 VGPRs) 3.41 ms; 128 pairs (8 tiles, two waves per SIMD) 3.60 ms with
     // 16-channel chunks and 3.84 ms with 8-channel chunks; 8 waves x 128 channels with double-buffered LDS 4.26 ms
-    hipLaunchKernelGGL((conv1d_wino_kernel<32>), grid, dim3(256), 0, stream, a);
+    if (m == 3)
+        hipLaunchKernelGGL((conv1d_wino_kernel<3>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((conv1d_wino_kernel<2>), grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

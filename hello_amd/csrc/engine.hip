@@ -231,7 +231,8 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
         if (o.kind == HELLO_OP_CONV1D) {
             const bool wino = (o.flags & HELLO_FLAG_WINOGRAD) != 0;
             const size_t cpad = wino ? (size_t)o.cout : (size_t)((o.cout + 31) / 32) * 32;
-            const size_t kpad = wino ? (size_t)4 * o.cin : (size_t)((o.k * o.cin + 31) / 32) * 32;
+            const size_t kpad = wino ? (size_t)(hello::conv1d_wino_outputs_per_tile(o.lin) + 2) * o.cin
+                                     : (size_t)((o.k * o.cin + 31) / 32) * 32;
             w_end = (size_t)o.w_off + cpad * kpad;
             b_end = (size_t)o.b_off + cpad;
         } else if (o.kind == HELLO_OP_HEAD) {
@@ -587,7 +588,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.wino = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
                 if (!a.src) return fail(HELLO_ERR_ARG, "op %d reads an input the caller did not supply", op_index);
                 if (a.wino) {
-                    a.kpad = 4 * o.cin;
+                    a.kpad = (hello::conv1d_wino_outputs_per_tile(o.lin) + 2) * o.cin;
                     a.cout_pad = o.cout;
                     if (!hello::conv1d_wino_supported(a))
                         return fail(HELLO_ERR_MODEL, "op %d: this convolution has no Winograd form", op_index);

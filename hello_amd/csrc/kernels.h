@@ -19,10 +19,12 @@ struct ConvArgs {
     int cout_pad;         // multiple of 32
     int relu;                  // activation: 0 none, 1 ReLU, 2 Softplus (beta 1, threshold 20)
     int src_u8;
-    int wino;                  // Winograd F(2,3) form (conv_wino.hip): w packed [cout][cin/8][4 components][8], kpad = 4*cin
+    int wino;                  // Winograd form (conv_wino.hip): F(3,3) when lin % 3 == 0, else F(2,3); w packed
+                               // [cout][cin/8][T components][8], kpad = T*cin, T = outputs per tile + 2
 };
 hipError_t launch_conv1d(const ConvArgs& a, hipStream_t stream);
 bool conv1d_wino_supported(const ConvArgs& a);
+int conv1d_wino_outputs_per_tile(int length);      // 3 when the row length is a multiple of 3, else 2
 hipError_t launch_conv1d_wino(const ConvArgs& a, hipStream_t stream);
 
 hipError_t launch_maxpool(const float* src, float* dst, long long rows, int lin, int lout, int c,

@@ -27,15 +27,35 @@ def test_filter_transform_reproduces_the_direct_convolution():
     np.testing.assert_allclose(out, _direct(x.astype(np.float64), w.astype(np.float64)), rtol=1e-6, atol=1e-6)
 
 
+def test_f33_filter_transform_reproduces_the_direct_convolution():
+    """F(3,3) on the points 0, 1, -1, 2, inf as conv_wino.hip evaluates it (rows whose length is a multiple of 3)."""
+    rng = np.random.default_rng(2)
+    w = rng.standard_normal((8, 16, 3)).astype(np.float32)
+    x = rng.standard_normal((16, 9)).astype(np.float32)
+    u = compiler.winograd_taps_f33(w).astype(np.float64)            # [cout, cin, 5]
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1)))
+    out = np.empty((8, 9))
+    for p in range(3):                                              # triples of positions (3p, 3p+1, 3p+2)
+        d = [xp[:, 3 * p + i] for i in range(5)]
+        s31 = d[3] - d[1]
+        v = [2 * (d[0] - d[2]) + s31, s31 - (d[1] + d[2]), 3 * (d[1] - d[2]) + s31, s31, (d[4] - d[2]) - 2 * s31]
+        m = [u[:, :, c] @ v[c] for c in range(5)]
+        out[:, 3 * p] = m[0] + m[1] + m[2] + m[3]
+        out[:, 3 * p + 1] = m[1] - m[2] + 2 * m[3]
+        out[:, 3 * p + 2] = m[1] + m[2] + 4 * m[3] + m[4]
+    np.testing.assert_allclose(out, _direct(x.astype(np.float64), w.astype(np.float64)), rtol=1e-6, atol=1e-6)
+
+
 def test_generic_winograd_weight_layout():
     rng = np.random.default_rng(1)
     w = rng.standard_normal((64, 24, 3)).astype(np.float32)
     b = rng.standard_normal(64).astype(np.float32)
-    packed, bias = compiler.pack_conv_winograd(w, b)
-    assert packed.shape == (64, 4 * 24) and np.array_equal(bias, b)
-    u = rp.winograd_taps(w)
-    for o, c, comp in [(0, 0, 0), (5, 9, 2), (63, 23, 3), (17, 16, 1)]:
-        assert packed[o, (c // 8) * 32 + comp * 8 + c % 8] == u[o, c, comp]     # [cin/8][component][8]
+    assert [compiler.winograd_outputs_per_tile(n) for n in (9, 18, 36, 150, 71, 121, 250)] == [3, 3, 3, 3, 2, 2, 2]
+    for length, taps, u in ((71, 4, rp.winograd_taps(w)), (18, 5, compiler.winograd_taps_f33(w))):
+        packed, bias = compiler.pack_conv_winograd(w, b, length)
+        assert packed.shape == (64, taps * 24) and np.array_equal(bias, b)
+        for o, c, comp in [(0, 0, 0), (5, 9, 2), (63, 23, taps - 1), (17, 16, 1)]:
+            assert packed[o, (c // 8) * 8 * taps + comp * 8 + c % 8] == u[o, c, comp]     # [cin/8][component][8]
 
 
 def test_fused_blob_sizes_and_flags():
@@ -57,7 +77,8 @@ def test_fused_blob_sizes_and_flags():
             for o in convs:                                         # only k3/s1/p1 convs with cout % 64 == 0 qualify
                 if o.flags & compiler.FLAG_WINOGRAD:
                     assert (o.k, o.stride, o.pad) == (3, 1, 1) and o.cout % 64 == 0 and o.cin % 8 == 0
-                    assert o.exec_macs_per_row == ((o.lout + 1) // 2) * 4 * o.cin * o.cout < o.macs_per_row
+                    m = compiler.winograd_outputs_per_tile(o.lout)
+                    assert o.exec_macs_per_row == -(-o.lout // m) * (m + 2) * o.cin * o.cout < o.macs_per_row
 
 
 def test_executed_macs_match_the_kernel_schedule():
