@@ -33,7 +33,8 @@ constexpr int BN = 64;     // channels per workgroup
 // with U = (g0/2, -(g0+g1+g2)/2, (-g0+g1-g2)/6, (g0+2g1+4g2)/6, g2) from the host: 5 contractions per 3
 // positions instead of 9 (1.8x fewer MFMAs; F(2,3) needs 20 for a 9-position row, this 15).  Chosen by the
 // launcher whenever the row length is a multiple of 3 (9, 18, 36, 150), and the weights are packed to match.
-template <int M>
+// ACT: 0 none | 1 ReLU | 2 Softplus; RES: a residual input is added after the activation.
+template <int M, int ACT, bool RES>
 __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     constexpr int NT = M + 2;                 // taps per tile == Winograd components
     constexpr int CPC = 8;                    // input channels per chunk
@@ -153,15 +154,16 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     // output transform instead of being paid once per 16-byte piece).
     const long long mg = m0 + ptile0 + lj;
     if (mg >= mp_total) return;
-    const long long item = mg / PP;
-    const int p = (int)(mg - item * PP);
+    const unsigned local = (unsigned)(mg - item0 * PP);        // tiles past the first row's start: small
+    const unsigned irow = local / (unsigned)PP;
+    const int p = (int)(local - irow * (unsigned)PP);
     bool live[M];                              // F(3,3) rows are whole triples
 #pragma unroll
     for (int u = 0; u < M; ++u) live[u] = M == 3 || M * p + u < L;
     const int ch0 = cb0 + wn * 32 + 4 * lh;
-    const long long o = (item * L + M * p) * a.cout + ch0;
+    const long long o = ((item0 + irow) * L + M * p) * a.cout + ch0;
     f32x4 res[M][4];
-    if (a.res) {
+    if constexpr (RES) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -190,12 +192,12 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < M; ++u)
-                y[u][e] = a.relu == 1 ? fmaxf(x[u], 0.f)
-                                      : (a.relu == 2 ? (x[u] > 20.f ? x[u] : __logf(1.f + __expf(x[u]))) : x[u]);
+                y[u][e] = ACT == 1 ? fmaxf(x[u], 0.f)
+                                   : (ACT == 2 ? (x[u] > 20.f ? x[u] : __logf(1.f + __expf(x[u]))) : x[u]);
         }
 #pragma unroll
         for (int u = 0; u < M; ++u) {
-            if (a.res) y[u] += res[u][q];
+            if constexpr (RES) y[u] += res[u][q];
             if (live[u]) *(f32x4*)(a.dst + o + u * a.cout + 8 * q) = y[u];
         }
     }
@@ -218,10 +220,16 @@ hipError_t launch_conv1d_wino(const ConvArgs& a, hipStream_t stream) {
     // measured on the allele stage (8 192 sites), F(2,3): 64 pairs x 64 channels per workgroup at three waves per
     // SIMD (4 accumulator tiles per wave, 132 VGPRs) 3.41 ms; 128 pairs (8 tiles, two waves per SIMD) 3.60 ms with
     // 16-channel chunks and 3.84 ms with 8-channel chunks; 8 waves x 128 channels with double-buffered LDS 4.26 ms
-    if (m == 3)
-        hipLaunchKernelGGL((conv1d_wino_kernel<3>), grid, dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((conv1d_wino_kernel<2>), grid, dim3(256), 0, stream, a);
+    const int variant = (m == 3 ? 6 : 0) + (a.relu < 0 || a.relu > 2 ? 0 : a.relu) * 2 + (a.res ? 1 : 0);
+    switch (variant) {
+#define HELLO_WINO_CASE(V, MM, ACT, RES) \
+    case V: hipLaunchKernelGGL((conv1d_wino_kernel<MM, ACT, RES>), grid, dim3(256), 0, stream, a); break;
+        HELLO_WINO_CASE(0, 2, 0, false) HELLO_WINO_CASE(1, 2, 0, true) HELLO_WINO_CASE(2, 2, 1, false)
+        HELLO_WINO_CASE(3, 2, 1, true) HELLO_WINO_CASE(4, 2, 2, false) HELLO_WINO_CASE(5, 2, 2, true)
+        HELLO_WINO_CASE(6, 3, 0, false) HELLO_WINO_CASE(7, 3, 0, true) HELLO_WINO_CASE(8, 3, 1, false)
+        HELLO_WINO_CASE(9, 3, 1, true) HELLO_WINO_CASE(10, 3, 2, false) HELLO_WINO_CASE(11, 3, 2, true)
+#undef HELLO_WINO_CASE
+    }
     return hipGetLastError();
 }
 
