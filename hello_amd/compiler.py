@@ -90,7 +90,7 @@ class Program:
     buffers: List[Tuple[int, int]]          # (domain, floats_per_row) per physical buffer id
     weights: np.ndarray                      # float32 blob
     fused_read_convolver: bool = False
-    winograd: bool = False           # k3/s1/p1 convolutions run in Winograd F(2,3) form where a kernel offers it
+    winograd: bool = False           # k3/s1/p1 convolutions run in Winograd form (F(2,3) / F(3,3)) where a kernel offers it
 
     def describe(self) -> str:
         lines = [f"program {self.spec_name}: {len(self.ops)} ops, {len(self.buffers)} buffers, "
