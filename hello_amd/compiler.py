@@ -146,13 +146,7 @@ def winograd_outputs_per_tile(length: int) -> int:
     return 3 if length % 3 == 0 else 2
 
 
-def winograd_taps_f33(w: np.ndarray) -> np.ndarray:
-    """[cout, cin, 3] -> [cout, cin, 5]: the F(3,3) filter transform for the points 0, 1, -1, 2, inf, evaluated in
-    float64 and rounded once: g0/2, -(g0+g1+g2)/2, (-g0+g1-g2)/6, (g0+2g1+4g2)/6, g2."""
-    g = w.astype(np.float64)
-    g0, g1, g2 = g[..., 0], g[..., 1], g[..., 2]
-    u = np.stack([g0 / 2, -(g0 + g1 + g2) / 2, (-g0 + g1 - g2) / 6, (g0 + 2 * g1 + 4 * g2) / 6, g2], axis=-1)
-    return u.astype(np.float32)
+from .readconv_pack import winograd_taps_f33  # noqa: E402  (the F(3,3) filter transform; also used by the fused kernel's packing)
 
 
 def pack_conv_winograd(w: np.ndarray, b: np.ndarray, length: int):
@@ -347,7 +341,7 @@ class _Lowering:
         if fusable:
             _, l1, _, l2, _, _ = readconv_pack.geometry(spec.window)
             y = self.new(ROWS_ALLELES, l2, 64)
-            w_off = self.blob.add(readconv_pack.pack(nodes, self.folded, cin, winograd=self.winograd))
+            w_off = self.blob.add(readconv_pack.pack(nodes, self.folded, cin, winograd=self.winograd, window=spec.window))
             wflag = FLAG_WINOGRAD if self.winograd else 0
             if self.fused == "trunk":
                 # stem layer by layer (3 valid convs + max pool), fused residual trunk + segment sum

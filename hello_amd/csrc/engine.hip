@@ -239,7 +239,7 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
             w_end = (size_t)o.w_off + (size_t)o.cout * o.cin;
             b_end = (size_t)o.b_off + o.cout;
         } else if (o.kind == HELLO_OP_READCONV_FUSED) {
-            w_end = (size_t)o.w_off + hello::readconv_weight_floats(o.k, (o.flags & HELLO_FLAG_WINOGRAD) != 0);
+            w_end = (size_t)o.w_off + hello::readconv_weight_floats(o.k, (o.flags & HELLO_FLAG_WINOGRAD) != 0, desc->window);
             b_end = (size_t)o.b_off;
         }
         if (w_end > e->n_weight_floats || b_end > e->n_weight_floats) {
@@ -652,7 +652,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.groups_per_wg = hello::readconv_groups_per_workgroup(a.n_reads, d.window);
                 a.extra_blocks = o.k;
                 a.winograd = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
-                if ((size_t)o.w_off + hello::readconv_weight_floats(o.k, a.winograd) > e->n_weight_floats)
+                if ((size_t)o.w_off + hello::readconv_weight_floats(o.k, a.winograd, d.window) > e->n_weight_floats)
                     return fail(HELLO_ERR_MODEL, "op %d: fused read-convolver weight block truncated", op_index);
                 HIP_TRY(hello::launch_readconv_fused(a, stream));
                 HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,

@@ -77,7 +77,7 @@ bool readconv_supports_window(int window);
 int readconv_reads_per_group(int window);
 int readconv_frame_rows(int window);       // positions per read after the read convolver: 36 | 61
 int readconv_groups_per_workgroup(long long n_reads, int window);
-int readconv_weight_floats(int extra_blocks, bool winograd);
+int readconv_weight_floats(int extra_blocks, bool winograd, int window);   // 150 bp + Winograd: 64-channel blocks in F(3,3) form
 bool readconv_supports_extra_blocks(int extra_blocks);
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
 // frames[a] = sum of the partial slots of allele a, in slot order

@@ -51,17 +51,20 @@ namespace rc {
 // convolutions of the identity-shortcut residual blocks are stored in their Winograd F(2,3) form: KT = 4
 // transformed taps U = G g (computed on the host in float64) instead of 3.
 constexpr int S1_STEPS = 6;                                // stem conv1: K = 3*C <= 21 -> 6 MFMA steps of 4
-template <bool WINO>
+// With F33 the 64-channel identity-shortcut residual blocks are stored in F(3,3) form: 5 transformed taps, ordered
+// [COUT/16][CIN/16][5][64 lanes][4] (wino3_layer walks the input groups in its outer loop).
+template <bool WINO, bool F33 = false>
 struct Offs {
     static constexpr int KT = WINO ? 4 : 3;
     static constexpr int W3232 = 2 * KT * 2 * 256, W3264 = 4 * 3 * 2 * 256, W3264S = 4 * 1 * 2 * 256;
     static constexpr int W6464 = 4 * KT * 4 * 256;
+    static constexpr int W6464D = F33 ? 4 * 5 * 4 * 256 : W6464;      // a convolution of the 64-channel residual blocks
     static constexpr int OFF_B = 0;                                   // 6 convs 32->32 (residual blocks)
     static constexpr int OFF_C1 = OFF_B + 6 * (W3232 + 32);           // 32->64 k3 s2
     static constexpr int OFF_SC = OFF_C1 + W3264 + 64;                // 32->64 k1 s2
     static constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3 of the strided block
     static constexpr int OFF_D = OFF_C2 + W6464 + 64;                 // 6 convs 64->64 (residual blocks)
-    static constexpr int W_TRUNK = OFF_D + 6 * (W6464 + 64);
+    static constexpr int W_TRUNK = OFF_D + 6 * (W6464D + 64);
     static constexpr int OFF_S1 = W_TRUNK;                            // [6 steps][64 lanes], bias[16]
     static constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps | 4 Winograd taps][64 lanes][4], bias[16]
     static constexpr int OFF_S3 = OFF_S2 + KT * 256 + 16;             // [2 blocks][3 taps | 4 Winograd taps][64 lanes][4], bias[32]
@@ -69,7 +72,7 @@ struct Offs {
     // transfer-learning models append identity-shortcut 64-channel blocks (read_convolver_addendum.py); their
     // weights follow the canonical blob.  First conv of 64-channel block `blk`:
     static constexpr int off_d(int blk) {
-        return blk < 3 ? OFF_D + 2 * blk * (W6464 + 64) : W_TOTAL + 2 * (blk - 3) * (W6464 + 64);
+        return blk < 3 ? OFF_D + 2 * blk * (W6464D + 64) : W_TOTAL + 2 * (blk - 3) * (W6464D + 64);
     }
 };
 
@@ -98,6 +101,9 @@ struct Cfg {
     // boundary are zeroed at the source instead); an odd L2 takes one shared zero row, like the 32-channel image
     static constexpr bool COMPACT = (L2 % 2) == 0;
     static constexpr int RS2 = COMPACT ? L2 : L2 + 1;
+    // the compact image is whole tiles of 16 TRIPLES of rows (and a read is whole triples): its residual blocks
+    // run in Winograd F(3,3) form (wino3_layer)
+    static constexpr bool F33 = COMPACT && (RS2 % 3) == 0 && ((RS2 * G_) % 48) == 0;
     static constexpr int NTT = (L1 + 6) / 7;           // stem pool tiles per read (7 pooled outputs each)
     static constexpr int WPR = NW_ / G_;               // waves sharing a read in the stem pool
     static_assert(RS1 % 2 == 0 && RS2 % 2 == 0 && NW_ % G_ == 0, "pairs of rows must not straddle reads");
@@ -122,14 +128,16 @@ struct Cfg {
 };
 }  // namespace rc
 
-int readconv_weight_floats(int extra_blocks, bool winograd) {
-    return winograd ? rc::Offs<true>::off_d(3 + extra_blocks) : rc::Offs<false>::off_d(3 + extra_blocks);
-}
-bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0 || extra_blocks == 2; }
-
 using Geometry = rc::Cfg<4, 4, 150>;      // 4 reads x 4 waves per workgroup, two workgroups per CU
 using Geometry250 = rc::Cfg<2, 4, 250>;   // 250 bp windows: 2 reads per workgroup fill the same LDS
 using GeometrySoftplus = rc::Cfg<4, 4, 150, rc::ACT_SOFTPLUS>;
+static_assert(Geometry::F33 && GeometrySoftplus::F33 && !Geometry250::F33, "weight packing rule of readconv_pack.py");
+int readconv_weight_floats(int extra_blocks, bool winograd, int window) {
+    if (!winograd) return rc::Offs<false>::off_d(3 + extra_blocks);
+    return window == 150 ? rc::Offs<true, true>::off_d(3 + extra_blocks) : rc::Offs<true>::off_d(3 + extra_blocks);
+}
+bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0 || extra_blocks == 2; }
+
 bool readconv_supports_window(int window) { return window == 150 || window == 250; }
 int readconv_reads_per_group(int window) { return window == 250 ? Geometry250::G : Geometry::G; }
 int readconv_frame_rows(int window) { return window == 250 ? Geometry250::L2 : Geometry::L2; }
@@ -170,11 +178,16 @@ __device__ __forceinline__ int swz(int row) {
 // they carry a swizzle (SW_W) that makes rows r, r+2, ..., r+30 conflict-free instead of r, r+1, ..., r+15:
 // at 64 channels chunk ^ 2*((row>>1)&7); at 32 channels (a row is half the banks) rows 4a+1 and 4a+2 also
 // trade places and the chunk is XORed with 2*((row>>2)&3).
-enum { SW_OLD = 0, SW_W = 1 };
+// SW_3 (64 channels): images walked THREE rows per lane (F(3,3) layers): chunk ^ 2*((row/3)&7); rows 3j..3j+2 share
+// their swizzle, and 16 lanes' rows 3j+i hit 16 distinct bank groups.
+enum { SW_OLD = 0, SW_W = 1, SW_3 = 2 };
 template <int C, int SW>
 __device__ __forceinline__ int img_off(int row, int chunk) {     // float offset of 16-byte chunk `chunk` of `row`
     if constexpr (SW == SW_OLD) {
         return row * C + 4 * (chunk ^ swz<C>(row));
+    } else if constexpr (SW == SW_3) {
+        static_assert(C == 64, "SW_3 images have 64 channels");
+        return row * 64 + 4 * (chunk ^ (2 * ((row / 3) & 7)));
     } else if constexpr (C == 64) {
         return row * 64 + 4 * (chunk ^ (2 * ((row >> 1) & 7)));
     } else {
@@ -445,7 +458,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
 // (requested one step ahead), 16 VALU, 16 MFMAs.  `w` holds U for this wave's 16 output channels:
 // w[c * C/16 + m]; with ROLL it is refilled in place with the next layer's registers after their last use.
 //   zmask   (32 channels) bit k: this lane's odd row of the wave's k-th tile is a shared zero row
-template <class CF, int C, int MODE, bool ROLL, bool FLIP = false>
+template <class CF, int C, int MODE, bool ROLL, bool FLIP = false, int SOUT = SW_W>
 __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* __restrict__ out,
                                            f32x4 (&w)[4 * C / 16], const float* __restrict__ next_w,
                                            const float* __restrict__ bias, unsigned zmask, float* __restrict__ dump,
@@ -473,8 +486,9 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
 #pragma unroll
     for (int s = 0; s < 2 * M; ++s) opb[s] = in + 32 * pg * C + img_off<C, SW_W>(2 * j + 2 * (s / M), 4 * (s % M) + q);
     constexpr int ODD = 64;                                                  // img_off(r + 1, c) - img_off(r, c), r even
-    float* const o0 = out + 32 * pg * C + img_off<C, SW_W>(2 * j + 1, 4 * cb + q);   // flat row 2P   = image row 2P + 1
-    float* const o1 = out + 32 * pg * C + img_off<C, SW_W>(2 * j + 2, 4 * cb + q);   // flat row 2P+1 = image row 2P + 2
+    static_assert(SOUT == SW_W || (C == 64 && NPG == 1 && MODE != MODE_RESID_INPLACE), "another output swizzle: one position group, not in place");
+    float* const o0 = out + 32 * pg * C + img_off<C, SOUT>(2 * j + 1, 4 * cb + q);   // flat row 2P   = image row 2P + 1
+    float* const o1 = out + 32 * pg * C + img_off<C, SOUT>(2 * j + 2, 4 * cb + q);   // flat row 2P+1 = image row 2P + 2
     const bool last_tile_here = !HAS_TAIL || (pg + NPG * (ITER - 1)) < NT;   // wave-uniform
 
     f32x4 ring[2][4];
@@ -524,6 +538,10 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
         }
         float* p0 = o0 + kk * TOFF;
         float* p1 = o1 + kk * TOFF;
+        if constexpr (SOUT != SW_W) {                                         // a swizzle without the tiles' 32-row period
+            p0 = out + img_off<C, SOUT>(32 * kk + 2 * j + 1, 4 * cb + q);
+            p1 = out + img_off<C, SOUT>(32 * kk + 2 * j + 2, 4 * cb + q);
+        }
         if constexpr (16 * (NT - 1) + 15 >= PAIRS && kk == ITER - 1) {       // only the last tile can overrun
             const bool ok = 16 * (pg + NPG * kk) + j < PAIRS;
             p0 = ok ? p0 : dump;
@@ -571,6 +589,137 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
         if constexpr (u == NU - 1) {
             if (!tail || last_tile_here) epi_store(std::integral_constant<int, ITER - 1>{});
         }
+    });
+}
+
+// ---- Winograd F(3,3) form of a k = 3, stride 1, pad 1 convolution 64 -> 64 over the compact image ---------
+// Three neighbouring outputs share five inputs d0..d4 (image rows 3T .. 3T+4 for the triple T of flat rows 3T..3T+2);
+// interpolation points 0, 1, -1, 2, inf:
+//     V0 = 2(d0-d2) + (d3-d1), V1 = (d3-d1) - (d1+d2), V2 = 3(d1-d2) + (d3-d1), V3 = d3-d1, V4 = (d4-d2) - 2(d3-d1)
+//     Mc = Uc * Vc over the input channels, c = 0..4, U = (g0/2, -(g0+g1+g2)/2, (-g0+g1-g2)/6, (g0+2g1+4g2)/6, g2)
+//     y(3T) = M0+M1+M2+M3,  y(3T+1) = M1 - M2 + 2 M3,  y(3T+2) = M1 + M2 + 4 M3 + M4
+// i.e. 5 contractions per 3 positions instead of 9 (F(2,3): 6).  The group's 144 rows are exactly 3 tiles of 16
+// triples (F(2,3): 72 pairs = 4.5 tiles, the fifth half empty): 240 MFMAs per wave and layer instead of 320.  A
+// read is 12 triples, so only d0 of a read's first triple and d4 of its last cross a read boundary: those lanes
+// fetch the image's leading zero row instead.  Images use the SW_3 swizzle.
+// The INPUT GROUPS are the outer loop and the 3 tiles the inner one: all 15 accumulators (3 tiles x 5 components)
+// stay live, but only one input group's weights (5 registers) are resident, with the next group's (or the next
+// layer's first) requested a whole group ahead: w[m & 1] serves group m, so a layer starts and ends on w[0].
+// Tile k's output transform + bias + activation + residual + stores run ahead of tile k+1's last step.
+template <class CF, int MODE, bool LAST>
+__device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float* __restrict__ out, f32x4 (&w)[2][5],
+                                            const float* __restrict__ wl, const float* __restrict__ next_wl,
+                                            const float* __restrict__ bias, int wave, int lane) {
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE, "identity-shortcut residual blocks only");
+    static_assert(CF::F33 && CF::NW == 4, "compact 64-channel image, one wave per 16-channel block");
+    constexpr int NT = CF::RS2 * CF::G / 48;                                 // 3 tiles of 16 triples
+    constexpr int TPR = CF::RS2 / 3;                                         // triples per read (12)
+    constexpr int M = 4;                                                     // input groups of 16 channels
+    constexpr int TOFF = 48 * 64;                                            // floats between tiles (48 rows: a period of SW_3)
+    constexpr int NU = M * NT;
+    const int cb = wave, j = lane & 15, q = lane >> 4;
+    const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // rows 3j + i: i = 0..2 share the swizzle of row 3j, i = 3, 4 that of row 3j + 3
+    const float* pa[M];
+    const float* pb[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        pa[m] = in + img_off<64, SW_3>(3 * j, 4 * m + q);
+        pb[m] = in + img_off<64, SW_3>(3 * j + 3, 4 * m + q);
+    }
+    const float* const zrow = in + 4 * q;                                    // the leading zero row
+    float* const o01 = out + img_off<64, SW_3>(3 * j + 1, 4 * cb + q);        // flat rows 3T, 3T+1 = image rows 3T+1, 3T+2
+    float* const o2 = out + img_off<64, SW_3>(3 * j + 3, 4 * cb + q);         // flat row 3T+2 = image row 3T+3
+
+    f32x4 ring[2][5];
+    f32x4 acc[NT][5];
+    f32x4 res[3] = {zero4, zero4, zero4};
+    auto issue = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int m = u / NT, k = u % NT;
+        bool first = false, last = false;                                    // this lane's triple opens / closes a read
+        static_for<0, 16>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            if constexpr ((16 * k + jj) % TPR == 0) first = first || (j == jj);
+            if constexpr ((16 * k + jj) % TPR == TPR - 1) last = last || (j == jj);
+        });
+        static_for<0, 5>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const float* ptr = (i < 3 ? pa[m] + i * 64 : pb[m] + (i - 3) * 64) + k * TOFF;
+            if constexpr (i == 0) ptr = first ? zrow : ptr;
+            if constexpr (i == 4) ptr = last ? zrow : ptr;
+            ring[u & 1][i] = *(const f32x4*)ptr;
+        });
+    };
+    // output transform, bias (rides in M1), activation, residual, stores of tile kk (its accumulators are complete)
+    auto epi_store = [&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        const f32x4(&a)[5] = acc[kk];
+        const f32x4 sum = a[1] + a[2], dif = a[1] - a[2], t2 = a[3] + a[3], t4 = t2 + t2;
+        f32x4 y0 = (a[0] + sum) + a[3];
+        f32x4 y1 = dif + t2;
+        f32x4 y2 = (sum + t4) + a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y0[e] = CF::act(y0[e]);
+            y1[e] = CF::act(y1[e]);
+            y2[e] = CF::act(y2[e]);
+        }
+        if constexpr (MODE == MODE_RESID_INPLACE) {
+            y0 = y0 + res[0];
+            y1 = y1 + res[1];
+            y2 = y2 + res[2];
+        }
+        *(f32x4*)(o01 + kk * TOFF) = y0;
+        *(f32x4*)(o01 + 64 + kk * TOFF) = y1;
+        *(f32x4*)(o2 + kk * TOFF) = y2;
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int m = u / NT, k = u % NT;
+        if constexpr (u + 1 < NU) issue(std::integral_constant<int, u + 1>{});
+        if constexpr (k == 0) {                                              // the next group's weights, a group ahead
+            const float* nw = (m + 1 < M) ? wl + (m + 1) * 5 * 256 : next_wl;
+            if constexpr (m + 1 < M || !LAST) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) w[(m + 1) & 1][c] = *(const f32x4*)(nw + c * 256);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the previous tile's epilogue: one block of VALU work + three stores ahead of this step's MFMAs
+        if constexpr (m == M - 1 && k >= 1) epi_store(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
+        {
+            const f32x4(&d)[5] = ring[u & 1];
+            // one block of packed VALU operations ahead of the step's MFMAs (VALU and MFMA share the issue port)
+            const f32x4 s31 = pk_sub(d[3], d[1]);
+            const f32x4 t02 = pk_sub(d[0], d[2]), p12 = pk_add(d[1], d[2]), m12 = pk_sub(d[1], d[2]), t42 = pk_sub(d[4], d[2]);
+            const f32x4 v0 = pk_add(pk_add(t02, t02), s31);
+            const f32x4 v1 = pk_sub(s31, p12);
+            const f32x4 v2 = pk_add(pk_add(pk_add(m12, m12), m12), s31);
+            const f32x4 v4 = pk_sub(t42, pk_add(s31, s31));
+            asm volatile("s_nop 1");         // VALU write -> MFMA source read distance, whatever the MFMA order below
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4(&a)[5] = acc[k];
+            const f32x4(&wm)[5] = w[m & 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool first = (m == 0) && (e == 0);
+                a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[0][e], v0[e], first ? zero4 : a[0], 0, 0, 0);
+                a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[1][e], v1[e], first ? b4 : a[1], 0, 0, 0);
+                a[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[2][e], v2[e], first ? zero4 : a[2], 0, 0, 0);
+                a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[3][e], s31[e], first ? zero4 : a[3], 0, 0, 0);
+                a[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[4][e], v4[e], first ? zero4 : a[4], 0, 0, 0);
+            }
+        }
+        if constexpr (MODE == MODE_RESID_INPLACE && m == M - 1) {            // residual input of this tile's epilogue
+            res[0] = *(const f32x4*)(o01 + k * TOFF);
+            res[1] = *(const f32x4*)(o01 + 64 + k * TOFF);
+            res[2] = *(const f32x4*)(o2 + k * TOFF);
+        }
+        if constexpr (u == NU - 1) epi_store(std::integral_constant<int, NT - 1>{});
     });
 }
 
@@ -873,7 +1022,8 @@ __device__ __forceinline__ void stem_conv3_pool_wino(const float* __restrict__ i
 template <class CF, bool STEM, int NB64, bool WINO>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
-    using O = Offs<WINO>;
+    constexpr bool F33 = WINO && CF::F33;                     // 64-channel residual blocks in F(3,3) form
+    using O = Offs<WINO, F33>;
     constexpr int L1 = CF::L1, RS1 = CF::RS1, L2 = CF::L2, RS2 = CF::RS2;
     static_assert(CF::COMPACT || WINO, "the zero-row 64-channel geometry is implemented for the Winograd form only");
     constexpr int W3232 = O::W3232, W3264 = O::W3264, W3264S = O::W3264S, W6464 = O::W6464;
@@ -924,6 +1074,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     float* const H = STEM ? bufA : bufB;
     f32x4 sreg[CF::NSREG];
     f32x4 wA[NVA], wB[NVB], w2[2];
+    f32x4 w3[2][5];                                           // F33: one input group's weights, current / next
     f32x4 (&w6)[6] = reinterpret_cast<f32x4 (&)[6]>(wA);       // the direct-form views of the same registers
     f32x4 (&w12)[12] = reinterpret_cast<f32x4 (&)[12]>(wB);
 
@@ -1065,7 +1216,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
     __syncthreads();
     if (tid < 32) ((f32x4*)X)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (WINO) {
+    // this wave's block of an F(3,3) layer, this lane: [4 input groups][5 components][64 lanes][4]
+    auto slice3 = [&](int off) { return W + off + cb4 * (20 * 256) + lane * 4; };
+    if constexpr (F33) {
+        // its output image is the first the F(3,3) layers walk: SW_3
+        wino_layer<CF, 64, MODE_ADD_REGS, false, false, SW_3>(H, X, wB, nullptr, W + OFF_C2 + W6464, pad2w, dump, wave, lane, sreg);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(slice3(O::off_d(0)) + c * 256);
+    } else if constexpr (WINO) {
         wino_layer<CF, 64, MODE_ADD_REGS, true>(H, X, wB, slice(O::off_d(0), cb4, NVB), W + OFF_C2 + W6464, pad2w, dump, wave,
                                                 lane, sreg);
     } else {
@@ -1077,8 +1235,16 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     // ---- NB64 x ResidualBlock(64) (3 in the canonical read convolver) ------------------------------
 #pragma unroll
     for (int blk = 0; blk < NB64; ++blk) {
-        const int off_a = O::off_d(blk), off_b = off_a + (W6464 + 64);
-        if constexpr (WINO) {
+        const int off_a = O::off_d(blk), off_b = off_a + (O::W6464D + 64);
+        if constexpr (F33) {
+            wino3_layer<CF, MODE_PLAIN, false>(X, H, w3, slice3(off_a), slice3(off_b), W + off_a + O::W6464D, wave, lane);
+            __syncthreads();
+            if (blk < NB64 - 1)
+                wino3_layer<CF, MODE_RESID_INPLACE, false>(H, X, w3, slice3(off_b), slice3(O::off_d(blk + 1)),
+                                                           W + off_b + O::W6464D, wave, lane);
+            else
+                wino3_layer<CF, MODE_RESID_INPLACE, true>(H, X, w3, slice3(off_b), nullptr, W + off_b + O::W6464D, wave, lane);
+        } else if constexpr (WINO) {
             wino_layer<CF, 64, MODE_PLAIN, true>(X, H, wB, slice(off_b, cb4, NVB), W + off_a + W6464, pad2w, dump, wave, lane);
             __syncthreads();
             if (blk < NB64 - 1)
@@ -1111,7 +1277,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         for (int i = 0; i < NF; ++i) {
             const int f = tid + THREADS * i;
             if (f < L2 * 16) {
-                const f32x4 v = *(const f32x4*)(X + img_off<64, SWX>(1 + rd * RS2 + (f >> 4), f & 15));
+                const f32x4 v = *(const f32x4*)(X + img_off<64, F33 ? SW_3 : SWX>(1 + rd * RS2 + (f >> 4), f & 15));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) carry[i][e] += v[e];
             }

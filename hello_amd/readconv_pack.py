@@ -81,7 +81,9 @@ def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, window: int = 
     if winograd:
         w1, w2 = -(-(rs1 // 2) * g // 16), -(-(rs2 // 2) * g // 16)   # tiles of 16 pairs
         strided = t2 * 4 * 6 * 4 + 2 * w2 * 4 * 2 * 4 + w2 * 4 * 4 * 16
-        blocks = 6 * (w1 * 2 * 2 * 16) + n64 * (w2 * 4 * 4 * 16)
+        # 64-channel blocks: F(3,3) where the image is whole tiles of 16 triples (20 MFMAs per tile, input group and wave)
+        per64 = (rs2 * g // 48) * 4 * 4 * 20 if f33(winograd, window) else w2 * 4 * 4 * 16
+        blocks = 6 * (w1 * 2 * 2 * 16) + n64 * per64
     else:
         strided = t2 * 4 * 6 * 4 + t2 * 4 * 2 * 4 + t2 * 4 * 12 * 4
         blocks = 6 * (t1 * 2 * 6 * 4) + n64 * (t2 * 4 * 12 * 4)
@@ -97,16 +99,44 @@ def winograd_taps(w: np.ndarray) -> np.ndarray:
     return u.astype(np.float32)
 
 
-def pack(nodes, folded, cin=None, winograd: bool = False) -> np.ndarray:
+def winograd_taps_f33(w: np.ndarray) -> np.ndarray:
+    """[cout, cin, 3] -> [cout, cin, 5]: the F(3,3) filter transform for the points 0, 1, -1, 2, inf, evaluated in
+    float64 and rounded once: g0/2, -(g0+g1+g2)/2, (-g0+g1-g2)/6, (g0+2g1+4g2)/6, g2."""
+    g = w.astype(np.float64)
+    g0, g1, g2 = g[..., 0], g[..., 1], g[..., 2]
+    u = np.stack([g0 / 2, -(g0 + g1 + g2) / 2, (-g0 + g1 - g2) / 6, (g0 + 2 * g1 + 4 * g2) / 6, g2], axis=-1)
+    return u.astype(np.float32)
+
+
+def f33(winograd: bool, window: int) -> bool:
+    """The 64-channel identity-shortcut residual blocks run in Winograd F(3,3) form: the 150 bp geometry, whose
+    compact 64-channel image (4 reads x 36 rows) is whole tiles of 16 triples (``Cfg::F33`` in readconv_fused.hip)."""
+    return bool(winograd) and window == 150
+
+
+def _pack_conv_f33(w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """[cout/16 blocks][cin/16 groups][5 components][64 lanes][4]: wino3_layer walks the input groups outermost."""
+    u = winograd_taps_f33(w)
+    cout, cin, _ = u.shape
+    n = (cout // 16) * 5 * (cin // 16) * 256
+    blocks = _pack_conv(u, b)[:n].reshape(cout // 16, 5, cin // 16, 64, 4)            # [cb, c, m, lane, t]
+    return np.concatenate([blocks.transpose(0, 2, 1, 3, 4).ravel(), b.astype(np.float32).ravel()])
+
+
+def pack(nodes, folded, cin=None, winograd: bool = False, window: int = 150) -> np.ndarray:
     """trunk block followed by the stem block (conv1 bytes form, conv2, conv3), then any extra 64-channel
     blocks.  With ``winograd`` the two convolutions of every identity-shortcut residual block are stored as
-    their four Winograd F(2,3) taps (the strided block stays in direct form)."""
+    their four Winograd F(2,3) taps -- the 64-channel ones as five F(3,3) taps where ``f33(winograd, window)`` --
+    (the strided block's first conv and shortcut stay in direct form)."""
     convs = trunk_convs(nodes)
     strided = {6, 7}                                 # kernel order: 6 x (32->32), strided a / shortcut / b, 6 x (64->64);
                                                      # the strided block's second conv (b) is k3/s1/p1 too
+    use33 = f33(winograd, window)
 
     def one(i, c):
         w, b = folded[c.key]
+        if use33 and i >= 9:
+            return _pack_conv_f33(w, b)
         return _pack_conv(winograd_taps(w), b) if (winograd and i not in strided) else _pack_conv(w, b)
 
     parts = [one(i, c) for i, c in enumerate(convs)]
@@ -123,6 +153,7 @@ def pack(nodes, folded, cin=None, winograd: bool = False) -> np.ndarray:
     blob = np.concatenate(parts)
     kt = 4 if winograd else 3
     w32, w64 = 2 * kt * 2 * 256, 4 * kt * 4 * 256
-    trunk = 6 * (w32 + 32) + (6144 + 64) + (2048 + 64) + (w64 + 64) + 6 * (w64 + 64)
-    assert blob.size == trunk + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32) + 2 * len(extras) * (w64 + 64), blob.size
+    w64d = 4 * 5 * 4 * 256 if use33 else w64
+    trunk = 6 * (w32 + 32) + (6144 + 64) + (2048 + 64) + (w64 + 64) + 6 * (w64d + 64)
+    assert blob.size == trunk + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32) + 2 * len(extras) * (w64d + 64), blob.size
     return blob

@@ -46,6 +46,20 @@ def test_f33_filter_transform_reproduces_the_direct_convolution():
     np.testing.assert_allclose(out, _direct(x.astype(np.float64), w.astype(np.float64)), rtol=1e-6, atol=1e-6)
 
 
+def test_fused_f33_weight_layout():
+    """64-channel residual-block convs of the 150 bp kernel: [cout/16][cin/16][5 components][64 lanes][4]."""
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal((64, 64, 3)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    blob = rp._pack_conv_f33(w, b)
+    assert blob.size == 4 * 4 * 5 * 256 + 64 and np.array_equal(blob[-64:], b)
+    u = compiler.winograd_taps_f33(w)
+    body = blob[:-64].reshape(4, 4, 5, 64, 4)
+    for cb, m, c, lane, t in [(0, 0, 0, 0, 0), (3, 2, 4, 63, 3), (1, 3, 1, 17, 2), (2, 0, 3, 40, 1)]:
+        assert body[cb, m, c, lane, t] == u[16 * cb + (lane & 15), 16 * m + 4 * (lane >> 4) + t, c]
+    assert rp.f33(True, 150) and not rp.f33(True, 250) and not rp.f33(False, 150)
+
+
 def test_generic_winograd_weight_layout():
     rng = np.random.default_rng(1)
     w = rng.standard_normal((64, 24, 3)).astype(np.float32)
@@ -67,9 +81,10 @@ def test_fused_blob_sizes_and_flags():
             op = next(o for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED)
             assert bool(op.flags & compiler.FLAG_WINOGRAD) == wino and op.k == extra and prog.winograd == wino
             kt = 4 if wino else 3
-            n64 = 7 + 2 * extra                                     # strided block's second conv + the blocks' convs
-            want = (6 * (2 * kt * 2 * 256 + 32) + (6144 + 64) + (2048 + 64) + n64 * (4 * kt * 4 * 256 + 64)
-                    + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32))
+            kt64 = 5 if wino else 3                                 # 64-channel residual blocks: F(3,3) at 150 bp
+            n64 = 6 + 2 * extra                                     # the blocks' convs (+ the strided block's second conv)
+            want = (6 * (2 * kt * 2 * 256 + 32) + (6144 + 64) + (2048 + 64) + (4 * kt * 4 * 256 + 64)
+                    + n64 * (4 * kt64 * 4 * 256 + 64) + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32))
             nodes = spec.nets["read_convolver0"]
             assert rp.pack(nodes, weights.fold(spec, state), 6, winograd=wino).size == want
             convs = [o for o in prog.ops if o.kind == compiler.OP_CONV1D]
@@ -84,8 +99,9 @@ def test_fused_blob_sizes_and_flags():
 def test_executed_macs_match_the_kernel_schedule():
     assert rp.executed_macs_per_read(False) == 5052 * 1024          # MFMAs per wave and group of 4 reads (ISA count)
     # stem: conv1 60 + conv2 19 tiles x 16 / 4 waves = 76 (120 direct) + conv3/pool 5 tiles x 32 per read = 160 (264)
-    assert rp.executed_macs_per_read(True) == (296 + 6 * 144 + 216 + 80 + 320 + 6 * 320) * 1024
-    assert rp.executed_macs_per_read(True, 2) - rp.executed_macs_per_read(True) == 4 * 320 * 1024
+    # 64-channel residual blocks in F(3,3) form: 3 tiles x 4 input groups x 20 MFMAs = 240 per wave (F(2,3): 320)
+    assert rp.executed_macs_per_read(True) == (296 + 6 * 144 + 216 + 80 + 320 + 6 * 240) * 1024
+    assert rp.executed_macs_per_read(True, 2) - rp.executed_macs_per_read(True) == 4 * 240 * 1024
 
 
 def test_window_geometry_matches_the_reference_layer_arithmetic():
