@@ -696,10 +696,11 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
             // one block of packed VALU operations ahead of the step's MFMAs (VALU and MFMA share the issue port)
             const f32x4 s31 = pk_sub(d[3], d[1]);
             const f32x4 t02 = pk_sub(d[0], d[2]), p12 = pk_add(d[1], d[2]), m12 = pk_sub(d[1], d[2]), t42 = pk_sub(d[4], d[2]);
-            const f32x4 v0 = pk_add(pk_add(t02, t02), s31);
+            const f32x4 two = {2.f, 2.f, 2.f, 2.f}, three = {3.f, 3.f, 3.f, 3.f};
+            const f32x4 v0 = __builtin_elementwise_fma(t02, two, s31);        // v_pk_fma_f32
             const f32x4 v1 = pk_sub(s31, p12);
-            const f32x4 v2 = pk_add(pk_add(pk_add(m12, m12), m12), s31);
-            const f32x4 v4 = pk_sub(t42, pk_add(s31, s31));
+            const f32x4 v2 = __builtin_elementwise_fma(m12, three, s31);
+            const f32x4 v4 = __builtin_elementwise_fma(s31, -two, t42);
             asm volatile("s_nop 1");         // VALU write -> MFMA source read distance, whatever the MFMA order below
             __builtin_amdgcn_sched_barrier(0);
             f32x4(&a)[5] = acc[k];
