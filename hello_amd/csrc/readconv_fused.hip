@@ -59,8 +59,9 @@ struct Offs {
     static constexpr int W3232 = 2 * KT * 2 * 256, W3264 = 4 * 3 * 2 * 256, W3264S = 4 * 1 * 2 * 256;
     static constexpr int W6464 = 4 * KT * 4 * 256;
     static constexpr int W6464D = F33 ? 4 * 5 * 4 * 256 : W6464;      // a convolution of the 64-channel residual blocks
+    static constexpr int W3232D = F33 ? 2 * 5 * 2 * 256 : W3232;      // ... of the 32-channel residual blocks
     static constexpr int OFF_B = 0;                                   // 6 convs 32->32 (residual blocks)
-    static constexpr int OFF_C1 = OFF_B + 6 * (W3232 + 32);           // 32->64 k3 s2
+    static constexpr int OFF_C1 = OFF_B + 6 * (W3232D + 32);          // 32->64 k3 s2
     static constexpr int OFF_SC = OFF_C1 + W3264 + 64;                // 32->64 k1 s2
     static constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3 of the strided block
     static constexpr int OFF_D = OFF_C2 + W6464 + 64;                 // 6 convs 64->64 (residual blocks)
@@ -104,6 +105,7 @@ struct Cfg {
     // the compact image is whole tiles of 16 TRIPLES of rows (and a read is whole triples): its residual blocks
     // run in Winograd F(3,3) form (wino3_layer)
     static constexpr bool F33 = COMPACT && (RS2 % 3) == 0 && ((RS2 * G_) % 48) == 0;
+    static constexpr bool F33_32 = F33 && (RS1 % 3) == 0 && ((RS1 * G_) % 96) == 0;   // the 32-channel blocks too
     static constexpr int NTT = (L1 + 6) / 7;           // stem pool tiles per read (7 pooled outputs each)
     static constexpr int WPR = NW_ / G_;               // waves sharing a read in the stem pool
     static_assert(RS1 % 2 == 0 && RS2 % 2 == 0 && NW_ % G_ == 0, "pairs of rows must not straddle reads");
@@ -132,6 +134,7 @@ using Geometry = rc::Cfg<4, 4, 150>;      // 4 reads x 4 waves per workgroup, tw
 using Geometry250 = rc::Cfg<2, 4, 250>;   // 250 bp windows: 2 reads per workgroup fill the same LDS
 using GeometrySoftplus = rc::Cfg<4, 4, 150, rc::ACT_SOFTPLUS>;
 static_assert(Geometry::F33 && GeometrySoftplus::F33 && !Geometry250::F33, "weight packing rule of readconv_pack.py");
+static_assert(Geometry::F33_32 && GeometrySoftplus::F33_32, "weight packing rule of readconv_pack.py");
 int readconv_weight_floats(int extra_blocks, bool winograd, int window) {
     if (!winograd) return rc::Offs<false>::off_d(3 + extra_blocks);
     return window == 150 ? rc::Offs<true, true>::off_d(3 + extra_blocks) : rc::Offs<true>::off_d(3 + extra_blocks);
@@ -606,33 +609,49 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
 // stay live, but only one input group's weights (5 registers) are resident, with the next group's (or the next
 // layer's first) requested a whole group ahead: w[m & 1] serves group m, so a layer starts and ends on w[0].
 // Tile k's output transform + bias + activation + residual + stores run ahead of tile k+1's last step.
-template <class CF, int MODE, bool LAST>
+// At 32 channels (C = 32) the same layer runs on the SW_W image with its shared zero rows: 288 rows = 6 tiles of 16
+// triples, 2 channel blocks x 2 position groups of waves, 3 tiles (pg, pg+2, pg+4) and 2 input groups per wave: 120
+// MFMAs per wave and layer, evenly (F(2,3): 9 tiles split 5 / 4, 144 on average).  No read boundaries to patch on
+// the input side (the zero rows are the padding); a read's 24th triple ends ON the zero row, whose output is
+// stored as zero.
+template <class CF, int C, int MODE, bool LAST>
 __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float* __restrict__ out, f32x4 (&w)[2][5],
                                             const float* __restrict__ wl, const float* __restrict__ next_wl,
                                             const float* __restrict__ bias, int wave, int lane) {
     static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE, "identity-shortcut residual blocks only");
-    static_assert(CF::F33 && CF::NW == 4, "compact 64-channel image, one wave per 16-channel block");
-    constexpr int NT = CF::RS2 * CF::G / 48;                                 // 3 tiles of 16 triples
-    constexpr int TPR = CF::RS2 / 3;                                         // triples per read (12)
-    constexpr int M = 4;                                                     // input groups of 16 channels
-    constexpr int TOFF = 48 * 64;                                            // floats between tiles (48 rows: a period of SW_3)
+    static_assert(C == 64 ? CF::F33 : (C == 32 && CF::F33_32), "image of whole tiles of 16 triples");
+    static_assert(CF::NW == 4, "4 waves: 4 channel blocks, or 2 channel blocks x 2 position groups");
+    constexpr int M = C / 16, NCB = C / 16, NPG = CF::NW / NCB;              // input groups; waves = blocks x position groups
+    constexpr int RS = C == 64 ? CF::RS2 : CF::RS1;
+    constexpr int NT = RS * CF::G / 48 / NPG;                                // 3 tiles of 16 triples per wave
+    constexpr int TPR = RS / 3;                                              // triples per read (12 | 24)
+    constexpr int SW = C == 64 ? SW_3 : SW_W;
+    constexpr bool EDGE = C == 64;                                           // reads stacked without zero rows between them
+    constexpr int TOFF = NPG * 48 * C;                                       // floats between a wave's tiles (a period of the swizzle)
     constexpr int NU = M * NT;
-    const int cb = wave, j = lane & 15, q = lane >> 4;
+    const int cb = wave % NCB, pg = wave / NCB, j = lane & 15, q = lane >> 4;
     const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // rows 3j + i: i = 0..2 share the swizzle of row 3j, i = 3, 4 that of row 3j + 3
-    const float* pa[M];
-    const float* pb[M];
+    // rows 48 pg + 3j + i, i = 0..4, input group m.  SW_3: i = 0..2 share the swizzle of row 3j, i = 3, 4 that of
+    // row 3j + 3 (two pointers per group); SW_W (32 channels): one pointer per row
+    constexpr int NP = C == 64 ? 2 : 5;
+    const float* pin[M][NP];
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-        pa[m] = in + img_off<64, SW_3>(3 * j, 4 * m + q);
-        pb[m] = in + img_off<64, SW_3>(3 * j + 3, 4 * m + q);
-    }
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pin[m][i] = in + img_off<C, SW>(48 * pg + 3 * j + (C == 64 ? 3 * i : i), 4 * m + q);
     const float* const zrow = in + 4 * q;                                    // the leading zero row
-    float* const o01 = out + img_off<64, SW_3>(3 * j + 1, 4 * cb + q);        // flat rows 3T, 3T+1 = image rows 3T+1, 3T+2
-    float* const o2 = out + img_off<64, SW_3>(3 * j + 3, 4 * cb + q);         // flat row 3T+2 = image row 3T+3
+    // flat rows 3T, 3T+1, 3T+2 = image rows 3T+1, 3T+2, 3T+3
+    float* po[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) po[u] = out + img_off<C, SW>(48 * pg + 3 * j + 1 + u, 4 * cb + q);
 
+    unsigned zmask = 0;                     // bit k: the third row of this lane's triple in the wave's k-th tile is a zero row
+    if constexpr (!EDGE) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) zmask |= ((16 * (pg + NPG * k) + j) % TPR == TPR - 1 ? 1u : 0u) << k;
+    }
     f32x4 ring[2][5];
     f32x4 acc[NT][5];
     f32x4 res[3] = {zero4, zero4, zero4};
@@ -640,16 +659,18 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
         constexpr int u = decltype(uc)::value;
         constexpr int m = u / NT, k = u % NT;
         bool first = false, last = false;                                    // this lane's triple opens / closes a read
-        static_for<0, 16>([&](auto jc) {
-            constexpr int jj = decltype(jc)::value;
-            if constexpr ((16 * k + jj) % TPR == 0) first = first || (j == jj);
-            if constexpr ((16 * k + jj) % TPR == TPR - 1) last = last || (j == jj);
-        });
+        if constexpr (EDGE) {
+            static_for<0, 16>([&](auto jc) {
+                constexpr int jj = decltype(jc)::value;
+                if constexpr ((16 * k + jj) % TPR == 0) first = first || (j == jj);
+                if constexpr ((16 * k + jj) % TPR == TPR - 1) last = last || (j == jj);
+            });
+        }
         static_for<0, 5>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const float* ptr = (i < 3 ? pa[m] + i * 64 : pb[m] + (i - 3) * 64) + k * TOFF;
-            if constexpr (i == 0) ptr = first ? zrow : ptr;
-            if constexpr (i == 4) ptr = last ? zrow : ptr;
+            const float* ptr = (C == 64 ? pin[m][i / 3] + (i % 3) * 64 : pin[m][i < NP ? i : 0]) + k * TOFF;
+            if constexpr (EDGE && i == 0) ptr = first ? zrow : ptr;
+            if constexpr (EDGE && i == 4) ptr = last ? zrow : ptr;
             ring[u & 1][i] = *(const f32x4*)ptr;
         });
     };
@@ -672,9 +693,12 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
             y1 = y1 + res[1];
             y2 = y2 + res[2];
         }
-        *(f32x4*)(o01 + kk * TOFF) = y0;
-        *(f32x4*)(o01 + 64 + kk * TOFF) = y1;
-        *(f32x4*)(o2 + kk * TOFF) = y2;
+        if constexpr (!EDGE) {                                               // the shared zero row between reads
+            if ((zmask >> kk) & 1u) y2 = zero4;
+        }
+        *(f32x4*)(po[0] + kk * TOFF) = y0;
+        *(f32x4*)(po[1] + kk * TOFF) = y1;
+        *(f32x4*)(po[2] + kk * TOFF) = y2;
     };
     issue(std::integral_constant<int, 0>{});
     static_for<0, NU>([&](auto uc) {
@@ -716,9 +740,8 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
             }
         }
         if constexpr (MODE == MODE_RESID_INPLACE && m == M - 1) {            // residual input of this tile's epilogue
-            res[0] = *(const f32x4*)(o01 + k * TOFF);
-            res[1] = *(const f32x4*)(o01 + 64 + k * TOFF);
-            res[2] = *(const f32x4*)(o2 + k * TOFF);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) res[r] = *(const f32x4*)(po[r] + k * TOFF);
         }
         if constexpr (u == NU - 1) epi_store(std::integral_constant<int, NT - 1>{});
     });
@@ -1112,7 +1135,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     const long long read0 = wg_read0 + (long long)grp * G;
     if (read0 >= a.n_reads) break;                            // uniform: the last workgroup may hold fewer groups
     const int n_here = (int)((a.n_reads - read0) < G ? (a.n_reads - read0) : G);
-    load_weights<NVA>(wA, W + OFF_B, cb2, lane);    // first trunk layer: requested before anything else waits
+    // first trunk layer: requested before anything else waits
+    if constexpr (F33) {
+        static_assert(!F33 || CF::F33_32, "the F(3,3) kernel runs its 32-channel blocks in F(3,3) form too");
+#pragma unroll
+        for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(W + OFF_B + cb2 * (10 * 256) + lane * 4 + c * 256);
+    } else {
+        load_weights<NVA>(wA, W + OFF_B, cb2, lane);
+    }
     if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
     if (STEM) {
         // the stem, from the uint8 pileups: conv1 bytes -> bufB, conv2 bufB -> bufA, conv3 + max pool
@@ -1183,11 +1213,21 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     __syncthreads();
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
-        const int off_a = OFF_B + (2 * blk) * (W3232 + 32), off_b = off_a + (W3232 + 32);
+        const int off_a = OFF_B + (2 * blk) * (O::W3232D + 32), off_b = off_a + (O::W3232D + 32);
         // the block's second conv rolls in the next block's first conv, or the strided conv (4 channel blocks;
         // its 6 registers are the first 6 of the 8 a Winograd layer refills)
         const float* nxt = (blk < 2) ? slice(off_b + (W3232 + 32), cb2, NVA) : slice(OFF_C1, cb4, 6);
-        if constexpr (WINO) {
+        if constexpr (F33) {
+            // this wave's block of a 32-channel F(3,3) layer, this lane: [2 input groups][5 components][64 lanes][4]
+            auto slice32 = [&](int off) { return W + off + cb2 * (10 * 256) + lane * 4; };
+            wino3_layer<CF, 32, MODE_PLAIN, false>(X, H, w3, slice32(off_a), slice32(off_b), W + off_a + O::W3232D, wave, lane);
+            __syncthreads();
+            if (blk < 2)
+                wino3_layer<CF, 32, MODE_RESID_INPLACE, false>(H, X, w3, slice32(off_b), slice32(off_b + (O::W3232D + 32)),
+                                                               W + off_b + O::W3232D, wave, lane);
+            else
+                wino3_layer<CF, 32, MODE_RESID_INPLACE, true>(H, X, w3, slice32(off_b), nullptr, W + off_b + O::W3232D, wave, lane);
+        } else if constexpr (WINO) {
             wino_layer<CF, 32, MODE_PLAIN, true>(X, H, wA, slice(off_b, cb2, NVA), W + off_a + W3232, pad1, dump, wave, lane);
             __syncthreads();
             wino_layer<CF, 32, MODE_RESID_INPLACE, true, true>(H, X, wA, nxt, W + off_b + W3232, pad1f, dump, wave, lane);
@@ -1202,6 +1242,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
 
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
+    if constexpr (F33) load_weights<6>(w6, W + OFF_C1, cb4, lane);      // (otherwise rolled in by the last 32-channel layer)
     load_weights<2>(w2, W + OFF_SC, cb4, lane);
     load_weights<NVB>(wB, W + OFF_C2, cb4, lane);
     if (tid < 32) ((f32x4*)H)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};   // rows 0 and 36G+1
@@ -1238,13 +1279,13 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     for (int blk = 0; blk < NB64; ++blk) {
         const int off_a = O::off_d(blk), off_b = off_a + (O::W6464D + 64);
         if constexpr (F33) {
-            wino3_layer<CF, MODE_PLAIN, false>(X, H, w3, slice3(off_a), slice3(off_b), W + off_a + O::W6464D, wave, lane);
+            wino3_layer<CF, 64, MODE_PLAIN, false>(X, H, w3, slice3(off_a), slice3(off_b), W + off_a + O::W6464D, wave, lane);
             __syncthreads();
             if (blk < NB64 - 1)
-                wino3_layer<CF, MODE_RESID_INPLACE, false>(H, X, w3, slice3(off_b), slice3(O::off_d(blk + 1)),
+                wino3_layer<CF, 64, MODE_RESID_INPLACE, false>(H, X, w3, slice3(off_b), slice3(O::off_d(blk + 1)),
                                                            W + off_b + O::W6464D, wave, lane);
             else
-                wino3_layer<CF, MODE_RESID_INPLACE, true>(H, X, w3, slice3(off_b), nullptr, W + off_b + O::W6464D, wave, lane);
+                wino3_layer<CF, 64, MODE_RESID_INPLACE, true>(H, X, w3, slice3(off_b), nullptr, W + off_b + O::W6464D, wave, lane);
         } else if constexpr (WINO) {
             wino_layer<CF, 64, MODE_PLAIN, true>(X, H, wB, slice(off_b, cb4, NVB), W + off_a + W6464, pad2w, dump, wave, lane);
             __syncthreads();

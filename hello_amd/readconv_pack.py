@@ -83,7 +83,8 @@ def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, window: int = 
         strided = t2 * 4 * 6 * 4 + 2 * w2 * 4 * 2 * 4 + w2 * 4 * 4 * 16
         # 64-channel blocks: F(3,3) where the image is whole tiles of 16 triples (20 MFMAs per tile, input group and wave)
         per64 = (rs2 * g // 48) * 4 * 4 * 20 if f33(winograd, window) else w2 * 4 * 4 * 16
-        blocks = 6 * (w1 * 2 * 2 * 16) + n64 * per64
+        per32 = (rs1 * g // 48) * 2 * 2 * 20 if f33(winograd, window) else w1 * 2 * 2 * 16
+        blocks = 6 * per32 + n64 * per64
     else:
         strided = t2 * 4 * 6 * 4 + t2 * 4 * 2 * 4 + t2 * 4 * 12 * 4
         blocks = 6 * (t1 * 2 * 6 * 4) + n64 * (t2 * 4 * 12 * 4)
@@ -109,8 +110,9 @@ def winograd_taps_f33(w: np.ndarray) -> np.ndarray:
 
 
 def f33(winograd: bool, window: int) -> bool:
-    """The 64-channel identity-shortcut residual blocks run in Winograd F(3,3) form: the 150 bp geometry, whose
-    compact 64-channel image (4 reads x 36 rows) is whole tiles of 16 triples (``Cfg::F33`` in readconv_fused.hip)."""
+    """The identity-shortcut residual blocks run in Winograd F(3,3) form: the 150 bp geometry, whose images (4 reads
+    x 72 rows at 32 channels, 4 x 36 at 64) are whole tiles of 16 triples (``Cfg::F33`` / ``F33_32`` in
+    readconv_fused.hip)."""
     return bool(winograd) and window == 150
 
 
@@ -135,7 +137,7 @@ def pack(nodes, folded, cin=None, winograd: bool = False, window: int = 150) -> 
 
     def one(i, c):
         w, b = folded[c.key]
-        if use33 and i >= 9:
+        if use33 and i not in strided and i != 8:    # every identity-shortcut residual block, 32 and 64 channels
             return _pack_conv_f33(w, b)
         return _pack_conv(winograd_taps(w), b) if (winograd and i not in strided) else _pack_conv(w, b)
 
@@ -154,6 +156,7 @@ def pack(nodes, folded, cin=None, winograd: bool = False, window: int = 150) -> 
     kt = 4 if winograd else 3
     w32, w64 = 2 * kt * 2 * 256, 4 * kt * 4 * 256
     w64d = 4 * 5 * 4 * 256 if use33 else w64
-    trunk = 6 * (w32 + 32) + (6144 + 64) + (2048 + 64) + (w64 + 64) + 6 * (w64d + 64)
+    w32d = 2 * 5 * 2 * 256 if use33 else w32
+    trunk = 6 * (w32d + 32) + (6144 + 64) + (2048 + 64) + (w64 + 64) + 6 * (w64d + 64)
     assert blob.size == trunk + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32) + 2 * len(extras) * (w64d + 64), blob.size
     return blob
