@@ -64,7 +64,7 @@ struct Offs {
     static constexpr int OFF_C1 = OFF_B + 6 * (W3232D + 32);          // 32->64 k3 s2
     static constexpr int OFF_SC = OFF_C1 + W3264 + 64;                // 32->64 k1 s2
     static constexpr int OFF_C2 = OFF_SC + W3264S + 64;               // 64->64 k3 of the strided block
-    static constexpr int OFF_D = OFF_C2 + W6464 + 64;                 // 6 convs 64->64 (residual blocks)
+    static constexpr int OFF_D = OFF_C2 + W6464D + 64;                // 6 convs 64->64 (residual blocks)
     static constexpr int W_TRUNK = OFF_D + 6 * (W6464D + 64);
     static constexpr int OFF_S1 = W_TRUNK;                            // [6 steps][64 lanes], bias[16]
     static constexpr int OFF_S2 = OFF_S1 + S1_STEPS * 64 + 16;        // [3 taps | 4 Winograd taps][64 lanes][4], bias[16]
@@ -242,7 +242,9 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
 }
 
 enum { MODE_PLAIN = 0, MODE_RESID_INPLACE = 1, MODE_TO_REGS = 2, MODE_ADD_REGS = 3 };
-enum { GEOM_TRUNK = 0, GEOM_STEM = 1, GEOM_WPAIR = 2 };   // WPAIR: tile 2t / 2t+1 = even / odd rows of the pairs of Winograd tile t
+enum { GEOM_TRUNK = 0, GEOM_STEM = 1, GEOM_WPAIR = 2, GEOM_WTRIPLE = 3 };
+// WPAIR: tile 2t / 2t+1 = even / odd rows of the pairs of Winograd tile t;  WTRIPLE: tile 3t + u = rows 3T + u of the
+// triples T of F(3,3) tile t
 
 // value of lane+n of the same 16-lane row (DPP row_shl); lanes whose source falls outside the row read 0
 // (bound_ctrl: no preload of the destination, and the shift can fold into the consuming instruction)
@@ -286,8 +288,15 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     // so here too a tile only adds a constant (two pointer sets for the even / odd tiles of GEOM_WPAIR).
     constexpr bool S2LIN = (GEOM != GEOM_STEM) && (STRIDE == 2) && (RS_IN == 2 * RS_OUT);
     static_assert(!S2LIN || GEOM != GEOM_WPAIR || NPG == 1, "paired-row tiles assume one position group");
-    const float* opbase[(S2LIN && GEOM == GEOM_WPAIR) ? 2 * KT * M : KT * M];
-    if constexpr (S2LIN && GEOM == GEOM_WPAIR) {
+    static_assert(GEOM != GEOM_WTRIPLE || (S2LIN && NPG == 1), "triple-row tiles: the linear stride-2 geometry, one position group");
+    const float* opbase[(S2LIN && GEOM == GEOM_WPAIR) ? 2 * KT * M : ((GEOM == GEOM_WTRIPLE) ? 3 * KT * M : KT * M)];
+    if constexpr (GEOM == GEOM_WTRIPLE) {
+#pragma unroll
+        for (int s = 0; s < 3 * KT * M; ++s) {           // rows 96 (t/3) + 6 j + 2 (t%3) + 1 - PAD + tap
+            const int u = s / (KT * M), ss = s % (KT * M);
+            opbase[s] = in + img_off<CIN, SIN>(6 * j + 2 * u + 1 - PAD + ss / M, 4 * (ss % M) + q);
+        }
+    } else if constexpr (S2LIN && GEOM == GEOM_WPAIR) {
 #pragma unroll
         for (int s = 0; s < 2 * KT * M; ++s) {           // rows 64 (t/2) + 4 j + 2 (t&1) + 1 - PAD + tap
             const int par = s / (KT * M), ss = s % (KT * M);
@@ -306,6 +315,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     }
     auto tile_operand = [&](int k, int s) -> f32x4 {     // k-th tile of this wave, step s = tap*M + m
         if (IDENT) return *(const f32x4*)(opbase[s] + k * NPG * 16 * CIN);
+        if constexpr (GEOM == GEOM_WTRIPLE) return *(const f32x4*)(opbase[(k % 3) * KT * M + s] + (k / 3) * 96 * CIN);
         if constexpr (S2LIN && GEOM == GEOM_WPAIR) return *(const f32x4*)(opbase[(k & 1) * KT * M + s] + (k / 2) * 64 * CIN);
         if constexpr (S2LIN && GEOM != GEOM_WPAIR) return *(const f32x4*)(opbase[s] + k * NPG * 32 * CIN);
         int row;
@@ -323,6 +333,8 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     float* const outbase = out + 16 * pg * COUT + img_off<COUT, SOUT>(j + LEAD, 4 * cb + q);
     auto out_ptr = [&](int k) -> float* {
         float* ptr = outbase + k * NPG * 16 * COUT;
+        if constexpr (SOUT == SW_3)                                     // a swizzle without the tiles' 16-row period
+            ptr = out + img_off<COUT, SOUT>(16 * (pg + NPG * k) + j + LEAD, 4 * cb + q);
         if ((NPG - 1 + NPG * k) * 16 + 15 >= VROWS)                   // only the last tile(s) can overrun
             ptr = ((pg + NPG * k) * 16 + j < VROWS) ? ptr : dump;
         return ptr;
@@ -618,7 +630,8 @@ template <class CF, int C, int MODE, bool LAST>
 __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float* __restrict__ out, f32x4 (&w)[2][5],
                                             const float* __restrict__ wl, const float* __restrict__ next_wl,
                                             const float* __restrict__ bias, int wave, int lane) {
-    static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE, "identity-shortcut residual blocks only");
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE, "block convolutions only (the strided block's second "
+                  "conv finds its shortcut in the output image, like a residual)");
     static_assert(C == 64 ? CF::F33 : (C == 32 && CF::F33_32), "image of whole tiles of 16 triples");
     static_assert(CF::NW == 4, "4 waves: 4 channel blocks, or 2 channel blocks x 2 position groups");
     constexpr int M = C / 16, NCB = C / 16, NPG = CF::NW / NCB;              // input groups; waves = blocks x position groups
@@ -1242,13 +1255,23 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     }
 
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
-    if constexpr (F33) load_weights<6>(w6, W + OFF_C1, cb4, lane);      // (otherwise rolled in by the last 32-channel layer)
+    if constexpr (F33) {                     // (otherwise rolled in by the last 32-channel layer)
+        load_weights<6>(w6, W + OFF_C1, cb4, lane);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(W + OFF_C2 + cb4 * (20 * 256) + lane * 4 + c * 256);
+    } else {
+        load_weights<NVB>(wB, W + OFF_C2, cb4, lane);
+    }
     load_weights<2>(w2, W + OFF_SC, cb4, lane);
-    load_weights<NVB>(wB, W + OFF_C2, cb4, lane);
     if (tid < 32) ((f32x4*)H)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};   // rows 0 and 36G+1
-    conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX, SWX>(
-        X, H, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
-    if constexpr (WINO) {
+    conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX,
+               F33 ? SW_3 : SWX>(X, H, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
+    if constexpr (F33) {
+        // the shortcut in the row order the F(3,3) epilogue of the block's second conv holds its outputs in
+        static_assert(!F33 || CF::NSREG >= 3 * (RS2 * CF::G / 48), "shortcut tiles kept in registers");
+        conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, 3 * (RS2 * CF::G / 48), MODE_TO_REGS, false, GEOM_WTRIPLE, 16, RS2 * CF::G,
+                   false, SWX, SWX>(X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
+    } else if constexpr (WINO) {
         // the shortcut in the row order the Winograd epilogue of the block's second conv holds its outputs in
         conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, CF::NSREG, MODE_TO_REGS, false, GEOM_WPAIR, 16, RS2 * CF::G, false, SWX,
                    SWX>(X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
@@ -1261,10 +1284,16 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     // this wave's block of an F(3,3) layer, this lane: [4 input groups][5 components][64 lanes][4]
     auto slice3 = [&](int off) { return W + off + cb4 * (20 * 256) + lane * 4; };
     if constexpr (F33) {
-        // its output image is the first the F(3,3) layers walk: SW_3
-        wino_layer<CF, 64, MODE_ADD_REGS, false, false, SW_3>(H, X, wB, nullptr, W + OFF_C2 + W6464, pad2w, dump, wave, lane, sreg);
+        // the shortcut moves from registers into the output image (each lane stores what it will read back as the
+        // residual of its own outputs): holding it across the layer would not fit beside 15 accumulators
+        {
+            const int j = lane & 15, q = lane >> 4;
 #pragma unroll
-        for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(slice3(O::off_d(0)) + c * 256);
+            for (int t = 0; t < 3 * (RS2 * G / 48); ++t)
+                *(f32x4*)(X + img_off<64, SW_3>(48 * (t / 3) + 3 * j + (t % 3) + 1, 4 * cb4 + q)) = sreg[t];
+        }
+        wino3_layer<CF, 64, MODE_RESID_INPLACE, false>(H, X, w3, slice3(OFF_C2), slice3(O::off_d(0)), W + OFF_C2 + O::W6464D, wave,
+                                                       lane);
     } else if constexpr (WINO) {
         wino_layer<CF, 64, MODE_ADD_REGS, true>(H, X, wB, slice(O::off_d(0), cb4, NVB), W + OFF_C2 + W6464, pad2w, dump, wave,
                                                 lane, sreg);

@@ -81,6 +81,8 @@ def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, window: int = 
     if winograd:
         w1, w2 = -(-(rs1 // 2) * g // 16), -(-(rs2 // 2) * g // 16)   # tiles of 16 pairs
         strided = t2 * 4 * 6 * 4 + 2 * w2 * 4 * 2 * 4 + w2 * 4 * 4 * 16
+        if f33(winograd, window):                    # shortcut on 3 x 3 tiles of 16 rows, second conv in F(3,3) form
+            strided = t2 * 4 * 6 * 4 + 3 * (rs2 * g // 48) * 4 * 2 * 4 + (rs2 * g // 48) * 4 * 4 * 20
         # 64-channel blocks: F(3,3) where the image is whole tiles of 16 triples (20 MFMAs per tile, input group and wave)
         per64 = (rs2 * g // 48) * 4 * 4 * 20 if f33(winograd, window) else w2 * 4 * 4 * 16
         per32 = (rs1 * g // 48) * 2 * 2 * 20 if f33(winograd, window) else w1 * 2 * 2 * 16
@@ -137,7 +139,7 @@ def pack(nodes, folded, cin=None, winograd: bool = False, window: int = 150) -> 
 
     def one(i, c):
         w, b = folded[c.key]
-        if use33 and i not in strided and i != 8:    # every identity-shortcut residual block, 32 and 64 channels
+        if use33 and i not in strided:               # every k3/s1 convolution of the trunk, 32 and 64 channels
             return _pack_conv_f33(w, b)
         return _pack_conv(winograd_taps(w), b) if (winograd and i not in strided) else _pack_conv(w, b)
 
@@ -157,6 +159,6 @@ def pack(nodes, folded, cin=None, winograd: bool = False, window: int = 150) -> 
     w32, w64 = 2 * kt * 2 * 256, 4 * kt * 4 * 256
     w64d = 4 * 5 * 4 * 256 if use33 else w64
     w32d = 2 * 5 * 2 * 256 if use33 else w32
-    trunk = 6 * (w32d + 32) + (6144 + 64) + (2048 + 64) + (w64 + 64) + 6 * (w64d + 64)
+    trunk = 6 * (w32d + 32) + (6144 + 64) + (2048 + 64) + (w64d + 64) + 6 * (w64d + 64)
     assert blob.size == trunk + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32) + 2 * len(extras) * (w64d + 64), blob.size
     return blob

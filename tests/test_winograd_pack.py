@@ -83,7 +83,7 @@ def test_fused_blob_sizes_and_flags():
             kt = 4 if wino else 3
             kt64 = 5 if wino else 3                                 # identity-shortcut residual blocks: F(3,3) at 150 bp
             n64 = 6 + 2 * extra                                     # the blocks' convs (+ the strided block's second conv)
-            want = (6 * (2 * kt64 * 2 * 256 + 32) + (6144 + 64) + (2048 + 64) + (4 * kt * 4 * 256 + 64)
+            want = (6 * (2 * kt64 * 2 * 256 + 32) + (6144 + 64) + (2048 + 64) + (4 * kt64 * 4 * 256 + 64)
                     + n64 * (4 * kt64 * 4 * 256 + 64) + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32))
             nodes = spec.nets["read_convolver0"]
             assert rp.pack(nodes, weights.fold(spec, state), 6, winograd=wino).size == want
@@ -100,7 +100,7 @@ def test_executed_macs_match_the_kernel_schedule():
     assert rp.executed_macs_per_read(False) == 5052 * 1024          # MFMAs per wave and group of 4 reads (ISA count)
     # stem: conv1 60 + conv2 19 tiles x 16 / 4 waves = 76 (120 direct) + conv3/pool 5 tiles x 32 per read = 160 (264)
     # residual blocks in F(3,3) form: 3 tiles x 4 (2) input groups x 20 MFMAs = 240 (120) per wave (F(2,3): 320 / 144)
-    assert rp.executed_macs_per_read(True) == (296 + 6 * 120 + 216 + 80 + 320 + 6 * 240) * 1024
+    assert rp.executed_macs_per_read(True) == (296 + 6 * 120 + 216 + 72 + 240 + 6 * 240) * 1024
     assert rp.executed_macs_per_read(True, 2) - rp.executed_macs_per_read(True) == 4 * 240 * 1024
 
 
