@@ -291,10 +291,10 @@ def main():
         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
         "launch_ms": round(dom_ms, 4), "flop_per_launch": float(dom_flops), "launches_per_step": dom["launches"],
         # `achieved` prices the ALGORITHMIC work (direct-form 2*MAC) against the FP32 MFMA peak; the
-        # residual-block convolutions run in Winograd F(2,3) form (4 instead of 6 fp32 contractions per pair of
-        # positions), so the matrix cores execute fewer FLOPs than that: their own rate and utilisation are
+        # k3/s1 convolutions run in Winograd form (F(3,3): 5 instead of 9 fp32 contractions per 3 positions; F(2,3):
+        # 4 instead of 6 per 2), so the matrix cores execute fewer FLOPs than that: their own rate and utilisation are
         "mfma_executed_tflops": round(executed, 3), "mfma_executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
-        "arithmetic": "fp32; k3/s1 convolutions in Winograd form (read convolver F(2,3), allele stage F(3,3))" if eng.program.winograd else "fp32, direct form",
+        "arithmetic": "fp32; k3/s1 convolutions in Winograd form (residual trunk and allele stage F(3,3), stem F(2,3))" if eng.program.winograd else "fp32, direct form",
         "kernels_ms_per_step": {kk: round(v["ms"], 4) for kk, v in sorted(kernels.items(), key=lambda x: -x[1]["ms"])},
         "whole_step_frac": round(flops_step / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
         "hbm_algorithmic_gbs": round((900.0 * reads_step) / (dt / args.steps) / 1e9, 3),

@@ -691,10 +691,11 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
     auto epi_store = [&](auto kc) {
         constexpr int kk = decltype(kc)::value;
         const f32x4(&a)[5] = acc[kk];
-        const f32x4 sum = a[1] + a[2], dif = a[1] - a[2], t2 = a[3] + a[3], t4 = t2 + t2;
+        const f32x4 sum = a[1] + a[2], dif = a[1] - a[2];
+        const f32x4 two = {2.f, 2.f, 2.f, 2.f}, four = {4.f, 4.f, 4.f, 4.f};
         f32x4 y0 = (a[0] + sum) + a[3];
-        f32x4 y1 = dif + t2;
-        f32x4 y2 = (sum + t4) + a[4];
+        f32x4 y1 = __builtin_elementwise_fma(a[3], two, dif);
+        f32x4 y2 = __builtin_elementwise_fma(a[3], four, sum) + a[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             y0[e] = CF::act(y0[e]);
