@@ -1,10 +1,13 @@
 """Static check of the fused kernel's device assembly: no inline-asm instruction may read a register that a
-v_mfma wrote a few instructions earlier.
+v_mfma wrote fewer wait states earlier than the hardware needs.
 
 The MFMA -> VALU read-after-write hazard is software managed on gfx950: the compiler pads it with s_nop, but
 its hazard recogniser does not look inside inline asm.  hello_amd/csrc/readconv_fused.hip uses inline asm for
-v_pk_add_f32 (input transform of the Winograd layers) and feeds it LDS-loaded operands only; this script
-fails if a future edit routes an accumulator into one of those instructions.
+v_pk_add_f32 (input transforms of the Winograd layers) and feeds it LDS-loaded operands only.  This script
+counts wait states (an instruction = 1, `s_nop N` = N + 1) between every v_mfma write and every inline-asm read
+of the same register and fails below REQUIRED (an 8-pass MFMA result needs 12 before a VALU read).  (A packed
+inline-asm output transform behind an explicit `s_nop 11` was tried for the F(3,3) layers: bit-identical
+results, 1.4 % slower than the compiler's scalar epilogue, which it schedules into the MFMA shadow.)
 
     python tools/check_asm_hazards.py [file.hip ...]      # exit code 1 on a violation
 """
@@ -15,7 +18,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WINDOW = 24          # instructions; the longest MFMA here (32x32x2 f32) needs 18 wait states
+REQUIRED = {"16x16": 12, "32x32": 20}     # wait states by MFMA shape (8 / 16 passes), with margin over the ISA's table
 
 
 def regs(tok):
@@ -50,12 +53,15 @@ def check(path):
         ops = t.split(None, 1)
         toks = ops[1].split(",") if len(ops) > 1 else []
         count += 1
+        if ops[0] == "s_nop" and len(ops) > 1:
+            count += int(ops[1].split()[0], 0)        # s_nop N = N + 1 wait states
         if in_asm and ops[0].startswith("v_"):
             n_asm += 1
             for x in toks[1:]:
                 for r in regs(x.split()[0] if x.strip() else ""):
                     name, idx = last_writer.get(r, ("", -10 ** 9))
-                    if name.startswith("v_mfma") and count - idx <= WINDOW:
+                    need = next((v for k, v in REQUIRED.items() if k in name), 20)
+                    if name.startswith("v_mfma") and count - idx <= need:
                         bad.append((t, count - idx))
                         break
         if toks and not ops[0].startswith(("ds_write", "global_store", "buffer_store", "s_", "ds_store")):
@@ -71,7 +77,7 @@ def main():
         n, bad = check(os.path.abspath(f))
         print(f"{os.path.basename(f)}: {n} inline-asm vector instructions, {len(bad)} read a fresh MFMA result")
         for t, back in bad[:10]:
-            print(f"   {t}    <- v_mfma {back} instructions earlier")
+            print(f"   {t}    <- v_mfma {back} wait states earlier")
         rc |= bool(bad)
     return rc
 
