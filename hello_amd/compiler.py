@@ -505,9 +505,9 @@ def _allocate(ops: List[Op], values: Dict[int, Value]):
 
 
 def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool = True) -> Program:
-    """``winograd``: the fused read convolver evaluates the k=3 convolutions of its identity-shortcut residual
-    blocks in Winograd F(2,3) form (4 instead of 6 contractions per pair of positions; same fp32 arithmetic,
-    results differ from the direct form by float re-association only)."""
+    """``winograd``: k3/s1/p1 convolutions are evaluated in Winograd form -- F(3,3) (5 instead of 9 contractions per
+    3 positions) where the row length / the fused kernel's geometry is whole triples, else F(2,3) (4 instead of 6
+    per pair) -- same fp32 arithmetic, results differ from the direct form by float re-association only."""
     low = _Lowering(spec, state, fused, winograd)
     n_experts, has_meta = low.lower()
     buffers = _allocate(low.ops, low.values)

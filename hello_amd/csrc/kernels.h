@@ -69,7 +69,7 @@ struct ReadConvArgs {
     int groups_per_wg;         // consecutive groups of readconv_reads_per_group() reads one workgroup walks
     long long n_reads;
     int extra_blocks;          // identity-shortcut 64-channel blocks after the canonical three: 0 | 2
-    int winograd;              // residual-block convolutions in Winograd F(2,3) form (weights packed accordingly)
+    int winograd;              // k3/s1 convolutions in Winograd form: F(3,3) trunk at 150 bp, else F(2,3) (weights packed accordingly)
     int window;                // pileup window: 150 | 250 (250: `reads` + Winograd form only)
     int softplus;              // Softplus instead of ReLU (`reads` + Winograd form, 150 bp only)
 };
@@ -77,7 +77,7 @@ bool readconv_supports_window(int window);
 int readconv_reads_per_group(int window);
 int readconv_frame_rows(int window);       // positions per read after the read convolver: 36 | 61
 int readconv_groups_per_workgroup(long long n_reads, int window);
-int readconv_weight_floats(int extra_blocks, bool winograd, int window);   // 150 bp + Winograd: 64-channel blocks in F(3,3) form
+int readconv_weight_floats(int extra_blocks, bool winograd, int window);   // 150 bp + Winograd: residual trunk in F(3,3) form
 bool readconv_supports_extra_blocks(int extra_blocks);
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
 // frames[a] = sum of the partial slots of allele a, in slot order

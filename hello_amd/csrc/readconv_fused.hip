@@ -21,14 +21,16 @@
 //           a wave owns one 16-channel block; lane (j, q) of a tile ends with channels 4q..4q+3 of column j
 //           -> bias / ReLU / residual / store are float4.  k is ordered so that lane-quarter q supplies
 //           channels 16m+4q+t at step (tap, m, t) for BOTH operands: one ds_read_b128 feeds four MFMAs.
-//   form    WINO (default): the k=3 / stride-1 / pad-1 convolutions of the residual blocks (13 of the 18
-//           convs, 94 % of the MACs outside the stem) run in Winograd F(2,3) form, 4 instead of 6 channel
-//           contractions per pair of positions: wino_layer.  Everything else, and the whole kernel with
+//   form    WINO (default): the k=3 / stride-1 / pad-1 convolutions run in Winograd form.  The residual trunk
+//           (13 of the 18 convs, 94 % of the MACs outside the stem) in F(3,3) -- 5 instead of 9 channel
+//           contractions per 3 positions, whole tiles of 16 triples: wino3_layer -- where the geometry is
+//           whole triples (150 bp), else in F(2,3) (4 instead of 6 per pair of positions: wino_layer, which
+//           also runs the stem's conv2 and conv3 + pool).  Everything else, and the whole kernel with
 //           WINO = false, runs the direct form: conv_layer (tile pairs, two accumulation chains per tile,
 //           operands two steps ahead, deferred epilogue).
-//   weights each wave keeps ONLY its own 16-channel slice of ONE layer in registers (<= 64 VGPRs), loaded
-//           straight from L2 in lane order (pre-packed by hello_amd/readconv_pack.py); the next layer's
-//           slice is rolled in place, each register refilled right after its last use.
+//   weights each wave keeps ONLY its own 16-channel slice of ONE layer in registers (<= 64 VGPRs; F(3,3)
+//           layers: of one 16-channel input group, 20 VGPRs + the next group's), loaded straight from L2 in
+//           lane order (pre-packed by hello_amd/readconv_pack.py); the next slice is rolled in behind it.
 //   stem    runs first in the same kernel over the stacked reads (natural stride 150 rows): conv1 reads the
 //           bytes themselves (channels-last bytes: the im2col index k = tap*C + c is the byte offset from
 //           the row start), conv2 runs over the stacked rows as one sequence (rows whose window straddles
@@ -51,8 +53,9 @@ namespace rc {
 // convolutions of the identity-shortcut residual blocks are stored in their Winograd F(2,3) form: KT = 4
 // transformed taps U = G g (computed on the host in float64) instead of 3.
 constexpr int S1_STEPS = 6;                                // stem conv1: K = 3*C <= 21 -> 6 MFMA steps of 4
-// With F33 the 64-channel identity-shortcut residual blocks are stored in F(3,3) form: 5 transformed taps, ordered
-// [COUT/16][CIN/16][5][64 lanes][4] (wino3_layer walks the input groups in its outer loop).
+// With F33 the k3/s1 convolutions of the residual trunk (the blocks' convs and the strided block's second conv)
+// are stored in F(3,3) form: 5 transformed taps, ordered [COUT/16][CIN/16][5][64 lanes][4] (wino3_layer walks the
+// input groups in its outer loop).
 template <bool WINO, bool F33 = false>
 struct Offs {
     static constexpr int KT = WINO ? 4 : 3;

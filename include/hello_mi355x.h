@@ -86,7 +86,9 @@ typedef enum hello_op_kind {
 #define HELLO_FLAG_SRC_U8   2        /* src0 is one of the uint8 input buffers                       */
 #define HELLO_FLAG_SOFTMAX  4        /* HEAD: softmax over cout (meta expert, :229-232)              */
 #define HELLO_FLAG_SOFTPLUS 16       /* CONV1D: Softplus(beta 1, threshold 20) instead of ReLU (…_layer_norm.py:16) */
-#define HELLO_FLAG_WINOGRAD 32       /* READCONV_FUSED: residual-block convolutions in Winograd F(2,3) form;
+#define HELLO_FLAG_WINOGRAD 32       /* READCONV_FUSED: k3/s1 convolutions in Winograd form (150 bp: residual trunk
+                                        F(3,3), stem F(2,3); 250 bp: F(2,3)); weights as hello_amd/readconv_pack.py
+                                        packs them for that form and window;
                                         CONV1D (k 3, stride 1, pad 1): weights are the T Winograd taps, packed
                                         [cout][cin/8][T][8]; T = 5 (F(3,3)) when lin % 3 == 0, else 4 (F(2,3)) */
 #define HELLO_FLAG_MIX_REST 8        /* MIX: dst[a] = src0[a] - (src1[site(a)] - src0[a])  (:372-383)  */
