@@ -1365,7 +1365,12 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
 
 template <class CF, int NB64, bool WINO, bool STEM_ONLY = false>
 static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
-    static bool configured = false;
+    // the LDS opt-in is a per-device attribute of the function: once per device this process launches on
+    // (threads that share a device race benignly: the call is idempotent)
+    static bool configured_on[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    bool& configured = configured_on[dev];
     if (!configured) {
         hipError_t e = hipSuccess;
         if constexpr (!STEM_ONLY)
