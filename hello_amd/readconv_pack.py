@@ -74,7 +74,8 @@ def executed_macs_per_read(winograd: bool, extra_blocks: int = 0, window: int = 
     t_stem12 = -(-(-(-window * g // 16)) // 4) * 4               # 16-row tiles of conv1 / conv2, 4 position groups
     # conv3 + pool: `ntt` stride-14 tiles of 24 MFMAs per read (2 blocks), or ceil(L1/15) Winograd tiles of 32
     conv3 = g * (-(-l1 // 15)) * 2 * 4 * 4 if winograd else g * ntt * 2 * 3 * 4
-    conv2 = -(-(window * g // 2) // 16) * 16 if winograd else t_stem12 * 3 * 4      # tiles of 16 pairs, 16 MFMAs each
+    # conv2: tiles of 16 pairs (16 MFMAs each) dealt to the 4 waves in whole rounds, or 3 taps x 4 per 16-row tile
+    conv2 = -(-(-(-(window * g // 2) // 16)) // 4) * 4 * 16 if winograd else t_stem12 * 3 * 4
     stem = t_stem12 * 6 + conv2 + conv3
     t1, t2 = -(-rs1 * g // 16), -(-rs2 * g // 16)                # direct tiles at 32 / 64 channels
     n64 = 6 + 2 * extra_blocks

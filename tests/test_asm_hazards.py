@@ -16,3 +16,17 @@ def test_no_inline_asm_reads_a_fresh_mfma_result():
     n, bad = check_asm_hazards.check(os.path.join(ROOT, "hello_amd", "csrc", "readconv_fused.hip"))
     assert n > 0, "the inline-asm packed adds disappeared: update this check"
     assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None, reason="no hipcc")
+def test_executed_mfma_accounting_matches_the_instruction_stream():
+    """bench.py's executed-MFMA rate comes from readconv_pack.executed_macs_per_read: it must equal the v_mfma
+    instructions the kernel really contains (one 16x16x4 MFMA = 1 024 MACs; per wave and group of 4 reads; the
+    group loop is not unrolled)."""
+    import check_asm_hazards
+    from hello_amd import readconv_pack as rp
+    path = os.path.join(ROOT, "hello_amd", "csrc", "readconv_fused.hip")
+    cfg150 = "_ZN5hello15readconv_kernelINS_2rc3CfgILi4ELi4ELi150ELi0EEELb1ELi%dELb%dEEEvNS_12ReadConvArgsE"
+    for extra, wino in ((0, True), (2, True), (0, False)):
+        per_wave_and_group = rp.executed_macs_per_read(wino, extra) * 4 / 4 / 1024       # 4 reads, 4 waves
+        assert check_asm_hazards.mfma_count(path, cfg150 % (3 + extra, wino)) == per_wave_and_group, (extra, wino)

@@ -30,13 +30,37 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 
+_ASM = {}
+
+
+def assembly(path):
+    """Device assembly of ``path`` (compiled once per process), as a list of lines."""
+    if path not in _ASM:
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "k.s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                            "--cuda-device-only", "-S", path, "-o", out], check=True, cwd=os.path.dirname(path),
+                           stderr=subprocess.DEVNULL)
+            _ASM[path] = open(out).read().split("\n")
+    return _ASM[path]
+
+
+def mfma_count(path, symbol):
+    """v_mfma instructions in the body of the function whose mangled name is ``symbol``."""
+    n, inside = 0, False
+    for ln in assembly(path):
+        t = ln.strip()
+        if t.startswith(symbol + ":"):
+            inside = True
+        elif inside and t.startswith("s_endpgm"):
+            return n
+        elif inside and t.startswith("v_mfma"):
+            n += 1
+    raise KeyError(symbol)
+
+
 def check(path):
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
-                        "--cuda-device-only", "-S", path, "-o", out], check=True, cwd=os.path.dirname(path),
-                       stderr=subprocess.DEVNULL)
-        lines = open(out).read().split("\n")
+    lines = assembly(path)
     last_writer, count, in_asm, bad, n_asm = {}, 0, False, [], 0      # register -> (instruction, index)
     for ln in lines:
         t = ln.strip()
