@@ -203,6 +203,14 @@ __device__ __forceinline__ int img_off(int row, int chunk) {     // float offset
     }
 }
 
+// img_off of row 48 t + 3 j + i (the i-th row of triple 16 t + j), i a small constant: SW_3's row / 3 without a
+// division by 3 of a lane-varying value (16 t + j + i / 3, and 16 t vanishes under & 7)
+template <int C, int SW>
+__device__ __forceinline__ int img_off_triple(int t, int j, int i, int chunk) {
+    if constexpr (SW == SW_3) return (48 * t + 3 * j + i) * 64 + 4 * (chunk ^ (2 * ((j + i / 3) & 7)));
+    else return img_off<C, SW>(48 * t + 3 * j + i, chunk);
+}
+
 template <int NV>
 __device__ __forceinline__ void load_weights(f32x4 (&w)[NV], const float* __restrict__ base, int cb, int lane) {
 #pragma unroll
@@ -656,12 +664,12 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
 #pragma unroll
     for (int m = 0; m < M; ++m)
 #pragma unroll
-        for (int i = 0; i < NP; ++i) pin[m][i] = in + img_off<C, SW>(48 * pg + 3 * j + (C == 64 ? 3 * i : i), 4 * m + q);
+        for (int i = 0; i < NP; ++i) pin[m][i] = in + img_off_triple<C, SW>(pg, j, (C == 64 ? 3 * i : i), 4 * m + q);
     const float* const zrow = in + 4 * q;                                    // the leading zero row
     // flat rows 3T, 3T+1, 3T+2 = image rows 3T+1, 3T+2, 3T+3
     float* po[3];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) po[u] = out + img_off<C, SW>(48 * pg + 3 * j + 1 + u, 4 * cb + q);
+    for (int u = 0; u < 3; ++u) po[u] = out + img_off_triple<C, SW>(pg, j, 1 + u, 4 * cb + q);
 
     unsigned zmask = 0;                     // bit k: the third row of this lane's triple in the wave's k-th tile is a zero row
     if constexpr (!EDGE) {
@@ -1294,7 +1302,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             const int j = lane & 15, q = lane >> 4;
 #pragma unroll
             for (int t = 0; t < 3 * (RS2 * G / 48); ++t)
-                *(f32x4*)(X + img_off<64, SW_3>(48 * (t / 3) + 3 * j + (t % 3) + 1, 4 * cb4 + q)) = sreg[t];
+                *(f32x4*)(X + img_off_triple<64, SW_3>(t / 3, j, (t % 3) + 1, 4 * cb4 + q)) = sreg[t];
         }
         wino3_layer<CF, 64, MODE_RESID_INPLACE, false>(H, X, w3, slice3(OFF_C2), slice3(O::off_d(0)), W + OFF_C2 + O::W6464D, wave,
                                                        lane);
