@@ -50,25 +50,30 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     const int t = threadIdx.x;
     const int L = a.lin;                       // == a.lout
     const int PP = (L + M - 1) / M;            // tiles per row
-    const long long items = a.m_total / L;
-    const long long mp_total = items * PP;
+    const unsigned items = a.wino_rows;       // the launcher admits fewer than 2^31 tiles: 32-bit tile arithmetic
+    const unsigned mp_total = items * (unsigned)PP;
     // One-dimensional grid, XCD-aware: workgroup ids round-robin over the 8 XCDs (each with its own L2), so
     // the cout/64 channel blocks of one tile of pairs take ids 8 apart: same XCD, back to back -> the
     // activation tile is fetched into that L2 once.
-    const int gy = a.cout / BN;
-    const long long id = blockIdx.x;
-    const long long slot = id >> 3;
-    const long long mtile = (slot / gy) * 8 + (id & 7);
-    const long long m0 = mtile * BMP;
-    const int cb0 = (int)(slot % gy) * BN;
+    const unsigned gy = (unsigned)(a.cout / BN);
+    const unsigned id = blockIdx.x;
+    const unsigned slot = id >> 3, srow = slot / gy;
+    const unsigned m0 = (srow * 8 + (id & 7)) * BMP;
+    const int cb0 = (int)(slot - srow * gy) * BN;
     if (m0 >= mp_total) return;
     // Operand staging goes through buffer descriptors (32-bit per-lane byte offsets, the chunk offset in an
     // SGPR, out-of-range lanes read zeros): the 64 tiles of a workgroup span few rows, so the activation
     // descriptor starts at the first of them and an offset of 2 GiB marks "zero padding / row past the tile".
-    const long long item0 = m0 / PP;
-    const long long left = (items - item0) * L * a.cin * 4;
+    const unsigned item0 = m0 / (unsigned)PP;
+    const long long left = (long long)(items - item0) * L * a.cin * 4;
+    // A workgroup's tiles are numbered from its first row's first tile: x = p0 + r with p0 < PP and r < 80, so
+    // x / PP is one 32-bit multiply-high by a wave-uniform reciprocal (exact for x * PP < 2^32) instead of a
+    // 64-bit division per lane.
+    const unsigned p0 = m0 - item0 * (unsigned)PP;
+    const unsigned tiles_left = mp_total - m0;
+    const unsigned magic = 0xffffffffu / (unsigned)PP + 1u;
     const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const float*)a.src + item0 * L * a.cin), 0, (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+        (void*)((const float*)a.src + (long long)item0 * L * a.cin), 0, (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.w + (long long)cb0 * a.kpad), 0, BN * a.kpad * 4, 0x00020000);
 
@@ -83,12 +88,12 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
         const int tap = q >> 1, csub = (q & 1) * 4;
         lds_off[j] = row * LD + q * 4;
         w_off[j] = (unsigned)(row * a.kpad + q * 4) * 4u;
-        const long long mg = m0 + row;
         act_off[j] = 0x80000000u;
-        if (row < BMP && mg < mp_total) {
-            const long long item = mg / PP;
-            const int pos = M * (int)(mg - item * PP) - 1 + tap;
-            if (pos >= 0 && pos < L) act_off[j] = (unsigned)(((int)(item - item0) * L + pos) * a.cin + csub) * 4u;
+        if (row < BMP && (unsigned)row < tiles_left) {
+            const unsigned x = p0 + (unsigned)row;
+            const unsigned irow = PP == 1 ? x : __umulhi(x, magic);       // rows past the workgroup's first
+            const int pos = M * (int)(x - irow * (unsigned)PP) - 1 + tap;
+            if (pos >= 0 && pos < L) act_off[j] = (unsigned)(((int)irow * L + pos) * a.cin + csub) * 4u;
         }
     }
 
@@ -105,11 +110,20 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     const int lj = lane & 31, lh = lane >> 5;
     const int wn = wave & 1;                   // 32-channel block of this wave
     const int ptile0 = (wave >> 1) * 32;       // first tile of this wave
+    // accumulator register r of lane (lj, lh) is channel (r&3) + 8*(r>>2) + 4*lh of the wave's block, tile lj.
+    // The bias rides in component 1, which enters every output of a tile with coefficient 1.
+    const int ch0 = cb0 + wn * 32 + 4 * lh;
     f32x16 acc[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *(const f32x4*)(a.bias + ch0 + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[1][4 * q + e] = b4[e];
+    }
 
     const int nchunks = a.cin / CPC;
     prefetch(0);
@@ -152,16 +166,14 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     // epilogue: accumulator register r of lane (lj, lh) is channel (r&3) + 8*(r>>2) + 4*lh, tile lj.
     // The residual rows of a tile are all requested before the first is used (their latency overlaps the
     // output transform instead of being paid once per 16-byte piece).
-    const long long mg = m0 + ptile0 + lj;
-    if (mg >= mp_total) return;
-    const unsigned local = (unsigned)(mg - item0 * PP);        // tiles past the first row's start: small
-    const unsigned irow = local / (unsigned)PP;
+    if ((unsigned)(ptile0 + lj) >= tiles_left) return;
+    const unsigned local = p0 + (unsigned)(ptile0 + lj);       // tiles past the first row's start: small
+    const unsigned irow = PP == 1 ? local : __umulhi(local, magic);
     const int p = (int)(local - irow * (unsigned)PP);
     bool live[M];                              // F(3,3) rows are whole triples
 #pragma unroll
     for (int u = 0; u < M; ++u) live[u] = M == 3 || M * p + u < L;
-    const int ch0 = cb0 + wn * 32 + 4 * lh;
-    const long long o = ((item0 + irow) * L + M * p) * a.cout + ch0;
+    const long long o = ((long long)(item0 + irow) * L + M * p) * a.cout + ch0;
     f32x4 res[M][4];
     if constexpr (RES) {
 #pragma unroll
@@ -172,7 +184,6 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 b4 = *(const f32x4*)(a.bias + ch0 + 8 * q);
         f32x4 y[M];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -180,15 +191,15 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
             if constexpr (M == 2) {
                 const float m0v = acc[0][4 * q + e], m1v = acc[1][4 * q + e];
                 const float m2v = acc[2][4 * q + e], m3v = acc[3][4 * q + e];
-                x[0] = ((m0v + m1v) + m2v) + b4[e];
-                x[1] = ((m1v - m2v) - m3v) + b4[e];
+                x[0] = (m0v + m1v) + m2v;
+                x[1] = (m1v - m2v) - m3v;
             } else {
                 const float m0v = acc[0][4 * q + e], m1v = acc[1][4 * q + e], m2v = acc[2][4 * q + e];
                 const float m3v = acc[3][4 * q + e], m4v = acc[4][4 * q + e];
                 const float sum = m1v + m2v, dif = m1v - m2v;
-                x[0] = ((m0v + sum) + m3v) + b4[e];
-                x[1] = (dif + 2.f * m3v) + b4[e];
-                x[2] = ((sum + 4.f * m3v) + m4v) + b4[e];
+                x[0] = (m0v + sum) + m3v;
+                x[1] = __builtin_fmaf(m3v, 2.f, dif);
+                x[2] = __builtin_fmaf(m3v, 4.f, sum) + m4v;
             }
 #pragma unroll
             for (int u = 0; u < M; ++u)
@@ -210,11 +221,14 @@ bool conv1d_wino_supported(const ConvArgs& a) {
 
 int conv1d_wino_outputs_per_tile(int length) { return length % 3 == 0 ? 3 : 2; }
 
-hipError_t launch_conv1d_wino(const ConvArgs& a, hipStream_t stream) {
+hipError_t launch_conv1d_wino(const ConvArgs& args, hipStream_t stream) {
+    ConvArgs a = args;
     if (a.m_total <= 0) return hipSuccess;
     const int m = conv1d_wino_outputs_per_tile(a.lin);
     if (!conv1d_wino_supported(a) || a.kpad != (m + 2) * a.cin) return hipErrorInvalidValue;
     const long long tiles = (a.m_total / a.lin) * ((a.lin + m - 1) / m);
+    if (tiles >= (1LL << 31) - 8 * BMP) return hipErrorInvalidValue;      // the kernel's tile arithmetic is 32-bit
+    a.wino_rows = (unsigned)(a.m_total / a.lin);
     const long long mtiles8 = ((tiles + BMP - 1) / BMP + 7) / 8 * 8;       // workgroup rows, a multiple of the XCD count
     const dim3 grid((unsigned)(mtiles8 * (a.cout / BN)));
     // measured on the allele stage (8 192 sites), F(2,3): 64 pairs x 64 channels per workgroup at three waves per

@@ -19,6 +19,7 @@ struct ConvArgs {
     int cout_pad;         // multiple of 32
     int relu;                  // activation: 0 none, 1 ReLU, 2 Softplus (beta 1, threshold 20)
     int src_u8;
+    unsigned wino_rows;        // conv_wino.hip: m_total / lin, filled in by its launcher
     int wino;                  // Winograd form (conv_wino.hip): F(3,3) when lin % 3 == 0, else F(2,3); w packed
                                // [cout][cin/8][T components][8], kpad = T*cin, T = outputs per tile + 2
 };
