@@ -1269,8 +1269,6 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
     if constexpr (F33) {                     // (otherwise rolled in by the last 32-channel layer)
         load_weights<6>(w6, W + OFF_C1, cb4, lane);
-#pragma unroll
-        for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(W + OFF_C2 + cb4 * (20 * 256) + lane * 4 + c * 256);
     } else {
         load_weights<NVB>(wB, W + OFF_C2, cb4, lane);
     }
@@ -1283,6 +1281,9 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         static_assert(!F33 || CF::NSREG >= 3 * (RS2 * CF::G / 48), "shortcut tiles kept in registers");
         conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, 3 * (RS2 * CF::G / 48), MODE_TO_REGS, false, GEOM_WTRIPLE, 16, RS2 * CF::G,
                    false, SWX, SWX>(X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
+        // the second conv's first input group: requested only now (20 registers less across the two convs above)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(W + OFF_C2 + cb4 * (20 * 256) + lane * 4 + c * 256);
     } else if constexpr (WINO) {
         // the shortcut in the row order the Winograd epilogue of the block's second conv holds its outputs in
         conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, CF::NSREG, MODE_TO_REGS, false, GEOM_WPAIR, 16, RS2 * CF::G, false, SWX,
