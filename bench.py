@@ -2,15 +2,26 @@
 """Headline benchmark: candidate sites/s of the variant-scoring hot path on MI355X.
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): Illumina 30x single-tech model
-(moe_attention_config_single_tech_old_equivalent_weight_norm), synthetic sites from the seeded
-generator, seeded synthetic weights.  One *step* = one forward of the hot path over one batch of
-``--sites`` candidate sites already resident in HBM: uint8 pileups + CSR counts -> allele logits ->
-genotype-pair posteriors, all on the GPU.  ``value`` = sites processed by all ranks / wall time of
-exactly K steps (barrier + synchronize on both sides, max over ranks).  With N > 1 every rank scores
-its own shard of sites (weak scaling, no data-path collective) and the per-rank logits are gathered
-once to rank 0 over RCCL inside the timed region.
+(moe_attention_config_single_tech_old_equivalent_weight_norm), >= 1 M synthetic candidate sites from the
+seeded generator, seeded synthetic weights.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S] [--no-cpu-baseline]
+``value`` is SURVEY.md 8d metric (1): host-resident uint8 pileups + CSR counts -> host-resident allele logits
+AND genotype-pair posteriors, PCIe both ways included, through the product's own feed
+(hello_amd.shard.partition_sites -> hello_amd.pipeline.HostPipeline -> hello_amd.engine.Engine).  One *step* =
+one pass of the hot path over one batch of ``--launches-per-step`` x ``--sites`` candidate sites per GPU
+(9 x 8 192 = 73 728 by default, scored in launches of ``--sites``; the launches cycle a pinned pool of
+``--pool`` distinct synthetic batches).  Exactly K steps are timed between barrier + synchronize fences, with
+every result harvested to host memory before the closing fence.  The device-resident rate (inputs already in
+HBM, outputs left there) is reported beside it as ``device_resident``: the pipeline hides the PCIe feed behind
+the kernels, so the two agree within a few percent.
+
+With N > 1 (one process per GPU under torch.distributed.run) the global step batch is N times as large
+(weak scaling); every rank computes the same read-balanced site partition from the shared counts, feeds ITS
+range through its own pipeline (pinned pool and host threads on CPUs near its GPU) and keeps its logits
+resident; ONE RCCL gather at the end of the run brings every rank's logits to rank 0, inside the timed
+region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S] [--launches-per-step B]
 """
 import argparse
 import json
@@ -126,15 +137,41 @@ def cpu_baseline(seed, budget_s=12.0):
                                     "sample": f"{done} sites in chunks of {chunk}, one process, {dt:.1f} s"}}
 
 
+def rank_pieces(pool_counts, launches_total, rank, world):
+    """The global step batch is ``launches_total`` pool batches back to back (cycling the pool).  Every rank
+    computes the same read-balanced partition of its sites (hello_amd.shard.partition_sites) from the shared
+    counts and gets its contiguous range as a list of (pool index, site lo, site hi) pieces -- whole pool
+    batches except, for N > 1, where a cut falls inside one.  -> (pieces, sizes of every rank's range)."""
+    from hello_amd import shard
+    seq = [i % len(pool_counts) for i in range(launches_total)]
+    reads = np.concatenate([pool_counts[k]["reads_per_site"] for k in seq])
+    aps = np.concatenate([pool_counts[k]["alleles_per_site"] for k in seq])
+    ranges = shard.partition_sites(reads, world)
+    sizes = shard.shard_sizes(aps, ranges)
+    lo, hi = ranges[rank]
+    pieces, base = [], 0
+    for k in seq:
+        n = pool_counts[k]["alleles_per_site"].shape[0]
+        a, b = max(lo, base), min(hi, base + n)
+        if b > a:
+            pieces.append((k, a - base, b - base))
+        base += n
+    return pieces, sizes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sites", type=int, default=8192, help="candidate sites per step per GPU")
-    ap.add_argument("--pool", type=int, default=2, help="distinct resident batches cycled through")
+    ap.add_argument("--sites", type=int, default=8192, help="candidate sites per engine launch")
+    ap.add_argument("--launches-per-step", type=int, default=9,
+                    help="launches of --sites sites that make one step's batch on one GPU (9 x 8192 = 73 728 sites: "
+                         "20 steps stream 1.47 M sites)")
+    ap.add_argument("--pool", type=int, default=3, help="distinct pinned synthetic batches the launches cycle through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-small-batch", action="store_true", help="skip the 256-sites-per-launch leg")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the device-resident, latency, small-batch and parity legs (headline only)")
     ap.add_argument("--fused", choices=["full", "trunk", "none"], default="full",
                     help="read convolver: one fused kernel from the bytes / layer-by-layer stem + fused trunk / "
                          "layer by layer")
@@ -145,6 +182,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     # CPU baseline first: it forks worker processes, which must happen before this process touches the GPU
     # (and is skipped under a profiler, whose preloaded library has initialised the GPU already)
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -157,8 +195,9 @@ def main():
             cpu = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}
 
     import torch
-    from hello_amd import netspec as ns, synth, weights
+    from hello_amd import netspec as ns, shard, synth, weights
     from hello_amd.engine import Engine, n_pairs
+    from hello_amd.pipeline import HostPipeline, pin_batch
 
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -167,6 +206,8 @@ def main():
     # HELLO_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
     backend = os.environ.get("HELLO_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    # host threads of this rank (pinned staging, CSR building) on CPUs near its GPU, before the pinned pool exists
+    cpus = shard.pin_rank(local_rank, local_world, dev_index) if world > 1 else sorted(os.sched_getaffinity(0))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -194,91 +235,94 @@ def main():
     state = weights.synth_state(spec, seed=args.seed)
     eng = Engine(spec, state, device=dev_index, fused={"full": True, "trunk": "trunk", "none": False}[args.fused])
 
-    # resident pool of synthetic batches (every rank its own sites: shard = rank)
-    pool = []
-    for i in range(args.pool):
-        b = synth.make_sites(args.sites, seed=1000 * (rank + 1) + i + args.seed, coverage=30)
-        pool.append(dict(
-            batch=b, reads=torch.from_numpy(b.reads0).to(dev), rpa=b.reads_per_allele0,
-            aps=b.alleles_per_site, pairs=n_pairs(b.alleles_per_site)))
-    max_a = max(p["batch"].n_alleles for p in pool)
-    max_p = max(p["pairs"] for p in pool)
-    if dist is not None:
-        # ranks hold different random shards: agree on one row width so the final gather is a plain gather
-        width = torch.tensor([max_a], dtype=torch.int64, device=dev)
-        dist.all_reduce(width, op=dist.ReduceOp.MAX)
-        max_a = int(width.item())
-    # outputs of every timed step stay on the device until the single gather at the end
-    out_logits = torch.zeros((args.steps, max_a), dtype=torch.float32, device=dev)
-    out_post = torch.zeros((4, max_p), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def step(i, record=None):
-        p = pool[i % len(pool)]
-        a = p["batch"].n_alleles
-        lg = out_logits[record if record is not None else 0, :a].view(1, a)
-        eng.forward(p["reads"], p["rpa"], p["aps"], stream=stream,
-                    out=(lg, None, out_post[:, :p["pairs"]]), posteriors=True)
+    # ---- the pinned host pool (the same seeded batches on every rank: one global site stream) ---------------
+    pool = [synth.make_sites(args.sites, seed=1000 + i + args.seed, coverage=30) for i in range(args.pool)]
+    pinned = [pin_batch(b) for b in pool]
+    counts = [dict(reads_per_site=shard.reads_per_site(b), alleles_per_site=b.alleles_per_site) for b in pool]
+    pieces, sizes = rank_pieces(counts, args.launches_per_step * world, rank, world)
+    piece_batches = [pinned[k] if (lo, hi) == (0, pool[k].n_sites) else pinned[k].site_slice(lo, hi) for k, lo, hi in pieces]
+    step_sites = sum(hi - lo for _, lo, hi in pieces)
+    step_alleles = sizes[rank][1]
+    assert step_sites == sizes[rank][0] and step_alleles == sum(int(b.n_alleles) for b in piece_batches)
+    pipe = HostPipeline(eng, depth=2, posteriors=True)
+    # a rank's logits of the whole run stay resident for the single gather at the end
+    sink = torch.zeros((eng.n_experts, max(args.steps, 1) * step_alleles), dtype=torch.float32, device=dev) if dist is not None else None
 
     def fence():
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            if backend == "nccl":
+                torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(n_steps, keep):
+        """n_steps passes over this rank's pieces through the pipeline; every result is harvested to host
+        memory before this returns.  -> number of launches harvested."""
+        harvested, col = 0, 0
+        for s in range(n_steps):
+            for p, b in enumerate(piece_batches):
+                snk = (sink, None, col, 0) if (sink is not None and keep is not None) else None
+                for item in pipe.submit(b, tag=(s, p), sink=snk):
+                    harvested += 1
+                    if keep is not None:
+                        keep.append(item)
+                col += int(b.n_alleles)
+        for item in pipe.flush():
+            harvested += 1
+            if keep is not None:
+                keep.append(item)
+        return harvested
+
+    run_steps(args.warmup, None)
     fence()
-    eng.set_profiling(args.steps)
+    n_launches = args.steps * len(piece_batches)
+    eng.set_profiling(min(n_launches, 4096), only="readconv_fused")     # two events per launch: the dominant kernel
+    results = []
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, record=i)
+    harvested = run_steps(args.steps, results)
     gathered = None
     if dist is not None:
-        # the one collective of the path: per-rank logits -> rank 0
-        gathered = [torch.empty_like(out_logits) for _ in range(world)] if rank == 0 else None
-        dist.gather(out_logits, gathered, dst=0)
+        # the one collective of the path: every rank's logits of the run -> rank 0 (SURVEY.md 8e), then to its host
+        run_sizes = [(s * args.steps, a * args.steps) for s, a in sizes]
+        gathered, _ = shard.gather_results(sink, None, run_sizes, eng.n_experts, False, dst=0)
+        if gathered is not None:
+            gathered = gathered.cpu()
     fence()
     dt = time.perf_counter() - t0
+    assert harvested == n_launches, (harvested, n_launches)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    sites_local = sum(pool[i % len(pool)]["batch"].n_sites for i in range(args.steps))
-    sites_total = sites_local * world
+    sites_total = sum(s for s, _ in sizes) * args.steps
     value = sites_total / dt
 
-    # ---- roofline of the dominant kernel, from HIP events recorded around every op of the timed steps
+    # ---- the dominant kernel's launch time over the timed region (HIP events on the launch stream) ---------
     op_rows, n_fw = eng.op_times_ms()
     eng.set_profiling(0)
-    if args.op_times and rank == 0:
-        for i, (k, n, ms) in enumerate(op_rows):
-            print(f"  op {i:3d} {k:15s} {ms:9.4f} ms  {n}", file=sys.stderr)
-        print(f"  sum of ops {sum(r[2] for r in op_rows):.3f} ms over {n_fw} forwards", file=sys.stderr)
-    flops_step = np.mean([site_flops(spec, pool[i % len(pool)]["batch"])[0] for i in range(args.steps)])
-    reads_step = np.mean([pool[i % len(pool)]["batch"].reads0.shape[0] for i in range(args.steps)])
-    alleles_step = np.mean([pool[i % len(pool)]["batch"].n_alleles for i in range(args.steps)])
-    rows_of = {0: reads_step, 1: 0.0, 2: alleles_step, 3: float(args.sites)}
     fused = eng.program.fused_read_convolver
-    # group the per-op event times by the kernel that ran them; algorithmic FLOPs = 2 * MAC of the op
-    kernels = {}
-    for op, (k, n, ms) in zip(eng.program.ops, op_rows):
-        kname = {"conv1d": "conv1d_mfma_kernel", "readconv_fused": "readconv_kernel"}.get(k, k + "_kernel")
-        if k == "conv1d" and (op.flags & 32):
-            kname = "conv1d_wino_kernel"
-        ent = kernels.setdefault(kname, dict(ms=0.0, flops=0.0, exec=0.0, launches=0))
-        ent["ms"] += ms
-        rows = reads_step if k == "readconv_fused" else rows_of[op.domain]   # the trunk's MACs are per read
-        ent["flops"] += 2.0 * op.macs_per_row * rows
-        ent["exec"] += 2.0 * (op.exec_macs_per_row or op.macs_per_row) * rows
-        ent["launches"] += 1
-    dom_name = max(kernels, key=lambda kk: kernels[kk]["ms"])
-    dom = kernels[dom_name]
-    dom_ms = dom["ms"] / dom["launches"]                 # average launch duration
-    dom_flops = dom["flops"] / dom["launches"]           # algorithmic FLOPs per launch
-    achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    executed = dom["exec"] / dom["launches"] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    dom_index = max(range(len(op_rows)), key=lambda i: op_rows[i][2])
+    dom_op = eng.program.ops[dom_index]
+    dom_ms = op_rows[dom_index][2]                                              # average launch duration
+    reads_per_launch = float(np.mean([b.reads0.shape[0] for b in piece_batches]))
+    rows_dom = reads_per_launch if dom_op.kind == 8 else float(np.mean([b.n_alleles for b in piece_batches]))
+    dom_flops = 2.0 * dom_op.macs_per_row * rows_dom                            # algorithmic FLOPs per launch
+    dom_exec = 2.0 * (dom_op.exec_macs_per_row or dom_op.macs_per_row) * rows_dom
+    algorithmic = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    executed = dom_exec / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    # every pass over a pool batch must reproduce its first result bit for bit (checked outside the timed region)
+    first, drift = {}, 0
+    for (s, p), logits, meta, post in results:
+        if p not in first:
+            first[p] = (logits, post)
+        elif not (np.array_equal(logits, first[p][0]) and np.array_equal(post, first[p][1])):
+            drift += 1
+    if gathered is not None:
+        mine = np.concatenate([lg for _, lg, _, _ in results], axis=1)
+        drift += 0 if np.array_equal(gathered[:, :mine.shape[1]].numpy(), mine) else 1
+    finite = all(np.isfinite(lg).all() and np.isfinite(po).all() for _, lg, _, po in results[:len(piece_batches)])
+    del results
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
@@ -286,24 +330,128 @@ def main():
             traffic = json.load(open(tpath)).get("bytes_per_launch")
         except Exception:
             traffic = None
+    flops_launch = float(np.mean([site_flops(spec, pool[k].site_slice(lo, hi))[0] for k, lo, hi in pieces]))
+    launch_s = dt / n_launches
     roofline = {
-        "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-        "launch_ms": round(dom_ms, 4), "flop_per_launch": float(dom_flops), "launches_per_step": dom["launches"],
-        # `achieved` prices the ALGORITHMIC work (direct-form 2*MAC) against the FP32 MFMA peak; the
-        # k3/s1 convolutions run in Winograd form (F(3,3): 5 instead of 9 fp32 contractions per 3 positions; F(2,3):
-        # 4 instead of 6 per 2), so the matrix cores execute fewer FLOPs than that: their own rate and utilisation are
-        "mfma_executed_tflops": round(executed, 3), "mfma_executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+        "bound": "mfma", "kernel": "readconv_kernel" if dom_op.kind == 8 else op_rows[dom_index][0],
+        # `achieved` = the FLOPs the matrix cores EXECUTE per launch / the kernel's average launch duration: the k3/s1
+        # convolutions run in Winograd form (F(3,3): 5 instead of 9 fp32 contractions per 3 positions; F(2,3): 4
+        # instead of 6 per 2), so the hardware fraction is priced on executed MFMA work and stays <= 1
+        "achieved": round(executed, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        # the same launch priced on ALGORITHMIC work (direct-form 2 * MAC, SURVEY.md 8d: 10.152 MFLOP per read)
+        "algorithmic_achieved": round(algorithmic, 3), "algorithmic_frac": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
+        "formulas": {"frac": "2 * executed MAC per read * reads per launch / launch_ms / 157.3 TFLOP/s",
+                     "algorithmic_frac": "2 * 5 076 096 MAC per read * reads per launch / launch_ms / 157.3 TFLOP/s "
+                                         "(exceeds 1 because Winograd executes fewer MFMA FLOPs than the direct form)"},
+        "launch_ms": round(dom_ms, 4), "launches_timed": int(n_fw), "reads_per_launch": round(reads_per_launch, 1),
+        "flop_per_launch": float(dom_flops), "executed_flop_per_launch": float(dom_exec),
         "arithmetic": "fp32; k3/s1 convolutions in Winograd form (residual trunk and allele stage F(3,3), stem F(2,3))" if eng.program.winograd else "fp32, direct form",
-        "kernels_ms_per_step": {kk: round(v["ms"], 4) for kk, v in sorted(kernels.items(), key=lambda x: -x[1]["ms"])},
-        "whole_step_frac": round(flops_step / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-        "hbm_algorithmic_gbs": round((900.0 * reads_step) / (dt / args.steps) / 1e9, 3),
+        "whole_launch_algorithmic_frac": round(flops_launch / launch_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+        "hbm_algorithmic_gbs": round((900.0 * reads_per_launch) / launch_s / 1e9, 3),
+        "pcie_h2d_gbs": round(float(np.mean([b.reads0.numel() for b in piece_batches])) / launch_s / 1e9, 3),
     }
 
-    # BASELINE.json's config 2 names launches of 256 sites: such a launch cannot fill the chip alone, so small
-    # batches are alternated over four engines (own scratch and stream each); reported beside the headline value
-    small = None
-    if world == 1 and not args.no_small_batch:
+    device_resident = latency = small = parity = None
+    if world == 1 and not args.no_secondary:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        # ---- device-resident rate: pileups already in HBM, outputs left there (no PCIe in the loop) --------------
+        try:
+            res = []
+            for b in pool[:2]:
+                a, p = b.n_alleles, n_pairs(b.alleles_per_site)
+                res.append(dict(batch=b, reads=torch.from_numpy(b.reads0).to(dev),
+                                out=(torch.empty((1, a), dtype=torch.float32, device=dev), None,
+                                     torch.empty((4, p), dtype=torch.float32, device=dev))))
+
+            def dstep(i):
+                r = res[i % len(res)]
+                eng.forward(r["reads"], r["batch"].reads_per_allele0, r["batch"].alleles_per_site, stream=stream,
+                            out=r["out"], posteriors=True)
+            for i in range(3):
+                dstep(i)
+            torch.cuda.synchronize(dev)
+            n_dev = 40
+            t1 = time.perf_counter()
+            for i in range(n_dev):
+                dstep(i)
+            torch.cuda.synchronize(dev)
+            dt_dev = time.perf_counter() - t1
+            # per-op device times from a separate, untimed pass (an event record around every op)
+            eng.set_profiling(10)
+            for i in range(10):
+                dstep(i)
+            torch.cuda.synchronize(dev)
+            rows, n_prof = eng.op_times_ms()
+            eng.set_profiling(0)
+            if args.op_times:
+                for i, (k, n, ms) in enumerate(rows):
+                    print(f"  op {i:3d} {k:15s} {ms:9.4f} ms  {n}", file=sys.stderr)
+                print(f"  sum of ops {sum(r[2] for r in rows):.3f} ms over {n_prof} forwards", file=sys.stderr)
+            kernels = {}
+            for op, (k, n, ms) in zip(eng.program.ops, rows):
+                kname = {"conv1d": "conv1d_mfma_kernel", "readconv_fused": "readconv_kernel"}.get(k, k + "_kernel")
+                if k == "conv1d" and (op.flags & 32):
+                    kname = "conv1d_wino_kernel"
+                ent = kernels.setdefault(kname, dict(ms=0.0, launches=0))
+                ent["ms"] += ms
+                ent["launches"] += 1
+            device_resident = {
+                "value": round(args.sites * n_dev / dt_dev, 1), "unit": "sites/s", "sites_per_launch": args.sites,
+                "launches": n_dev, "ms_per_launch": round(1e3 * dt_dev / n_dev, 4),
+                "kernels_ms_per_launch": {kk: round(v["ms"], 4) for kk, v in sorted(kernels.items(), key=lambda x: -x[1]["ms"])},
+                "kernel_launches": {kk: v["launches"] for kk, v in kernels.items()},
+                "note": "inputs resident in HBM, outputs left on the device; per-op table from a separate profiled pass"}
+            del res
+        except Exception as exc:
+            print(f"device-resident leg failed: {exc!r}", file=sys.stderr)
+
+        # ---- latency: the reference's deployment form is ONE site per call (caller_calling.py:872-891) ------------
+        try:
+            from hello_amd.wrapper import ScoringNetwork
+            net = ScoringNetwork(spec, state, device=dev_index, providePredictions=True)
+            lb = synth.make_sites(256, seed=args.seed + 77, coverage=30)
+            names = synth.allele_names(lb)
+            aoff = np.concatenate([[0], np.cumsum(lb.alleles_per_site)])
+            roff = np.concatenate([[0], np.cumsum(lb.reads_per_allele0)])
+            site_args = [({names[s][j]: (torch.from_numpy(lb.reads0[roff[a]:roff[a + 1]]).float(), None)
+                           for j, a in enumerate(range(aoff[s], aoff[s + 1]))},
+                          torch.from_numpy(lb.ref_onehot[s:s + 1]).float()) for s in range(lb.n_sites)]
+            for fd, seg in site_args[:16]:
+                net(fd, seg)
+            t1 = time.perf_counter()
+            for fd, seg in site_args:
+                net(fd, seg)
+            per_site = (time.perf_counter() - t1) / len(site_args)
+
+            def launch_ms(n, on_device, reps):
+                sub = lb.site_slice(0, n)
+                reads = torch.from_numpy(sub.reads0).to(dev) if on_device else sub.reads0
+                for _ in range(3):
+                    net.engine.forward(reads, sub.reads_per_allele0, sub.alleles_per_site, posteriors=True)
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                for _ in range(reps):
+                    net.engine.forward(reads, sub.reads_per_allele0, sub.alleles_per_site, posteriors=True)
+                torch.cuda.synchronize(dev)
+                return 1e3 * (time.perf_counter() - t) / reps
+            latency = {
+                "per_site_call_ms": round(1e3 * per_site, 4), "per_site_calls_per_s": round(1.0 / per_site, 1),
+                "per_site_form": "network(featureDict, ref_segment) -> 5-tuple, float tensors in, one engine, host in/out",
+                "launch_1_site_host_ms": round(launch_ms(1, False, 50), 4),
+                "launch_16_sites_host_ms": round(launch_ms(16, False, 50), 4),
+                "launch_256_sites_host_ms": round(launch_ms(256, False, 30), 4),
+                "launch_16_sites_device_ms": round(launch_ms(16, True, 50), 4),
+                "launch_256_sites_device_ms": round(launch_ms(256, True, 50), 4),
+                "note": "ONE engine, one stream; *_host: NumPy arrays in, NumPy logits + posteriors out (synchronous); "
+                        "*_device: resident input, back-to-back asynchronous launches (steady-state ms per launch)"}
+            latency["launch_256_sites_device_sites_per_s"] = round(256e3 / latency["launch_256_sites_device_ms"], 1)
+            net.close()
+        except Exception as exc:
+            print(f"latency leg failed: {exc!r}", file=sys.stderr)
+
+        # BASELINE.json's config 2 names launches of 256 sites: such a launch cannot fill the chip alone, so small
+        # batches are alternated over four engines (own scratch and stream each); reported beside the headline value
         try:
             small_engines = [eng] + [Engine(spec, state, device=dev_index) for _ in range(3)]
             streams = [torch.cuda.Stream(dev) for _ in small_engines]
@@ -333,32 +481,41 @@ def main():
         except Exception as exc:
             print(f"small-batch leg failed: {exc!r}", file=sys.stderr)
 
-    parity = None
-    if cpu is not None and getattr(cpu_baseline, "reference_answers", None) is not None:
-        check, want_probs, want_post = cpu_baseline.reference_answers
-        got_logits, _, got_post = eng.forward_batch(check, posteriors=True)
-        got_probs = 1.0 / (1.0 + np.exp(-got_logits[0].astype(np.float64)))
-        parity = {"max_abs_delta_allele_probability": float(np.abs(got_probs - want_probs).max()),
-                  "max_abs_delta_pair_posterior": float(np.abs(got_post[0] - want_post).max()),
-                  "tolerance": 1e-4, "sites": int(check.n_sites), "alleles": int(check.n_alleles),
-                  "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
+        if cpu is not None and getattr(cpu_baseline, "reference_answers", None) is not None:
+            check, want_probs, want_post = cpu_baseline.reference_answers
+            got_logits, _, got_post = eng.forward_batch(check, posteriors=True)
+            got_probs = 1.0 / (1.0 + np.exp(-got_logits[0].astype(np.float64)))
+            parity = {"max_abs_delta_allele_probability": float(np.abs(got_probs - want_probs).max()),
+                      "max_abs_delta_pair_posterior": float(np.abs(got_post[0] - want_post).max()),
+                      "tolerance": 1e-4, "sites": int(check.n_sites), "alleles": int(check.n_alleles),
+                      "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
 
     if rank == 0:
-        b0 = pool[0]["batch"]
+        b0 = pool[0]
         line = {
             "metric": "candidate sites/sec (whole node)", "value": round(value, 1), "unit": "sites/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / max(args.steps, 1), 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Illumina 30x single-tech model (moe_attention single_tech weight_norm), "
-                                   "synthetic pileups cov 30, seeded synthetic weights",
-                       "sites_per_step_per_gpu": args.sites, "sites_total": sites_total,
+            "config": {"workload": "Illumina 30x single-tech model (moe_attention single_tech weight_norm), synthetic "
+                                   f"pileups cov 30, seeded synthetic weights; host-resident uint8 pileups + counts -> "
+                                   f"host-resident logits + genotype-pair posteriors (PCIe both ways inside the timed "
+                                   f"region) through shard.partition_sites + HostPipeline; a step = "
+                                   f"{args.launches_per_step} launches x {args.sites} sites per GPU, cycling a pinned "
+                                   f"pool of {args.pool} distinct batches",
+                       "sites_per_launch": args.sites, "launches_per_step_per_gpu": args.launches_per_step,
+                       "sites_per_step": int(sum(s for s, _ in sizes)), "sites_total": int(sites_total),
+                       "timed_region_s": round(dt, 3),
                        "reads_per_site": round(b0.reads0.shape[0] / b0.n_sites, 2),
                        "alleles_per_site": round(b0.n_alleles / b0.n_sites, 3),
-                       "window": 150, "channels": 6, "parallelism": f"site-sharded dp{world}",
-                       "fused_read_convolver": bool(fused), "outputs": "logits + genotype-pair posteriors"},
+                       "window": 150, "channels": 6, "parallelism": f"site-sharded dp{world}, one gather at the end",
+                       "fused_read_convolver": bool(fused), "outputs": "logits + genotype-pair posteriors (host)",
+                       "host_cpus_of_rank0": len(cpus),
+                       "repeat_passes_bit_identical": drift == 0, "outputs_finite": bool(finite)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "device_resident": device_resident,
+            "latency": latency,
             "parity": parity,
             "small_batch": small,
         }
@@ -367,6 +524,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if drift:
+        raise SystemExit(f"{drift} repeated passes differed from the first pass over the same batch")
 
 
 if __name__ == "__main__":

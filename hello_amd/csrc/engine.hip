@@ -101,6 +101,10 @@ struct hello_engine {
     // profiling ring: events[f][i] brackets op i of the f-th profiled forward (i = n_ops: end marker)
     std::vector<std::vector<hipEvent_t>> prof_events;
     int prof_count = 0;              // forwards recorded since profiling was (re)enabled
+    int prof_filter = 0;             // record only around ops of this kind (0: all)
+    int debug_op = -1;               // op whose dst is snapshotted after it ran (-1: none)
+    DevBuf d_debug;
+    size_t debug_floats = 0;         // size of the last snapshot
 
     // device views into d_csr for the current batch
     int32_t *roff0 = nullptr, *roff1 = nullptr, *aoff = nullptr, *site_of_allele = nullptr;
@@ -277,6 +281,7 @@ void hello_engine_destroy(hello_engine* e) {
     e->d_partial.release();
     e->d_feat_in.release();
     e->d_feat_out.release();
+    e->d_debug.release();
     if (e->d_weights) (void)hipFree(e->d_weights);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     if (e->ev_staged) (void)hipEventDestroy(e->ev_staged);
@@ -310,12 +315,16 @@ int hello_engine_set_profiling(hello_engine* e, int max_forwards) {
     e->profiling = max_forwards > 0;
     e->prof_count = 0;
     if ((int)e->prof_events.size() < max_forwards) e->prof_events.resize(max_forwards);
-    for (int f = 0; f < max_forwards; ++f) {
-        auto& ring = e->prof_events[f];
-        ring.resize(e->ops.size() + 1, nullptr);
-        for (auto& ev : ring)
-            if (!ev) HIP_TRY(hipEventCreate(&ev));
-    }
+    // events are created when a forward first records them (a filtered recording needs two per matching op)
+    for (int f = 0; f < max_forwards; ++f) e->prof_events[f].resize(e->ops.size() + 1, nullptr);
+    return HELLO_OK;
+}
+
+int hello_engine_set_profiling_filter(hello_engine* e, int32_t op_kind) {
+    if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
+    if (op_kind < 0 || op_kind > HELLO_OP_READCONV_FUSED) return fail(HELLO_ERR_ARG, "unknown op kind %d", op_kind);
+    e->prof_filter = op_kind;
+    e->prof_count = 0;               // recordings made under another filter do not mix
     return HELLO_OK;
 }
 
@@ -329,6 +338,7 @@ int hello_engine_op_times_ms(hello_engine* e, float* ms_sum, int32_t capacity, i
         auto& ring = e->prof_events[f];
         HIP_TRY(hipEventSynchronize(ring[e->ops.size()]));
         for (int i = 0; i < n; ++i) {
+            if (e->prof_filter && e->ops[i].kind != e->prof_filter) continue;
             float t = 0.f;
             HIP_TRY(hipEventElapsedTime(&t, ring[i], ring[i + 1]));
             ms_sum[i] += t;
@@ -336,6 +346,28 @@ int hello_engine_op_times_ms(hello_engine* e, float* ms_sum, int32_t capacity, i
     }
     *n_ops = n;
     *n_forwards = e->prof_count;
+    return HELLO_OK;
+}
+
+int hello_engine_debug_capture(hello_engine* e, int32_t op_index) {
+    if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
+    if (op_index < -1 || op_index >= (int)e->ops.size()) return fail(HELLO_ERR_ARG, "op index %d out of range", op_index);
+    if (op_index >= 0 && e->ops[op_index].kind == HELLO_OP_HEAD)
+        return fail(HELLO_ERR_ARG, "op %d is a HEAD: its output is the logits / meta array itself", op_index);
+    e->debug_op = op_index;
+    e->debug_floats = 0;
+    return HELLO_OK;
+}
+
+int hello_engine_debug_read(hello_engine* e, float* out, int64_t capacity, int64_t* n_floats) {
+    if (!e || !n_floats) return fail(HELLO_ERR_ARG, "NULL argument");
+    *n_floats = (int64_t)e->debug_floats;
+    if (!out) return HELLO_OK;
+    if (e->debug_floats == 0) return fail(HELLO_ERR_ARG, "no forward has run since hello_engine_debug_capture");
+    if (capacity < (int64_t)e->debug_floats) return fail(HELLO_ERR_ARG, "capacity %lld < %zu floats", (long long)capacity, e->debug_floats);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->last_stream ? e->last_stream : e->own_stream));
+    HIP_TRY(hipMemcpy(out, e->d_debug.p, e->debug_floats * sizeof(float), hipMemcpyDeviceToHost));
     return HELLO_OK;
 }
 
@@ -567,8 +599,19 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     if (e->profiling && e->prof_count < (int)e->prof_events.size() &&
         e->prof_events[e->prof_count].size() == e->ops.size() + 1)
         ring = &e->prof_events[e->prof_count];
+    // an event of the ring is created the first time a forward records it; with a filter only the two events
+    // that bracket a matching op are recorded
+    auto mark = [&](int slot) -> int {
+        hipEvent_t& ev = (*ring)[slot];
+        if (!ev) HIP_TRY(hipEventCreate(&ev));
+        HIP_TRY(hipEventRecord(ev, stream));
+        return 0;
+    };
+    const int n_ops_total = (int)e->ops.size();
+    auto wanted = [&](int i) { return i >= 0 && i < n_ops_total && (!e->prof_filter || e->ops[i].kind == e->prof_filter); };
     for (const hello_op& o : e->ops) {
-        if (ring) HIP_TRY(hipEventRecord((*ring)[op_index], stream));
+        if (ring && (wanted(op_index) || wanted(op_index - 1)))
+            if (int rc = mark(op_index)) return rc;
         const long long rows = rows_of(o.domain, S, A, R0, R1);
         switch (o.kind) {
             case HELLO_OP_CONV1D: {
@@ -660,10 +703,23 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 break;
             }
         }
+        if (op_index == e->debug_op) {
+            // snapshot of this op's output before a later op reuses the buffer
+            const size_t per_row = o.kind == HELLO_OP_CONCAT ? (size_t)o.lout * (o.cin + o.c1)
+                                   : (o.kind == HELLO_OP_CONV1D || o.kind == HELLO_OP_READCONV_FUSED) ? (size_t)o.lout * o.cout
+                                   : (o.kind == HELLO_OP_MAXPOOL ? (size_t)o.lout * o.cin : (size_t)o.lin * o.cin);
+            const size_t n = (size_t)rows * per_row;
+            if (n * sizeof(float) > e->d_debug.cap) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (e->d_debug.ensure(n * sizeof(float))) return fail(HELLO_ERR_HIP, "device allocation of %zu bytes failed", n * sizeof(float));
+            }
+            HIP_TRY(hipMemcpyAsync(e->d_debug.p, ptr(o.dst), n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            e->debug_floats = n;
+        }
         ++op_index;
     }
     if (ring) {
-        HIP_TRY(hipEventRecord((*ring)[op_index], stream));
+        if (int rc = mark(op_index)) return rc;     // the end marker (op_times_ms waits for it)
         e->prof_count++;
     }
     if (posteriors)
@@ -676,8 +732,10 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
         HIP_TRY(hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, stream));
         if (d.has_meta) HIP_TRY(hipMemcpyAsync(meta, d_meta, meta_bytes, hipMemcpyDeviceToHost, stream));
         if (posteriors) HIP_TRY(hipMemcpyAsync(posteriors, d_post, post_bytes, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
     }
+    // host pointers may be pageable and die with the caller's frame: the copies from / to them are complete
+    // only after this (device-in / device-out calls stay asynchronous on the stream)
+    if (!in_dev || !out_dev) HIP_TRY(hipStreamSynchronize(stream));
     return HELLO_OK;
 }
 

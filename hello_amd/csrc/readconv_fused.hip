@@ -1391,9 +1391,9 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         configured = true;
     }
+    if (a.groups_per_wg < 1) return hipErrorInvalidValue;
     const long long per_wg = (long long)CF::G * a.groups_per_wg;
     const unsigned groups = (unsigned)((a.n_reads + per_wg - 1) / per_wg);       // workgroups
-    if (a.groups_per_wg < 1) return hipErrorInvalidValue;
     if (a.reads) {
         if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
         hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);

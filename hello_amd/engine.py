@@ -67,11 +67,15 @@ def load_library():
     lib.hello_engine_last_forward_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.hello_engine_set_profiling.argtypes = [vp, C.c_int]
     lib.hello_engine_op_times_ms.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.hello_engine_set_profiling_filter.argtypes = [vp, i32]
+    lib.hello_engine_debug_capture.argtypes = [vp, i32]
+    lib.hello_engine_debug_read.argtypes = [vp, vp, i64, C.POINTER(i64)]
     lib.hello_engine_destroy.argtypes = [vp]
     lib.hello_engine_destroy.restype = None
     for fn in ("hello_engine_create", "hello_engine_forward", "hello_engine_posteriors",
                "hello_engine_synchronize", "hello_engine_last_forward_ms", "hello_engine_set_profiling",
-               "hello_engine_op_times_ms"):
+               "hello_engine_op_times_ms", "hello_engine_set_profiling_filter", "hello_engine_debug_capture",
+               "hello_engine_debug_read"):
         getattr(lib, fn).restype = C.c_int
     _lib = lib
     return lib
@@ -152,24 +156,60 @@ class Engine:
         S, A = int(aps.shape[0]), int(rpa0.shape[0])
         on_device = _is_torch(reads0) and reads0.is_cuda
         flags = HELLO_LAYOUT_RCL if layout_rcl else 0
+        prog = self.program
+        if rpa0.ndim != 1 or aps.ndim != 1 or (rpa1 is not None and rpa1.shape != rpa0.shape):
+            raise ValueError("count arrays must be one-dimensional (reads_per_allele1 as long as reads_per_allele0)")
 
-        def prep(x):
+        def prep(x, what, trailing):
+            """Only the leading dimension crosses the C ABI, which then reads rows * prod(trailing) bytes:
+            every shape, dtype, device and contiguity assumption is checked here (the reference raises a
+            Conv1d channel error for a pileup of the wrong width, NNTools.py:633-657)."""
             if x is None:
                 return None, 0, None
+            if tuple(x.shape[1:]) != trailing or len(x.shape) != 3:
+                raise ValueError(f"{what}: expected [rows, {trailing[0]}, {trailing[1]}] "
+                                 f"({'[R, C, L]' if layout_rcl and what != 'ref_onehot' else 'channels last'}), "
+                                 f"got {tuple(x.shape)}")
             if on_device:
                 import torch
-                assert x.is_cuda and x.dtype == torch.uint8 and x.is_contiguous()
+                if not (_is_torch(x) and x.is_cuda):
+                    raise ValueError(f"{what}: device and host inputs cannot be mixed in one call")
+                if x.dtype != torch.uint8:
+                    raise TypeError("pileup tensors must be uint8")
+                if x.device.index != self.device:
+                    raise ValueError(f"{what} lives on cuda:{x.device.index}, the engine on cuda:{self.device}")
+                if not x.is_contiguous():
+                    raise ValueError(f"{what} must be contiguous")
                 return x, x.data_ptr(), x
-            arr = np.ascontiguousarray(x.cpu().numpy() if _is_torch(x) else x)
+            if _is_torch(x) and x.is_cuda:
+                raise ValueError(f"{what}: device and host inputs cannot be mixed in one call")
+            arr = x.numpy() if _is_torch(x) else np.asarray(x)
             if arr.dtype != np.uint8:
                 raise TypeError("pileup tensors must be uint8")
+            arr = np.ascontiguousarray(arr)
             return arr, arr.ctypes.data, arr
 
-        r0, p0, keep0 = prep(reads0)
-        r1, p1, keep1 = prep(reads1)
-        rf, pf, keepf = prep(ref_onehot)
+        def trailing(channels):
+            return (channels, prog.window) if layout_rcl else (prog.window, channels)
+
+        if prog.channels1 and reads1 is None:
+            raise ValueError("this model scores two read technologies: reads1 / reads_per_allele1 are required")
+        if not prog.channels1:
+            reads1 = rpa1 = None                # like the reference's single-technology forward, which never reads them
+        elif rpa1 is None:
+            raise ValueError("reads1 given without reads_per_allele1")
+        if prog.uses_ref and ref_onehot is None:
+            raise ValueError("this model reads the one-hot reference segment: ref_onehot [S, window, 5] is required")
+        if not prog.uses_ref:
+            ref_onehot = None
+        r0, p0, keep0 = prep(reads0, "reads0", trailing(prog.channels0))
+        r1, p1, keep1 = prep(reads1, "reads1", trailing(prog.channels1))
+        rf, pf, keepf = prep(ref_onehot, "ref_onehot", (prog.window, 5))
         n0 = int(r0.shape[0])
         n1 = int(r1.shape[0]) if r1 is not None else 0
+        if rf is not None and int(rf.shape[0]) != S:
+            raise ValueError(f"ref_onehot holds {int(rf.shape[0])} segments for {S} sites")
+        P = n_pairs(aps) if posteriors else 0
         if on_device:
             import torch
             flags |= HELLO_IN_DEVICE | HELLO_OUT_DEVICE
@@ -177,20 +217,34 @@ class Engine:
             if out is not None:
                 logits, meta = out[0], out[1]
                 post = out[2] if len(out) > 2 else None
+                for t, need, what in ((logits, self.n_experts * A, "out[0] (logits)"),
+                                      (meta if self.has_meta else None, S * 3, "out[1] (meta)"),
+                                      (post if posteriors else None, 4 * P, "out[2] (posteriors)")):
+                    if t is None:
+                        continue
+                    if not (_is_torch(t) and t.is_cuda and t.device.index == self.device and t.dtype == torch.float32):
+                        raise ValueError(f"{what} must be a float32 tensor on cuda:{self.device}")
+                    if not t.is_contiguous() or t.numel() != need:
+                        raise ValueError(f"{what} must be contiguous with exactly {need} elements "
+                                         f"(got {'a non-contiguous view' if not t.is_contiguous() else t.numel()})")
+                if self.has_meta and meta is None:
+                    raise ValueError("this model produces meta weights: out[1] is required")
             else:
                 logits = torch.empty((self.n_experts, A), dtype=torch.float32, device=reads0.device)
                 meta = torch.empty((S, 3), dtype=torch.float32, device=reads0.device) if self.has_meta else None
             if posteriors and post is None:
-                post = torch.empty((4, n_pairs(aps)), dtype=torch.float32, device=reads0.device)
+                post = torch.empty((4, P), dtype=torch.float32, device=reads0.device)
             lp = logits.data_ptr()
             mp = meta.data_ptr() if meta is not None else None
             pp = post.data_ptr() if posteriors else None
             if stream is None:
                 stream = torch.cuda.current_stream(reads0.device).cuda_stream
         else:
+            if out is not None:
+                raise ValueError("preallocated outputs are a device-path feature")
             logits = np.empty((self.n_experts, A), dtype=np.float32)
             meta = np.empty((S, 3), dtype=np.float32) if self.has_meta else None
-            post = np.empty((4, n_pairs(aps)), dtype=np.float32) if posteriors else None
+            post = np.empty((4, P), dtype=np.float32) if posteriors else None
             lp = logits.ctypes.data
             mp = meta.ctypes.data if meta is not None else None
             pp = post.ctypes.data if posteriors else None
@@ -232,9 +286,25 @@ class Engine:
         _check(self.lib.hello_engine_last_forward_ms(self.handle, C.byref(ms)))
         return float(ms.value)
 
-    def set_profiling(self, max_forwards: int):
-        """Arm per-op HIP-event timing for the next ``max_forwards`` forwards (0 disarms)."""
+    def set_profiling(self, max_forwards: int, only: Optional[str] = None):
+        """Arm per-op HIP-event timing for the next ``max_forwards`` forwards (0 disarms).  ``only`` = an op
+        kind name of ``compiler.OP_NAMES`` ("readconv_fused", ...): record around ops of that kind alone (two
+        events per op and forward -- cheap enough for a timed region)."""
+        kind = 0 if only is None else {v: k for k, v in compiler.OP_NAMES.items()}[only]
+        _check(self.lib.hello_engine_set_profiling_filter(self.handle, kind))
         _check(self.lib.hello_engine_set_profiling(self.handle, int(max_forwards)))
+
+    def capture_op_output(self, op_index: Optional[int]):
+        """Debug: snapshot the output of op ``op_index`` of every following forward (None disarms)."""
+        _check(self.lib.hello_engine_debug_capture(self.handle, -1 if op_index is None else int(op_index)))
+
+    def read_op_output(self) -> np.ndarray:
+        """The snapshot of the last forward, float32 [rows, positions, channels] (rows of the op's domain)."""
+        n = C.c_int64()
+        _check(self.lib.hello_engine_debug_read(self.handle, None, 0, C.byref(n)))
+        out = np.empty(int(n.value), dtype=np.float32)
+        _check(self.lib.hello_engine_debug_read(self.handle, out.ctypes.data, out.size, C.byref(n)))
+        return out
 
     def op_times_ms(self):
         """-> (list of (op kind, layer name, mean ms per forward), number of forwards averaged)."""

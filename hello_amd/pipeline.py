@@ -50,6 +50,18 @@ def _grow(t, n, **kw):
     return t
 
 
+def pin_batch(batch):
+    """A SiteBatch whose pileup arrays are pinned torch tensors (slices along the read axis stay pinned and
+    contiguous, so ``site_slice`` views of it cross PCIe without a staging copy)."""
+    import torch
+    from .synth import SiteBatch
+
+    def pin(x):
+        return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).pin_memory()
+    return SiteBatch(pin(batch.reads0), batch.reads_per_allele0, batch.alleles_per_site, pin(batch.ref_onehot),
+                     pin(batch.reads1), batch.reads_per_allele1)
+
+
 class HostPipeline:
     def __init__(self, engine: Optional[Engine] = None, depth: int = 2, posteriors: bool = True,
                  engines: Optional[List[Engine]] = None):
@@ -108,8 +120,11 @@ class HostPipeline:
         return tag, logits, meta, post
 
     # ------------------------------------------------------------------------------------------
-    def submit(self, batch, tag=None) -> List[Tuple]:
-        """Queue one batch; returns the batches that finished meanwhile (possibly none), oldest first."""
+    def submit(self, batch, tag=None, sink=None) -> List[Tuple]:
+        """Queue one batch; returns the batches that finished meanwhile (possibly none), oldest first.
+        ``sink`` = (logits_dev [E, >= col + A], meta_dev [>= row + S, 3] | None, col, row): the batch's logits
+        (and meta) are also copied, on the compute stream, into these device tensors at that allele column /
+        site row -- the multi-GPU path keeps a rank's results resident for the one gather at the end."""
         import torch
         index = self.count % len(self.slots)
         e = self.engines[index % len(self.engines)]
@@ -149,6 +164,11 @@ class HostPipeline:
             e.forward(dev[0], batch.reads_per_allele0, aps, dev[1],
                       batch.reads_per_allele1 if dev[1] is not None else None, dev[2],
                       stream=compute.cuda_stream, out=out, posteriors=self.posteriors)
+            if sink is not None:
+                sink_logits, sink_meta, col, row = sink
+                sink_logits[:, col:col + A].copy_(out[0], non_blocking=True)
+                if sink_meta is not None and out[1] is not None:
+                    sink_meta[row:row + S].copy_(out[1], non_blocking=True)
             for i, n in enumerate(sizes):
                 if n:
                     slot.pinned_out[i][:n].copy_(slot.dev_out[i][:n], non_blocking=True)

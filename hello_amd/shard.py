@@ -2,10 +2,15 @@
 reference python/MixtureOfExpertsAdvanced.py:161-252), so a batch is cut into contiguous site ranges
 balanced by read count, every rank scores its range with its own engine (weights replicated, like the
 reference's one-model-per-worker process pool, python/call.py:111,215-221), and the per-allele logits
-are collected with ONE gather to rank 0 (RCCL over xGMI with the "nccl" backend; "gloo" in CPU tests).
+(+ per-site meta weights of ensemble models, packed behind them in the same buffer) are collected with
+exactly ONE collective: a gather to rank 0 (RCCL over xGMI with the "nccl" backend; "gloo" in CPU tests).
+
+Every rank holds the batch's counts, so every rank computes the same partition and therefore every
+rank's allele / site counts locally: there is no size exchange and no host-blocking ``.item()``.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -31,64 +36,140 @@ def partition_sites(reads_per_site: Sequence[int], n_parts: int) -> List[Tuple[i
     return [(cuts[i], cuts[i + 1]) for i in range(n_parts)]
 
 
-def reads_per_site(batch) -> np.ndarray:
-    """Read count of every site of a SiteBatch (both technologies)."""
-    aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
-    r = np.add.reduceat(batch.reads_per_allele0.astype(np.int64), aoff[:-1])
-    if batch.reads_per_allele1 is not None:
-        r = r + np.add.reduceat(batch.reads_per_allele1.astype(np.int64), aoff[:-1])
+def reads_per_site_counts(alleles_per_site, reads_per_allele0, reads_per_allele1=None) -> np.ndarray:
+    """Read count of every site from the CSR counts (both technologies)."""
+    aps = np.asarray(alleles_per_site, dtype=np.int64)
+    aoff = np.concatenate([[0], np.cumsum(aps)])
+    r = np.add.reduceat(np.asarray(reads_per_allele0, dtype=np.int64), aoff[:-1])
+    if reads_per_allele1 is not None:
+        r = r + np.add.reduceat(np.asarray(reads_per_allele1, dtype=np.int64), aoff[:-1])
     return r
 
 
-def gather_rows(local, dst: int = 0, group=None):
-    """Gather variable-length [E, n_local] float32 tensors to ``dst`` and concatenate along dim 1 in rank
-    order.  One size exchange + one padded gather; returns the concatenation on ``dst``, None elsewhere."""
+def reads_per_site(batch) -> np.ndarray:
+    """Read count of every site of a SiteBatch (both technologies)."""
+    return reads_per_site_counts(batch.alleles_per_site, batch.reads_per_allele0, batch.reads_per_allele1)
+
+
+def shard_sizes(alleles_per_site, ranges: Sequence[Tuple[int, int]]) -> List[Tuple[int, int]]:
+    """(sites, alleles) of every rank's range -- computed locally by every rank from the shared counts."""
+    aoff = np.concatenate([[0], np.cumsum(np.asarray(alleles_per_site, dtype=np.int64))])
+    return [(hi - lo, int(aoff[hi] - aoff[lo])) for lo, hi in ranges]
+
+
+def _row_floats(n_experts: int, has_meta: bool, sites: int, alleles: int) -> int:
+    return n_experts * alleles + (3 * sites if has_meta else 0)
+
+
+def gather_results(logits, meta, sizes: Sequence[Tuple[int, int]], n_experts: int, has_meta: bool,
+                   dst: int = 0, group=None):
+    """THE collective of the path.  ``logits`` [E, A_rank] and ``meta`` [S_rank, 3] | None (torch tensors on
+    the communicator's device; a rank with an empty range passes empty tensors or None) are packed into one
+    flat row, padded to the widest rank's row, and gathered to ``dst`` with a single ``dist.gather``.
+    ``sizes`` = shard_sizes(...) -- the same list on every rank.  Returns (logits [E, A], meta [S, 3] | None)
+    on ``dst`` in rank (= site) order, (None, None) elsewhere."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    n_local = torch.tensor([local.shape[1]], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    width = max(max(sizes), 1)
-    padded = torch.zeros((local.shape[0], width), dtype=local.dtype, device=local.device)
-    padded[:, :local.shape[1]] = local
-    bucket = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, bucket, dst=dst, group=group)
+    if len(sizes) != world:
+        raise ValueError(f"{len(sizes)} shard sizes for a world of {world}")
+    s_r, a_r = sizes[rank]
+    device = _default_device()          # the communicator's: RCCL wants device buffers, gloo host buffers
+    width = max(max(_row_floats(n_experts, has_meta, s, a) for s, a in sizes), 1)
+    row = torch.zeros(width, dtype=torch.float32, device=device)
+    if a_r:
+        if tuple(logits.shape) != (n_experts, a_r):
+            raise ValueError(f"rank {rank}: logits are {tuple(logits.shape)}, its range holds [{n_experts}, {a_r}]")
+        row[:n_experts * a_r] = logits.reshape(-1).to(device=device, dtype=torch.float32)
+    if has_meta and s_r:
+        if meta is None or tuple(meta.shape) != (s_r, 3):
+            raise ValueError(f"rank {rank}: meta is missing or not [{s_r}, 3]")
+        row[n_experts * a_r:n_experts * a_r + 3 * s_r] = meta.reshape(-1).to(device=device, dtype=torch.float32)
+    bucket = [torch.empty_like(row) for _ in range(world)] if rank == dst else None
+    dist.gather(row, bucket, dst=dst, group=group)
     if rank != dst:
-        return None
-    return torch.cat([b[:, :n] for b, n in zip(bucket, sizes)], dim=1)
-
-
-def score_sharded(score_fn, batch, rank: int, world: int, dst: int = 0, group=None, device=None):
-    """Score ``batch`` across ``world`` ranks.  ``score_fn(sub_batch) -> (logits [E, A_sub], meta | None)``
-    (NumPy or torch).  Returns (logits [E, A], meta [S, 3] | None) on ``dst``; (None, None) elsewhere."""
-    import torch
-    lo, hi = partition_sites(reads_per_site(batch), world)[rank]
-    n_exp = None
-    if hi > lo:
-        logits, meta = score_fn(batch.site_slice(lo, hi))
-        logits = torch.as_tensor(logits)
-        meta = None if meta is None else torch.as_tensor(meta)
-        n_exp = logits.shape[0]
-    else:
-        logits, meta = None, None
-    # ranks with an empty range still take part in the collective
-    import torch.distributed as dist
-    info = torch.tensor([n_exp or 0, 0 if meta is None else 1], dtype=torch.int64)
-    if device is not None:
-        info = info.to(device)
-    dist.all_reduce(info, op=dist.ReduceOp.MAX, group=group)
-    n_exp, has_meta = int(info[0].item()), bool(info[1].item())
-    dev = device if device is not None else (logits.device if logits is not None else "cpu")
-    if logits is None:
-        logits = torch.zeros((n_exp, 0), dtype=torch.float32, device=dev)
-    logits = logits.to(dev, dtype=torch.float32)
-    out = gather_rows(logits, dst, group)
+        return None, None
+    out = torch.cat([b[:n_experts * a].view(n_experts, a) for b, (s, a) in zip(bucket, sizes)], dim=1)
     out_meta = None
     if has_meta:
-        m = torch.zeros((3, 0), dtype=torch.float32, device=dev) if meta is None else meta.to(dev).t().contiguous()
-        g = gather_rows(m, dst, group)
-        out_meta = None if g is None else g.t().contiguous()
+        out_meta = torch.cat([b[n_experts * a:n_experts * a + 3 * s].view(s, 3) for b, (s, a) in zip(bucket, sizes)], dim=0)
     return out, out_meta
+
+
+def _default_device():
+    """The communicator's device: the current CUDA device under the nccl (= RCCL) backend, else the CPU."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def score_sharded(score_fn, batch, rank: int, world: int, n_experts: int = 1, has_meta: bool = False,
+                  dst: int = 0, group=None, device=None):
+    """Score ``batch`` across ``world`` ranks.  ``score_fn(sub_batch) -> (logits [E, A_sub], meta | None)``
+    (NumPy or torch).  ``n_experts`` / ``has_meta`` are properties of the model (``Engine.n_experts`` /
+    ``Engine.has_meta``): a rank whose range is empty still knows the row layout.  Returns (logits [E, A],
+    meta [S, 3] | None) on ``dst``; (None, None) elsewhere.  One collective (``gather_results``)."""
+    import torch
+    ranges = partition_sites(reads_per_site(batch), world)
+    sizes = shard_sizes(batch.alleles_per_site, ranges)
+    lo, hi = ranges[rank]
+    dev = torch.device(device) if device is not None else _default_device()
+    logits = meta = None
+    if hi > lo:
+        logits, meta = score_fn(batch.site_slice(lo, hi))
+        logits = torch.as_tensor(logits).to(dev)
+        meta = None if meta is None else torch.as_tensor(meta).to(dev)
+    else:
+        logits = torch.zeros((n_experts, 0), dtype=torch.float32, device=dev)
+    return gather_results(logits, meta, sizes, n_experts, has_meta, dst, group)
+
+
+# ------------------------------------------------------------------------------------------------
+# host side of one rank: CPU affinity near its GPU
+# ------------------------------------------------------------------------------------------------
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def rank_cpus(local_rank: int, local_world: int, device_index: Optional[int] = None) -> List[int]:
+    """CPUs one rank's host threads (pinned staging copies, CSR building) should run on: an equal share of
+    the CPUs this process may use, taken from the NUMA node of the rank's GPU when sysfs tells it (the ranks
+    on the same node split that node's CPUs), else a plain equal split of the affinity mask."""
+    allowed = sorted(os.sched_getaffinity(0))
+    node_cpus = None
+    if device_index is not None:
+        try:
+            import torch
+            prop = torch.cuda.get_device_properties(device_index)
+            bdf = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
+            node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+            if node >= 0:
+                node_cpus = [c for c in _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+                             if c in set(allowed)]
+        except Exception:
+            node_cpus = None
+    pool = node_cpus if node_cpus else allowed
+    share = max(1, len(pool) // max(local_world, 1))
+    start = (local_rank % max(1, len(pool) // share)) * share
+    mine = pool[start:start + share]
+    return mine or allowed
+
+
+def pin_rank(local_rank: int, local_world: int, device_index: Optional[int] = None) -> List[int]:
+    """Apply ``rank_cpus`` to this process (call before allocating the rank's pinned pool, so first touch lands
+    near the GPU).  Returns the CPUs set; never raises (a container may forbid it)."""
+    cpus = rank_cpus(local_rank, local_world, device_index)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        pass
+    return cpus

@@ -203,6 +203,19 @@ int hello_engine_last_forward_ms(hello_engine* engine, float* ms);
 int hello_engine_set_profiling(hello_engine* engine, int max_forwards);
 int hello_engine_op_times_ms(hello_engine* engine, float* ms_sum, int32_t capacity, int32_t* n_ops,
                              int32_t* n_forwards);
+/* Restrict the recording to ops of one hello_op_kind (0 = every op): two event records per matching op and
+ * forward instead of one per op, cheap enough to stay armed inside a timed region (bench.py times the
+ * dominant kernel, HELLO_OP_READCONV_FUSED, this way).  Ops of other kinds then report 0 ms. */
+int hello_engine_set_profiling_filter(hello_engine* engine, int32_t op_kind);
+
+/* Debug read-back of one op's output (parity tests of single kernels; the reference's counterpart is a forward
+ * hook on the module).  debug_capture(i >= 0) arms: every following forward copies the dst buffer of op i,
+ * right after the op has run (scratch buffers are reused by later ops), into an engine-owned device buffer;
+ * debug_capture(-1) disarms.  debug_read waits for the last forward and copies that snapshot to the host:
+ * float32 [rows of the op's domain][positions][channels], `*n_floats` = its size (also when `out` is NULL or
+ * `capacity` too small, which is HELLO_ERR_ARG unless out is NULL). */
+int hello_engine_debug_capture(hello_engine* engine, int32_t op_index);
+int hello_engine_debug_read(hello_engine* engine, float* out, int64_t capacity, int64_t* n_floats);
 
 void hello_engine_destroy(hello_engine* engine);
 

@@ -216,12 +216,13 @@ def _forward_merged(self, tensors, alleles_per_site, reads_per_allele):
     (:369-370, :422-436); expert input a - (repeat(s) - a) (:372-383); meta softmax over dim 1 (:480)."""
     spec = self.spec
     aps = np.asarray(alleles_per_site, dtype=np.int64)
-    a0 = self._net("alleleConv0", segment_sum(self._net("readConv0", np.asarray(tensors[0], dtype=F32)),
-                                              reads_per_allele[0]))
+    frames0 = segment_sum(self._net("readConv0", np.asarray(tensors[0], dtype=F32)), reads_per_allele[0])
+    a0 = self._net("alleleConv0", frames0)
+    frames = {"frames0": frames0}
     hybrid = spec.has("readConv1") and tensors[1] is not None
     if hybrid:
-        a1 = self._net("alleleConv1", segment_sum(self._net("readConv1", np.asarray(tensors[1], dtype=F32)),
-                                                  reads_per_allele[1]))
+        frames["frames1"] = segment_sum(self._net("readConv1", np.asarray(tensors[1], dtype=F32)), reads_per_allele[1])
+        a1 = self._net("alleleConv1", frames["frames1"])
         a2 = self._net("alleleConvCombiner", (a0, a1)) if spec.has("alleleConvCombiner") else a0 + a1
     s0 = segment_sum(a0, aps)
 
@@ -230,7 +231,7 @@ def _forward_merged(self, tensors, alleles_per_site, reads_per_allele):
         return self._net(f"expert{idx}", allele - remaining)
 
     p0 = expert(0, a0, s0)
-    self.last = {"ca0": a0}
+    self.last = dict(frames, ca0=a0)
     if not hybrid:
         return p0
     s1 = segment_sum(a1, aps)

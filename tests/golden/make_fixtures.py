@@ -414,9 +414,49 @@ def make_addendum_pickle_fixture():
           f"[{res['logits'].min():.3f},{res['logits'].max():.3f}]")
 
 
+FRAME_CASES = ["single_tech_hp", "single_tech_deep", "hybrid_no_ensemble", "merged_single", "merged_hybrid_250",
+               "single_tech_softplus", "single_tech_addendum", "single_tech_bn"]
+
+
+def make_frames_fixture():
+    """Kernel-level pins for the fused read convolver: the reference's per-allele frames
+    reduceSlots(read_convolver(x)) ([sum A, 64, L2], MixtureOfExpertsAdvanced.py:162-163) of BOTH technologies on
+    the committed inputs of existing fixtures (7 channels, 90-128 reads per site, 250 bp windows, Softplus, the
+    transfer-learning blocks, BatchNorm).  One file, frames.npz: <case>_frames0 / <case>_frames1."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import load_fixture
+    out = {}
+    for name in FRAME_CASES:
+        spec, state, batch, _ = load_fixture(name)
+        cfg = str(np.load(os.path.join(HERE, name + ".npz"))["config"])
+        norm = str(np.load(os.path.join(HERE, name + ".npz"))["norm"])
+        wrapper = reference_model(cfg, norm)
+        load_state(wrapper, state)
+        moe = wrapper.moeMerged
+        nets = [getattr(moe, "read_convolver0", None) or moe.readConv0]
+        second = getattr(moe, "read_convolver1", None) or getattr(moe, "readConv1", None)
+        if batch.reads1 is not None and second is not None:
+            nets.append(second)
+        for tech, net in enumerate(nets):
+            reads = batch.reads0 if tech == 0 else batch.reads1
+            rpa = batch.reads_per_allele0 if tech == 0 else batch.reads_per_allele1
+            x = torch.from_numpy(np.ascontiguousarray(np.transpose(reads, (0, 2, 1)))).float()
+            with torch.no_grad():
+                frames = REF.reduceSlots(net(x), rpa.tolist()).numpy()
+            out[f"{name}_frames{tech}"] = frames.astype(np.float32)
+            print(f"frames {name} tech {tech}: {frames.shape}, |max| {np.abs(frames).max():.3f}")
+    path = os.path.join(HERE, "frames.npz")
+    np.savez_compressed(path, **out)
+    print(f"frames.npz: {os.path.getsize(path) / 1024:.0f} KB")
+
+
 def main():
     only = set(sys.argv[1:])          # optional: regenerate just the named fixtures
     sanity_known_answer()
+    if not only or "frames" in only:
+        make_frames_fixture()
+        if only == {"frames"}:
+            return
     if not only or "mini_reference" in only:
         make_pickle_fixture()
     if not only or "mini_merged" in only:

@@ -49,6 +49,49 @@ def test_golden_logits(engines, name, fused):
         assert meta is None
 
 
+def _frames_op(program, tech):
+    """Index of the op whose output is the per-allele frames of technology ``tech``: the fused read convolver, or
+    the reads -> alleles segment sum of the layer-by-layer path."""
+    from hello_amd import compiler
+    for i, o in enumerate(program.ops):
+        if o.seg == tech and (o.kind == compiler.OP_READCONV_FUSED or
+                              (o.kind == compiler.OP_SEGSUM and o.domain == compiler.ROWS_ALLELES)):
+            return i
+    raise AssertionError("no frames op")
+
+
+def _frame_cases():
+    import os
+    from tests.util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "frames.npz"))
+    cases = {("single_tech_batched", 0): load_fixture("single_tech_batched")[3]["frames0"]}
+    for k in z.files:
+        name, tech = k.rsplit("_frames", 1)
+        cases[(name, int(tech))] = z[k]
+    return cases
+
+
+@pytest.mark.parametrize("fused", [False, "trunk", True, "direct"])
+def test_read_convolver_frames_match_reference(engines, fused):
+    """Kernel-level parity of the dominant kernel: the per-allele frames [sum A, L2, 64] the fused read convolver
+    (stem + trunk + reads -> alleles sum) writes, read back through the C ABI's debug capture, against the
+    REFERENCE's reduceSlots(read_convolver(x)) on the same committed inputs (single_tech_batched.npz,
+    frames.npz).  Tolerance: 1e-5 of the frame's scale + 1e-5 relative (float re-association of the Winograd
+    forms and of the summation order; the reference's own cumsum-difference carries the same order of noise)."""
+    worst = 0.0
+    for (name, tech), want in sorted(_frame_cases().items()):
+        spec, state, batch, _ = load_fixture(name)
+        eng = get_engine(engines, name, spec, state, fused)
+        eng.capture_op_output(_frames_op(eng.program, tech))
+        eng.forward_batch(batch)
+        got = eng.read_op_output().reshape(want.shape[0], want.shape[2], want.shape[1]).transpose(0, 2, 1)
+        eng.capture_op_output(None)
+        scale = float(np.abs(want).max())
+        worst = max(worst, float(np.abs(got - want).max()) / scale)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, err_msg=f"{name} tech {tech} fused={fused}")
+    print(f"frames vs reference, fused={fused}: worst |d| / scale = {worst:.2e}")
+
+
 @pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_full", "hybrid_ensemble2", "hybrid_no_ensemble",
                                   "merged_single", "merged_hybrid", "merged_hybrid_250", "single_tech_addendum",
                                   "hybrid_no_ensemble_addendum", "single_tech_softplus",
@@ -144,6 +187,43 @@ def test_error_paths(engines):
     with pytest.raises(RuntimeError, match="alleles_per_site"):
         eng.forward(batch.reads0, batch.reads_per_allele0, aps)
     eng.forward_batch(batch)      # the engine stays usable after a rejected call
+    # shapes, dtypes, devices: only the leading dimension crosses the C ABI, so the binding checks the rest
+    import torch
+    seven = np.zeros((batch.reads0.shape[0], 150, 7), np.uint8)
+    with pytest.raises(ValueError, match="reads0"):                      # 7-channel pileups into a 6-channel model
+        eng.forward(seven, batch.reads_per_allele0, batch.alleles_per_site)
+    with pytest.raises(ValueError, match="reads0"):                      # wrong window
+        eng.forward(batch.reads0[:, :149], batch.reads_per_allele0, batch.alleles_per_site)
+    with pytest.raises(ValueError, match="reads0"):                      # [R, C, L] without the layout flag
+        eng.forward(np.ascontiguousarray(np.transpose(batch.reads0, (0, 2, 1))), batch.reads_per_allele0,
+                    batch.alleles_per_site)
+    with pytest.raises(TypeError, match="uint8"):
+        eng.forward(batch.reads0.astype(np.float32), batch.reads_per_allele0, batch.alleles_per_site)
+    dev_reads = torch.from_numpy(batch.reads0).cuda()
+    with pytest.raises(ValueError, match="contiguous"):
+        eng.forward(torch.from_numpy(np.repeat(batch.reads0, 2, axis=1)).cuda()[:, ::2], batch.reads_per_allele0,
+                    batch.alleles_per_site)
+    a = batch.n_alleles
+    with pytest.raises(ValueError, match="contiguous"):                  # a strided view as the output
+        eng.forward(dev_reads, batch.reads_per_allele0, batch.alleles_per_site,
+                    out=(torch.empty((1, 2 * a), device="cuda")[:, ::2], None))
+    with pytest.raises(ValueError, match="elements"):                    # too small an output
+        eng.forward(dev_reads, batch.reads_per_allele0, batch.alleles_per_site,
+                    out=(torch.empty((1, a - 1), device="cuda"), None))
+    with pytest.raises(ValueError, match="float32"):                     # a host tensor as the output of a device call
+        eng.forward(dev_reads, batch.reads_per_allele0, batch.alleles_per_site, out=(torch.empty((1, a)), None))
+    hyb_spec = ns.build("hybrid_ensemble2")
+    hyb = get_engine(engines, "err_hybrid", hyb_spec, weights.synth_state(hyb_spec, seed=2), True)
+    hb = synth.make_sites(3, seed=4, coverage=10, hybrid_coverage=5)
+    with pytest.raises(ValueError, match="two read technologies"):
+        hyb.forward(hb.reads0, hb.reads_per_allele0, hb.alleles_per_site)
+    with pytest.raises(ValueError, match="ref_onehot"):
+        hyb.forward(hb.reads0, hb.reads_per_allele0, hb.alleles_per_site, hb.reads1, hb.reads_per_allele1)
+    with pytest.raises(ValueError, match="segments"):
+        hyb.forward(hb.reads0, hb.reads_per_allele0, hb.alleles_per_site, hb.reads1, hb.reads_per_allele1,
+                    hb.ref_onehot[:2])
+    hyb.forward_batch(hb)
+    eng.forward_batch(batch)
 
 
 def test_malformed_programs_are_rejected_at_creation():

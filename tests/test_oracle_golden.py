@@ -1,11 +1,13 @@
 """Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz, produced by
 tests/golden/make_fixtures.py from /root/reference in the build container)."""
+import os
+
 import numpy as np
 import pytest
 
 from hello_amd import synth
 from oracle import moe_oracle as mo
-from tests.util import FIXTURES, load_fixture
+from tests.util import FIXTURES, GOLDEN, load_fixture
 
 # reference self-noise between its own per-site and batched calls is <= 4e-6 on logits
 LOGIT_TOL = dict(rtol=2e-5, atol=2e-5)
@@ -34,6 +36,24 @@ def test_batched_logits_match_reference(name, backend):
     if "frames0" in exp:
         scale = np.abs(exp["frames0"]).max()
         np.testing.assert_allclose(oracle.last["frames0"], exp["frames0"], rtol=1e-5, atol=1e-6 * scale)
+
+
+def test_read_convolver_frames_match_reference():
+    """Kernel-level pins (tests/golden/frames.npz): reduceSlots(read_convolver(x)) of both technologies, as the
+    reference computed them on the committed inputs -- 7 channels, 90-128 reads per site, 250 bp, Softplus, the
+    transfer-learning blocks, BatchNorm."""
+    z = np.load(os.path.join(GOLDEN, "frames.npz"))
+    cases = sorted({k.rsplit("_frames", 1)[0] for k in z.files})
+    assert len(cases) >= 8
+    for name in cases:
+        spec, state, batch, _ = load_fixture(name)
+        oracle = mo.Oracle(spec, state)
+        _batched(oracle, batch)
+        for tech in (0, 1):
+            key = f"{name}_frames{tech}"
+            if key in z.files:
+                want = z[key]
+                np.testing.assert_allclose(oracle.last[f"frames{tech}"], want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
 
 
 @pytest.mark.parametrize("name", [f for f in FIXTURES if f not in ("single_tech_bn", "single_tech_deep")])
