@@ -2,9 +2,14 @@
 
 Literal restatement of ``AlleleSearcherLiteFiltered::computeFeaturesColoredSimple`` and its colour
 helpers (reference c++/src/AlleleSearcherLiteFiltered.cpp:971-1180, constants :369-384).  The C++ cannot
-be built here (Boost.Python/numpy/log are absent), so this oracle is pinned by known answers worked out
-by hand on the inputs of the reference's own unit test (python/test_aligner.py:279-384: three reads, one
-deletion, one insertion, one mismatch; tagless and haplotagged), see tests/test_featurizer.py.
+be built here (Boost.Python/numpy/log are absent).  **Pinned** by outputs of the reference itself: its own
+Python statement of the encoding (python/test_aligner.py:15-180, the code its unit test holds the C++ to) is
+executed in the build container by tests/golden/make_fixtures.py on the test's two cases (:279-384) and 336 random
+reads (tests/golden/featurizer_reference.npz); tests/test_featurizer.py replays them bit for bit, beside the
+hand-worked answers.  That encoder and the C++ are the same function only on CIGARs without clips, with insertions
+no worse in quality than the base before them and deletions wholly inside or outside the window (the Python one
+ignores clips and indexes out of the window otherwise): the fixtures stay inside that domain; outside it this
+oracle follows the C++ text, and the GPU tests compare against it on random CIGARs of every kind.
 
 Track order (:376-382): read base, reference base, base quality, mapping quality, strand, allele-position
 marker, haplotag.  Output uint8 [reads][feature_length][channels].

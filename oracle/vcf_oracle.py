@@ -1,9 +1,13 @@
 """CPU ORACLE -- TEST INFRASTRUCTURE ONLY (posterior -> genotype -> VCF record).
 
-Literal restatement of the reference's record emission, followed as text because the reference modules
-cannot be imported here (``vcfFromContigs`` needs Biopython, ``prepareVcf`` needs pysam: ordinary
-ModuleNotFoundError in this container) -- so this part of the oracle is *parity unpinned by execution*;
-tests/test_vcf.py pins it with hand-worked cases of each normalisation rule instead.
+Literal restatement of the reference's record emission (vcfFromContigs.py:139-227, prepareVcf.py:36-105,126-176,
+caller_calling.py:698-754).  The reference modules cannot be imported here (``vcfFromContigs`` imports Biopython,
+``prepareVcf`` / ``caller_calling`` import pysam: ordinary ModuleNotFoundError in this container), but the functions
+on this path use neither: tests/golden/make_fixtures.py executes exactly those source ranges in the build container
+and records what they return (tests/golden/vcf_reference.json: 160 createVcfRecord cases, 240 callAlleles cases,
+three models through caller_calling.vcfRecords with the reference's own network, one .features shard through
+prepareVcf.vcfRecords).  **Pinned**: tests/test_vcf.py replays them (record lines equal character for character
+in canonical ALT order); the hand-worked cases of each normalisation rule stay beside them.
 
 One deliberate deviation ("VCF-identical"): the reference orders ALT alleles by
 ``list(set(...))`` (prepareVcf.py:63,75; caller_calling.py:712,718), i.e. by Python's per-process string

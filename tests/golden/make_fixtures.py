@@ -450,8 +450,338 @@ def make_frames_fixture():
     print(f"frames.npz: {os.path.getsize(path) / 1024:.0f} KB")
 
 
+def _reference_read_encoder():
+    """The reference's own Python statement of the pileup encoding: python/test_aligner.py:15-180 (colour tables,
+    ReadDescriptor, write_to_array, create_read_encoding).  The module cannot be imported (its line 5 imports
+    libCallability, the Boost.Python build of the C++ featurizer, absent here), so exactly that source range is
+    executed in a namespace holding the standard-library names its import block (lines 1-12) provides.  Nothing of
+    libCallability is stubbed: the range does not use it."""
+    import collections
+    import functools
+    import operator
+    import random
+    lines = open("/root/reference/python/test_aligner.py").read().split("\n")
+    src = "\n".join(lines[14:180])                     # lines 15..180, 1-based
+    assert lines[14].startswith("READ_BASE_TRACK") and lines[179].strip() == "return array, alleles_in_region"
+    space = {"np": np, "random": random, "reduce": functools.reduce, "partial": functools.partial,
+             "concat": operator.concat, "defaultdict": collections.defaultdict, "namedtuple": collections.namedtuple,
+             "List": list, "Dict": dict, "__name__": "reference_test_aligner_range"}
+    exec(compile(src, "test_aligner.py[15:180]", "exec"), space)
+    return space
+
+
+def _random_read_in_common_domain(rng, ref_len, start, end, tagged):
+    """A read whose CIGAR stays inside the domain on which the reference's Python encoder and its C++ featurizer are
+    the same function (the reference's test asserts their equality only on its two cases): no clips (the Python
+    encoder ignores them without advancing the read), insertions after >= 1 aligned base whose inserted bases are
+    no worse in quality than the base before them (Python takes that base's quality, the C++ the minimum), deletions
+    either wholly inside the window together with the base before them or not touching it (the Python encoder indexes
+    out of the window otherwise)."""
+    M, I, D, N, EQ, X = 0, 1, 2, 3, 7, 8
+    while True:
+        ref_start = int(rng.integers(0, end - 10))
+        ops, quals, rf = [], [], ref_start
+        ok = True
+        for k in range(int(rng.integers(1, 7))):
+            n = int(rng.integers(1, 70))
+            ops.append([int(rng.choice([M, EQ, X])), n])
+            quals += [int(q) for q in rng.integers(2, 60, size=n)]
+            rf += n
+            u = rng.random()
+            if u < 0.3:
+                n = int(rng.integers(1, 9))
+                ops.append([I, n])
+                quals += [int(q) for q in rng.integers(quals[-1], 61, size=n)]
+            elif u < 0.6:
+                n = int(rng.integers(1, 25))
+                inside = (start + 1 <= rf) and (rf + n <= end)
+                apart = (rf < start or rf > end) and not (start <= rf - 1 < end)
+                if not (inside or apart):
+                    ok = False
+                    break
+                ops.append([D, n])
+                rf += n
+            elif u < 0.68:
+                n = int(rng.integers(1, 30))
+                ops.append([N, n])
+                rf += n
+        if ops[-1][0] != M and ops[-1][0] != EQ and ops[-1][0] != X:
+            ops.append([M, 3])
+            quals += [30, 31, 32]
+            rf += 3
+        if ok and rf < ref_len:
+            break
+    bases = "".join(rng.choice(list("ACGT"), size=len(quals)))
+    return dict(read=bases, quality=quals, cigartuples=ops, reference_start=ref_start,
+                mapq=int(rng.integers(0, 90)), orientation=int(rng.choice([-1, 1])),
+                hp=(int(rng.integers(0, 3)) if tagged else None))
+
+
+def make_featurizer_fixtures():
+    """Pins for the pileup-tensor producer generated by the reference's own encoder: its two unit-test
+    cases (test_aligner.py:279-384) and 336 random reads over 16 sites (6 and 7 channels, windows of 150 / 33 / 10,
+    reads starting before and ending after the window, insertions, deletions, skips).  featurizer_reference.npz
+    holds the reads as flat arrays and the encoder's output as uint8 [reads, L, C] per site."""
+    enc = _reference_read_encoder()
+    RD, encode = enc["ReadDescriptor"], enc["create_read_encoding"]
+    rng = np.random.Generator(np.random.PCG64(20240607))
+    sites = []
+    # the reference's two cases: reference string, three reads, allele span [10, 14) (what its C++ run reports)
+    M, I, D = 0, 1, 2
+    for tagged in (False, True):
+        hp = (1, 0, 2) if tagged else (None, None, None)
+        reads = [dict(read="TAATCG", quality=[26] * 6, cigartuples=[[M, 2], [D, 3], [M, 4]], reference_start=9, mapq=30,
+                      orientation=-1, hp=hp[0]),
+                 dict(read="TAACGGATCG", quality=[30] * 10, cigartuples=[[M, 2], [I, 1], [M, 7]], reference_start=9,
+                      mapq=44, orientation=1, hp=hp[1]),
+                 dict(read="TGCGGATCG", quality=[15] * 9, cigartuples=[[M, 9]], reference_start=9, mapq=75,
+                      orientation=1, hp=hp[2])]
+        sites.append(("ACGATACCGTACGGATCGGATCGT", 10, 14, 10, tagged, reads))
+    for s in range(16):
+        tagged = bool(s % 2)
+        length = 150 if s < 12 else (33 if s < 14 else 10)
+        ref_len = 420
+        reference = "".join(rng.choice(list("ACGT"), size=ref_len))
+        a0 = int(rng.integers(150, 260))
+        a1 = a0 + int(rng.integers(1, 12))
+        start = (a0 + a1) // 2 - length // 2
+        reads = [_random_read_in_common_domain(rng, ref_len, start, start + length, tagged) for _ in range(21)]
+        sites.append((reference, a0, a1, length, tagged, reads))
+    out, n_reads = {}, 0
+    for i, (reference, a0, a1, length, tagged, reads) in enumerate(sites):
+        enc_out = []
+        for r in reads:
+            arr, _ = encode(RD(read=r["read"], name=0, quality=r["quality"], cigartuples=r["cigartuples"],
+                               reference_start=r["reference_start"], mapq=r["mapq"], orientation=r["orientation"],
+                               pacbio=False, hp=r["hp"]), reference, length, (a0, a1))
+            assert arr.min() >= 0 and arr.max() <= 255
+            enc_out.append(arr.T.astype(np.uint8))
+        n_reads += len(reads)
+        out[f"s{i}_reference"] = np.array(reference)
+        out[f"s{i}_span"] = np.array([a0, a1, length, int(tagged)], np.int64)
+        out[f"s{i}_bases"] = np.array([r["read"] for r in reads])
+        out[f"s{i}_quals"] = np.concatenate([np.asarray(r["quality"], np.uint8) for r in reads])
+        out[f"s{i}_cigars"] = np.concatenate([np.asarray(r["cigartuples"], np.int32).reshape(-1, 2) for r in reads])
+        out[f"s{i}_n_cigar"] = np.array([len(r["cigartuples"]) for r in reads], np.int32)
+        out[f"s{i}_meta"] = np.array([[r["reference_start"], r["mapq"], r["orientation"], 0 if r["hp"] is None else r["hp"]]
+                                      for r in reads], np.int64)
+        out[f"s{i}_expected"] = np.stack(enc_out)
+    out["n_sites"] = np.array(len(sites))
+    path = os.path.join(HERE, "featurizer_reference.npz")
+    np.savez_compressed(path, **out)
+    print(f"featurizer_reference.npz: {len(sites)} sites, {n_reads} reads, {os.path.getsize(path) / 1024:.0f} KB")
+
+
+class _InMemoryFasta:
+    """The FASTA *file* of the fixtures: chromosome -> sequence held in memory, read the way the reference reads
+    its PySamFastaWrapper (python/PySamFastaWrapper.py:5-29): ``.chrom`` selects the chromosome, a slice returns the
+    list of bases, an index one base, len() the chromosome length.  Input data, not a library."""
+
+    def __init__(self, genomes, chrom=None):
+        self.genomes, self.chrom = genomes, chrom
+
+    def __len__(self):
+        return len(self.genomes[self.chrom])
+
+    def __getitem__(self, index):
+        seq = self.genomes[self.chrom]
+        return list(seq[index.start:index.stop]) if isinstance(index, slice) else seq[index]
+
+
+def _source_range(path, first, last, starts_with):
+    lines = open(path).read().split("\n")
+    assert lines[first - 1].startswith(starts_with), (path, first, lines[first - 1])
+    return "\n".join(lines[first - 1:last])
+
+
+def _reference_calling_functions(genomes):
+    """The reference's own record-emission code, as source ranges executed in one namespace (the modules cannot be
+    imported: vcfFromContigs imports Bio, prepareVcf / caller_calling import pysam, both absent -- ordinary
+    ModuleNotFoundError; none of the ranges below uses them):
+        vcfFromContigs.py:139-227   fixEmptyAlleles, createVcfRecord
+        prepareVcf.py:36-105        callAlleles
+        prepareVcf.py:112-182       vcfRecords (per-shard expert / best / mean records from a .features file)
+        caller_calling.py:50-97     DEFAULT_FEATURE_LENGTH, one_hot_encode, get_reference_segment
+        caller_calling.py:612-754   scoreSite, vcfRecords (network call -> record + .features entry)
+    ``ReferenceCache`` (the name prepareVcf binds to PySamFastaWrapper) is the in-memory FASTA of the fixtures."""
+    import logging
+    import math
+    import pickle
+    ref_py = "/root/reference/python/"
+    space = {"math": math, "np": np, "torch": torch, "logging": logging, "pickle": pickle, "os": os,
+             "ReferenceCache": lambda database=None, chrom=None: _InMemoryFasta(genomes, chrom),
+             "__name__": "reference_calling_ranges"}
+    exec(compile(_source_range(ref_py + "vcfFromContigs.py", 139, 227, "def fixEmptyAlleles"), "vcfFromContigs[139:227]", "exec"), space)
+    exec(compile(_source_range(ref_py + "prepareVcf.py", 36, 105, "def callAlleles"), "prepareVcf[36:105]", "exec"), space)
+    shard = dict(space)
+    exec(compile(_source_range(ref_py + "prepareVcf.py", 112, 182, "def vcfRecords"), "prepareVcf[112:182]", "exec"), shard)
+    caller = dict(space)
+    exec(compile(_source_range(ref_py + "caller_calling.py", 50, 97, "DEFAULT_FEATURE_LENGTH"), "caller_calling[50:97]", "exec"), caller)
+    exec(compile(_source_range(ref_py + "caller_calling.py", 612, 754, "def scoreSite"), "caller_calling[612:754]", "exec"), caller)
+    return space, shard, caller
+
+
+def _site_alleles(rng, genome, start, n_alleles):
+    """Allele strings of one site: the reference allele genome[start:stop] first, then SNVs, insertions, deletions
+    (possibly down to the empty allele, which the reference re-anchors on the previous base) -- inside short repeats
+    often enough that right / left parsimony has something to trim."""
+    length = int(rng.choice([1, 1, 2, 3]))
+    ref = genome[start:start + length]
+    alleles = [ref]
+    while len(alleles) < n_alleles:
+        u = rng.random()
+        if u < 0.35:
+            cand = "".join(rng.choice(list("ACGT"), size=length))
+        elif u < 0.7:
+            cand = ref + "".join(rng.choice([ref[-1], genome[start + length], "A", "C", "G", "T"], size=int(rng.integers(1, 4))))
+        else:
+            cand = ref[:max(0, length - int(rng.integers(1, 3)))]
+        if cand not in alleles:
+            alleles.append(cand)
+    return alleles, length
+
+
+def make_vcf_fixtures():
+    """Pins for posterior -> genotype -> VCF record -> .features -> per-shard calls, produced
+    by the reference's own functions (see _reference_calling_functions) on seeded inputs; vcf_reference.json holds the
+    inputs and what the reference returned.  ALT order in the reference is list(set(...)), i.e. per-process hash
+    order: the lines are stored as returned (generate with PYTHONHASHSEED=0) and tests compare in canonical ALT order."""
+    import json
+    import pickle
+    import tempfile
+    rng = np.random.Generator(np.random.PCG64(77001))
+    genomes = {}
+    for name in ("chrA", "chrB"):
+        g = rng.choice(list("ACGT"), size=2400)
+        for k in range(0, 2400, 37):                       # short homopolymers / dinucleotide repeats
+            g[k:k + int(rng.integers(2, 6))] = g[k]
+        genomes[name] = "".join(g)
+    space, shard, caller = _reference_calling_functions(genomes)
+    fasta = _InMemoryFasta(genomes)
+    pairs_of = lambda al: [(al[i], al[j]) for i in range(len(al)) for j in range(i, len(al))]      # noqa: E731
+    key = lambda pair: "|".join(pair)                                                               # noqa: E731
+
+    # (1) createVcfRecord on its own: alleles with '-', empty alleles, shared prefixes / suffixes
+    records = []
+    for _ in range(160):
+        chrom = str(rng.choice(sorted(genomes)))
+        start = int(rng.integers(10, 2300))
+        alleles, length = _site_alleles(rng, genomes[chrom], start, int(rng.choice([2, 2, 3, 4])))
+        alts = [a if (a or rng.random() < 0.5) else "-" for a in alleles[1:]]
+        gt = [int(rng.integers(0, len(alts) + 1)), int(rng.integers(0, len(alts) + 1))]
+        qual = float(rng.uniform(0, 80))
+        fasta.chrom = chrom
+        out = space["createVcfRecord"](chrom, start, fasta, [0], [alleles[0]], [list(alts)], [gt], string="HELLO", qual=qual)
+        records.append(dict(chromosome=chrom, start=start, ref=alleles[0], alts=alts, gt=gt, qual=qual,
+                            line=out[0] if out else None))
+
+    # (2) callAlleles on random likelihood dictionaries
+    calls = []
+    for _ in range(240):
+        chrom = str(rng.choice(sorted(genomes)))
+        start = int(rng.integers(10, 2300))
+        alleles, length = _site_alleles(rng, genomes[chrom], start, int(rng.choice([1, 2, 2, 3, 4])))
+        order = list(rng.permutation(len(alleles)))
+        alleles = [alleles[i] for i in order]
+        pairs = pairs_of(alleles)
+        p = rng.dirichlet(np.ones(len(pairs)) * 0.3).astype(np.float32)
+        if rng.random() < 0.1:
+            p[:] = 0
+            p[int(rng.integers(0, len(pairs)))] = 1.0          # certainty: QUAL capped at 80
+        like = {pr: float(v) for pr, v in zip(pairs, p)}
+        fasta.chrom = chrom
+        line = space["callAlleles"](dict(like), chrom, start, length, fasta)
+        calls.append(dict(chromosome=chrom, start=start, length=length, likelihoods={key(k): v for k, v in like.items()},
+                          line=line))
+
+    # (3) the per-shard caller: reference network + caller_calling.vcfRecords on synthetic site dictionaries
+    caller_cases = []
+    feature_items = []
+    for cfg, wseed, bseed, kw in (("single_tech", 41, 301, dict(coverage=18)),
+                                  ("hybrid_full", 42, 302, dict(coverage=14, hybrid_coverage=8)),
+                                  ("hybrid_no_ensemble", 43, 303, dict(coverage=14, hybrid_coverage=8))):
+        spec = ns.build(cfg)
+        state = weights.synth_state(spec, seed=wseed)
+        wrapper = reference_model(cfg, "wn")
+        load_state(wrapper, state)
+        wrapper.providePredictions = True
+        batch = synth.make_sites(14, seed=bseed, **kw)
+        aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
+        r0 = np.concatenate([[0], np.cumsum(batch.reads_per_allele0)])
+        r1 = None if batch.reads1 is None else np.concatenate([[0], np.cumsum(batch.reads_per_allele1)])
+        hybrid = batch.reads1 is not None
+        sites = []
+        for s in range(batch.n_sites):
+            chrom = "chrA" if s % 2 == 0 else "chrB"
+            start = 200 + 150 * s + int(rng.integers(0, 20))
+            n_al = int(batch.alleles_per_site[s])
+            alleles, length = _site_alleles(rng, genomes[chrom], start, n_al)
+            alleles = [alleles[i] for i in rng.permutation(n_al)]
+            idx = range(aoff[s], aoff[s + 1])
+            site = {"alleles": alleles, "chromosome": chrom, "start": start, "stop": start + length,
+                    "tensors": [batch.reads0[r0[a]:r0[a + 1]] for a in idx],
+                    "tensors2": [batch.reads1[r1[a]:r1[a + 1]] for a in idx] if hybrid else [None] * n_al,
+                    "supportingReadsStrict": [int(batch.reads_per_allele0[a]) for a in idx],
+                    "supportingReadsStrict2": [0] * n_al}
+            fasta.chrom = chrom
+            out = caller["vcfRecords"](site, wrapper, fasta, hybrid=hybrid, featureLength=150)
+            entry = dict(alleles=alleles, chromosome=chrom, start=start, stop=start + length, record=None, features=None)
+            if out is not None:
+                record, feats = out
+                entry["record"] = record
+                entry["features"] = dict(chromosome=feats["chromosome"], position=int(feats["position"]), length=int(feats["length"]),
+                                         meta=[float(m) for m in np.asarray(feats["meta"]).reshape(-1)],
+                                         expertPredictions=[{key(k): float(v) for k, v in e.items()} for e in feats["expertPredictions"]])
+                feature_items.append(feats)
+            sites.append(entry)
+        import hashlib
+        caller_cases.append(dict(config=cfg, weight_seed=wseed, batch_seed=bseed, batch_kwargs=kw,
+                                 reads0_sha=hashlib.sha256(batch.reads0.tobytes()).hexdigest()[:16], sites=sites))
+        print(f"caller {cfg}: {sum(e['record'] is not None for e in sites)} records of {len(sites)} sites")
+
+    # (4) prepareVcf.vcfRecords on the .features list those sites produced (sites with an alternative allele only:
+    #     the reference concatenates None + '\n' otherwise)
+    items = []
+    for f in feature_items:
+        fasta.chrom = f["chromosome"]
+        if all(space["callAlleles"](dict(e), f["chromosome"], f["position"], f["length"], fasta) is not None
+               for e in f["expertPredictions"]):
+            items.append({"chromosome": f["chromosome"], "position": int(f["position"]), "length": int(f["length"]),
+                          "meta": np.asarray(f["meta"], np.float32).reshape(-1),
+                          "expertPredictions": tuple({k: float(v) for k, v in e.items()} for e in f["expertPredictions"])})
+    with tempfile.TemporaryDirectory() as tmp:
+        data = os.path.join(tmp, "shard0.features")
+        with open(data, "wb") as fh:
+            pickle.dump(items, fh)
+        out_dir = os.path.join(tmp, "out")
+        os.makedirs(out_dir)
+        chroms = shard["vcfRecords"](data, "in-memory", out_dir)
+        read = lambda suffix: open(os.path.join(out_dir, "shard0.features" + suffix)).read().split("\n")[:-1]   # noqa: E731
+        shard_out = dict(expert0=read(".expert0.vcf"), expert1=read(".expert1.vcf"), expert2=read(".expert2.vcf"),
+                         best=read(".best.vcf"), mean=read(".mean.vcf"), choices=read(".choices.bed"),
+                         chromosomes=sorted(chroms))
+    shard_items = [dict(chromosome=i["chromosome"], position=i["position"], length=i["length"],
+                        meta=[float(m) for m in i["meta"]],
+                        expertPredictions=[{key(k): v for k, v in e.items()} for e in i["expertPredictions"]]) for i in items]
+    payload = dict(genomes=genomes, records=records, calls=calls, caller=caller_cases,
+                   shard=dict(items=shard_items, **shard_out))
+    path = os.path.join(HERE, "vcf_reference.json")
+    with open(path, "w") as fh:
+        json.dump(payload, fh, indent=0)
+    print(f"vcf_reference.json: {len(records)} records, {len(calls)} calls, {len(shard_items)} shard items, "
+          f"{os.path.getsize(path) / 1024:.0f} KB")
+
+
 def main():
     only = set(sys.argv[1:])          # optional: regenerate just the named fixtures
+    if not only or "vcf" in only:
+        make_vcf_fixtures()
+        if only == {"vcf"}:
+            return
+    if not only or "featurizer" in only:
+        make_featurizer_fixtures()
+        if only == {"featurizer"}:
+            return
     sanity_known_answer()
     if not only or "frames" in only:
         make_frames_fixture()

@@ -2,10 +2,13 @@
 known answers worked out by hand on the inputs of the reference's own unit test
 (reference python/test_aligner.py:279-384: one deletion, one insertion, one mismatch read over
 "ACGATACCGTACGGATCGGATCGT", feature length 10, allele span [10, 14))."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import featurizer_oracle as fo
+from tests.util import GOLDEN
 
 REFERENCE = "ACGATACCGTACGGATCGGATCGT"
 M, I, D = fo.BAM_CMATCH, fo.BAM_CINS, fo.BAM_CDEL
@@ -66,3 +69,36 @@ def test_colour_alphabet_matches_the_synthetic_generator():
     from hello_amd import synth
     assert [fo.base_color(b) for b in "ACGT"] == synth.BASE_CODE.tolist()
     assert fo.base_color("*") == 0 and fo.base_color("N") == 0
+
+
+def reference_generated_sites():
+    """tests/golden/featurizer_reference.npz: reads + the output of the REFERENCE's own Python encoder
+    (python/test_aligner.py:15-180, executed in the build container by tests/golden/make_fixtures.py) for its two
+    unit-test cases and 336 random reads.  -> [(reference, a0, a1, length, tagged, [fo.Read], expected uint8)]"""
+    z = np.load(os.path.join(GOLDEN, "featurizer_reference.npz"))
+    sites = []
+    for i in range(int(z["n_sites"])):
+        a0, a1, length, tagged = (int(v) for v in z[f"s{i}_span"])
+        quals, cigars = z[f"s{i}_quals"], z[f"s{i}_cigars"]
+        reads, qp, cp = [], 0, 0
+        for bases, n_cig, (rs, mapq, orient, hp) in zip(z[f"s{i}_bases"], z[f"s{i}_n_cigar"], z[f"s{i}_meta"]):
+            bases = str(bases)
+            reads.append(fo.Read(bases, quals[qp:qp + len(bases)].tolist(),
+                                 [(int(o), int(n)) for o, n in cigars[cp:cp + n_cig]], int(rs), int(mapq), int(orient), int(hp)))
+            qp, cp = qp + len(bases), cp + int(n_cig)
+        sites.append((str(z[f"s{i}_reference"]), a0, a1, length, bool(tagged), reads, z[f"s{i}_expected"]))
+    return sites
+
+
+def test_oracle_equals_the_reference_encoder_on_generated_fixtures():
+    sites = reference_generated_sites()
+    assert sum(len(s[5]) for s in sites) >= 300
+    kinds = set()
+    for reference, a0, a1, length, tagged, reads, expected in sites:
+        got = fo.features_for_reads(reads, reference, 0, a0, a1, length, include_hp=tagged)
+        np.testing.assert_array_equal(got, expected)
+        kinds |= {op for r in reads for op, _ in r.cigar}
+    assert {fo.BAM_CMATCH, fo.BAM_CINS, fo.BAM_CDEL, fo.BAM_CREF_SKIP, fo.BAM_CEQUAL, fo.BAM_CDIFF} <= kinds
+    # the hand-worked answers of this file ARE the reference encoder's answers on its own two cases
+    np.testing.assert_array_equal(sites[0][6], EXPECTED)
+    np.testing.assert_array_equal(sites[1][6][:, :, :6], EXPECTED)

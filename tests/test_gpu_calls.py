@@ -72,3 +72,46 @@ def test_calls_identical_to_oracle(cfg, kw):
             assert abs(got_call.qual - float(qual)) < 0.05
     assert n_calls >= 40
     net.close()
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_calls_identical_to_the_reference_caller(case):
+    """tests/golden/vcf_reference.json: what the REFERENCE's per-shard caller (caller_calling.py:612-754, its own
+    network, its own createVcfRecord) emitted for these sites.  The product chain -- ScoringNetwork on the GPU ->
+    vcf.call_site / feature_record -- must make identical calls: same CHROM, POS, REF, ALT set, genotype; posteriors
+    within 1e-4; the .features entry the same pairs in the same order."""
+    import torch
+    from hello_amd.wrapper import ScoringNetwork
+    from tests.util import canonical_vcf_line, caller_case_sites, load_vcf_reference, reference_segment_onehot
+    z = load_vcf_reference()
+    spec, state, sites = caller_case_sites(z["caller"][case])
+    net = ScoringNetwork(spec, state, providePredictions=True)
+    n = 0
+    for fd, site in sites:
+        genome = z["genomes"][site["chromosome"]]
+        seg = torch.from_numpy(reference_segment_onehot(genome, site["start"], site["stop"])).float()
+        fdt = {k: (torch.Tensor(v[0]), None if v[1] is None else torch.Tensor(v[1])) for k, v in fd.items()}   # caller_calling.py:631-639
+        mix, e0, e1, e2, meta = net(fdt, seg)
+        length = site["stop"] - site["start"]
+        call = vcf.call_site(mix, site["chromosome"], site["start"], length, genome, info="MixtureOfExpertPrediction")
+        want = canonical_vcf_line(site["record"])
+        assert (call is None) == (want is None)
+        if want is None:
+            continue
+        n += 1
+        feats = site["features"]
+        rec = vcf.feature_record((mix, e0, e1, e2, meta), site["chromosome"], site["start"], length)
+        assert (rec["chromosome"], rec["position"], rec["length"]) == (feats["chromosome"], feats["position"], feats["length"])
+        np.testing.assert_allclose(rec["meta"], feats["meta"], atol=1e-4)
+        for got_e, want_e in zip(rec["expertPredictions"], feats["expertPredictions"]):
+            assert list(got_e) == list(want_e)
+            assert np.abs(np.array(list(got_e.values())) - np.array(list(want_e.values()))).max() < 1e-4
+        ps = sorted((float(v) for v in mix.values()), reverse=True)
+        if len(ps) > 1 and ps[0] - ps[1] < 2e-4:
+            continue                                   # a genuinely ambiguous site may flip
+        gf, wf = call.line().split("\t"), want.split("\t")
+        assert gf[:5] + gf[6:] == wf[:5] + wf[6:]
+        if 1.0 - ps[0] > 1e-2:
+            assert abs(call.qual - float(wf[5])) < 0.05
+    assert n >= 11
+    net.close()

@@ -6,7 +6,7 @@ import pytest
 from hello_amd import netspec as ns, weights
 from hello_amd.featurizer import AlignedRead, SiteReads, featurize
 from oracle import featurizer_oracle as fo
-from tests.test_featurizer import EXPECTED, REFERENCE, reference_test_reads
+from tests.test_featurizer import EXPECTED, REFERENCE, reference_generated_sites, reference_test_reads
 
 pytestmark = pytest.mark.gpu
 
@@ -108,3 +108,18 @@ def test_features_stay_on_the_device_into_the_scoring_engine(engine):
     b, _ = engine.forward(host, rpa, aps)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
+def test_reference_generated_fixtures_bit_exact(engine):
+    """The HIP featurizer against what the REFERENCE's own encoder produced (featurizer_reference.npz): its two
+    unit-test cases and 336 random reads, 6 and 7 channels, windows of 150 / 33 / 10 -- one launch per (length,
+    channels) group, every site of the group in the same launch."""
+    sites = reference_generated_sites()
+    groups = {}
+    for site in sites:
+        groups.setdefault((site[3], site[4]), []).append(site)
+    for (length, tagged), members in groups.items():
+        packed = [to_site([("x", reads)], reference, 0, a0, a1) for reference, a0, a1, _, _, reads, _ in members]
+        out, rpa, aps = featurize(engine, packed, feature_length=length, include_hp=tagged)
+        np.testing.assert_array_equal(out, np.concatenate([m[6] for m in members]))
+        assert rpa.tolist() == [len(m[5]) for m in members]

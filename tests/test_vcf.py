@@ -9,6 +9,7 @@ import pytest
 
 from hello_amd import vcf
 from oracle import vcf_oracle as vo
+from tests.util import canonical_vcf_line, caller_case_sites, load_vcf_reference, reference_segment_onehot
 
 GENOME = "ACGTACGTTTGACCATGCA"
 
@@ -140,3 +141,81 @@ def test_features_records_round_trip_and_shard_calls_match_oracle(tmp_path):
         assert [line(c) for c in g] == w
     assert ["\t".join(map(str, row)) for row in got.choices] == want[5]
     assert sum(c is not None for c in got.mean) > 30
+
+
+# ---- pins generated by the REFERENCE's own functions (tests/golden/vcf_reference.json, made by
+# ---- tests/golden/make_fixtures.py from source ranges of vcfFromContigs.py, prepareVcf.py, caller_calling.py)
+def test_record_normalisation_equals_reference_createVcfRecord():
+    z = load_vcf_reference()
+    n = 0
+    for r in z["records"]:
+        genome = z["genomes"][r["chromosome"]]
+        got = vo.create_vcf_record(r["chromosome"], r["start"], genome, r["ref"], list(r["alts"]), r["gt"], qual=r["qual"])
+        assert got == r["line"], r
+        norm = vcf.normalise(r["start"], r["ref"], r["alts"], genome)
+        if r["line"] is None:
+            assert norm is None
+        else:
+            f = r["line"].split("\t")
+            assert (norm[0] + 1, norm[1], ",".join(norm[2])) == (int(f[1]), f[3], f[4])
+            n += 1
+    assert n > 120
+
+
+def test_calls_equal_reference_callAlleles():
+    z = load_vcf_reference()
+    n = 0
+    for c in z["calls"]:
+        genome = z["genomes"][c["chromosome"]]
+        want = canonical_vcf_line(c["line"])
+        assert vo.call_alleles(c["likelihoods"], c["chromosome"], c["start"], c["length"], genome) == want
+        got = vcf.call_site(c["likelihoods"], c["chromosome"], c["start"], c["length"], genome)
+        assert (None if got is None else got.line()) == want
+        n += want is not None
+    assert n > 180
+
+
+def test_shard_calls_equal_reference_prepareVcf():
+    z = load_vcf_reference()
+    sh = z["shard"]
+    items = [dict(i, meta=np.asarray(i["meta"], np.float32)) for i in sh["items"]]
+    want = [[canonical_vcf_line(x) for x in sh[k]] for k in ("expert0", "expert1", "expert2", "best", "mean")]
+    e0, e1, e2, best, mean, choices = vo.prepare_shard(items, z["genomes"])
+    assert [e0, e1, e2, best, mean] == want and choices == sh["choices"]
+    got = vcf.calls_from_features(items, z["genomes"])
+    for g, w in zip(list(got.expert) + [got.best, got.mean], want):
+        assert [c.line() for c in g] == w
+    assert ["\t".join(map(str, row)) for row in got.choices] == sh["choices"]
+    assert len(items) >= 30
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_oracle_chain_equals_reference_caller(case):
+    """caller_calling.py:612-754 run by the reference on its own network: the oracle chain (per-site wrapper oracle
+    -> vcf oracle) must give the same record and the same .features entry for every site."""
+    from oracle import moe_oracle as mo
+    z = load_vcf_reference()
+    spec, state, sites = caller_case_sites(z["caller"][case])
+    wrapper = mo.WrapperOracle(spec, state, provide_predictions=True)
+    n = 0
+    for fd, site in sites:
+        genome = z["genomes"][site["chromosome"]]
+        seg = reference_segment_onehot(genome, site["start"], site["stop"])
+        fd32 = {k: (v[0].astype(np.float32), None if v[1] is None else v[1].astype(np.float32)) for k, v in fd.items()}
+        mix, e0, e1, e2, meta = wrapper(fd32, seg.astype(np.float32))
+        line = vo.call_alleles({k: float(v) for k, v in mix.items()}, site["chromosome"], site["start"],
+                               site["stop"] - site["start"], genome, string="MixtureOfExpertPrediction")
+        want = canonical_vcf_line(site["record"])
+        assert (line is None) == (want is None)
+        if want is None:
+            continue
+        n += 1
+        gf, wf = line.split("\t"), want.split("\t")
+        assert gf[:5] + gf[6:] == wf[:5] + wf[6:]                       # everything but QUAL, exactly
+        assert abs(float(gf[5]) - float(wf[5])) < 0.05 or float(wf[5]) > 40
+        feats = site["features"]
+        np.testing.assert_allclose(meta, feats["meta"], rtol=1e-5, atol=1e-6)
+        for got_e, want_e in zip((e0, e1, e2), feats["expertPredictions"]):
+            assert list(got_e) == list(want_e)                         # same pairs, same order
+            np.testing.assert_allclose([float(v) for v in got_e.values()], list(want_e.values()), rtol=1e-4, atol=1e-6)
+    assert n >= 11

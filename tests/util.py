@@ -36,3 +36,66 @@ def load_fixture(name):
         z["reads_per_allele1"] if "reads_per_allele1" in z.files else None)
     exp = {k[4:]: z[k] for k in z.files if k.startswith("exp_")}
     return spec, state, batch, exp
+
+
+def canonical_vcf_line(line):
+    """A record line with its ALT alleles in sorted order and the genotype indices remapped accordingly: the
+    reference orders ALTs by list(set(...)) (per-process hash order, prepareVcf.py:63,75), so two runs are compared
+    in this form.  None stays None."""
+    if line is None:
+        return None
+    f = line.split("\t")
+    alts = f[4].split(",")
+    order = sorted(range(len(alts)), key=lambda i: alts[i])
+    new_index = {old + 1: new + 1 for new, old in enumerate(order)}
+    new_index[0] = 0
+    f[4] = ",".join(alts[i] for i in order)
+    f[9] = "/".join(str(new_index[int(g)]) for g in f[9].split("/"))
+    return "\t".join(f)
+
+
+def load_vcf_reference():
+    """tests/golden/vcf_reference.json with pair keys back as tuples."""
+    import json
+    z = json.load(open(os.path.join(GOLDEN, "vcf_reference.json")))
+    unkey = lambda d: {tuple(k.split("|")): v for k, v in d.items()}           # noqa: E731
+    for c in z["calls"]:
+        c["likelihoods"] = unkey(c["likelihoods"])
+    for case in z["caller"]:
+        for site in case["sites"]:
+            if site["features"] is not None:
+                site["features"]["expertPredictions"] = [unkey(e) for e in site["features"]["expertPredictions"]]
+    for item in z["shard"]["items"]:
+        item["expertPredictions"] = tuple(unkey(e) for e in item["expertPredictions"])
+    return z
+
+
+def caller_case_sites(case):
+    """(spec, state, [(featureDict of uint8 arrays, ref one-hot [1, L, 5] uint8, fixture site)]) of one caller case of
+    vcf_reference.json: the pileups are regenerated from the stored seed (checked against the stored digest)."""
+    z = load_vcf_reference() if isinstance(case, int) else None
+    case = z["caller"][case] if z is not None else case
+    spec = ns.build(case["config"])
+    state = weights.synth_state(spec, seed=case["weight_seed"])
+    batch = synth.make_sites(len(case["sites"]), seed=case["batch_seed"], **case["batch_kwargs"])
+    assert hashlib.sha256(batch.reads0.tobytes()).hexdigest()[:16] == case["reads0_sha"], "synthetic generator drifted"
+    aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
+    r0 = np.concatenate([[0], np.cumsum(batch.reads_per_allele0)])
+    r1 = None if batch.reads1 is None else np.concatenate([[0], np.cumsum(batch.reads_per_allele1)])
+    out = []
+    for s, site in enumerate(case["sites"]):
+        fd = {}
+        for name, a in zip(site["alleles"], range(aoff[s], aoff[s + 1])):
+            fd[name] = (batch.reads0[r0[a]:r0[a + 1]], None if r1 is None else batch.reads1[r1[a]:r1[a + 1]])
+        out.append((fd, site))
+    return spec, state, out
+
+
+def reference_segment_onehot(genome, start, stop, span=150):
+    """caller_calling.py:53-97 (one_hot_encode / get_reference_segment): uint8 [1, span, 5], order ACGT + other."""
+    mid = (start + stop) // 2
+    left = mid - span // 2
+    seg = genome[left:left + span]
+    out = np.zeros((1, len(seg), 5), np.uint8)
+    out[0, np.arange(len(seg)), ["ACGT".find(b) if b in "ACGT" else 4 for b in seg]] = 1
+    return out
