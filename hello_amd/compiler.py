@@ -318,9 +318,9 @@ class _Lowering:
         return y
 
     # -- model -------------------------------------------------------------------------------
-    def read_frames(self, tech: int, stem: str = "read_convolver") -> Value:
+    def read_frames(self, tech: int, stem: str = "read_convolver", suffix: str = "") -> Value:
         spec = self.spec
-        name = f"{stem}{tech}"
+        name = f"{stem}{tech}{suffix}"
         nodes = spec.nets[name]
         cin = spec.channels[tech]
         buf = BUF_READS0 if tech == 0 else BUF_READS1
@@ -377,15 +377,31 @@ class _Lowering:
         return (cs0, cs1), ca
 
     def lower_merged(self):
-        """MoEMergedAdvanced.forward (MixtureOfExpertsAdvanced.py:398-484), useAdditive=True."""
+        """MoEMergedAdvanced.forward (MixtureOfExpertsAdvanced.py:398-484): useAdditive=True, the class default
+        (concatenated expert input; single technology only -- the reference raises on a hybrid one, :436) and
+        separate meta read convolvers (:438-458)."""
         spec = self.spec
         hybrid = spec.has("readConv1")
+        additive = spec.use_additive
+        if hybrid and not additive:
+            raise ValueError("hybrid MoEMergedAdvanced with useAdditive=False: the reference's own forward raises on it "
+                             "(MixtureOfExpertsAdvanced.py:436)")
 
-        def expert(idx, allele: Value, site: Value):
+        def mix(allele: Value, site: Value, a0, a1, flags=0) -> Value:
             x = self.new(ROWS_ALLELES, allele.length, allele.channels)
             self.ops.append(Op(OP_MIX, ROWS_ALLELES, src0=allele.vid, src1=site.vid, dst=x.vid,
                                cin=allele.channels, lin=allele.length, lout=allele.length,
-                               a0=2.0, a1=-1.0, seg=SEG_AS, flags=FLAG_MIX_REST))
+                               a0=a0, a1=a1, seg=SEG_AS, flags=flags))
+            return x
+
+        def expert(idx, allele: Value, site: Value):
+            if additive:
+                x = mix(allele, site, 2.0, -1.0, FLAG_MIX_REST)              # a - (s - a), in that rounding order
+            else:
+                rest = mix(allele, site, -1.0, 1.0)                          # s - a  (= -a + s exactly)
+                x = self.new(ROWS_ALLELES, allele.length, 2 * allele.channels)
+                self.ops.append(Op(OP_CONCAT, ROWS_ALLELES, src0=allele.vid, src1=rest.vid, dst=x.vid, cin=allele.channels,
+                                   c1=allele.channels, lin=allele.length, lout=allele.length))      # cat((a, s - a), dim=1)
             self.net(spec.nets[f"expert{idx}"], x, head_slot=idx)
 
         a0 = self.net(spec.nets["alleleConv0"], self.read_frames(0, "readConv"))
@@ -408,7 +424,15 @@ class _Lowering:
         else:
             s2 = self.segsum(a2, SEG_AS)                                              # :434
         expert(2, a2, s2)
-        self.net(spec.nets["meta"], s2, head_slot=3, softmax=True)
+        site_meta = s2
+        if spec.has("readConv0Meta"):
+            # separate read convolvers for the meta-expert: each site's reads summed (reads -> alleles -> sites)
+            if not spec.has("readConv1Meta"):
+                raise ValueError("readConv0Meta without readConv1Meta")
+            m0 = self.segsum(self.read_frames(0, "readConv", "Meta"), SEG_AS)
+            m1 = self.segsum(self.read_frames(1, "readConv", "Meta"), SEG_AS)
+            site_meta = self.net(spec.nets["siteConvCombiner"], (m0, m1)) if spec.has("siteConvCombiner") else self.add(m0, m1)
+        self.net(spec.nets["meta"], site_meta, head_slot=3, softmax=True)
         return 3, True
 
     def lower(self):

@@ -106,13 +106,14 @@ def _conv_node(prefix, idx, layers, pos):
     wn = _cls(layer) == "WeightNormedConv1d"
     conv = layer._modules["conv1d"] if wn else layer
     key = f"{prefix}.{idx}.conv1d" if wn else f"{prefix}.{idx}"
-    used, norm, bn_key, act = 1, ("wn" if wn else "none"), None, "none"
+    used, norm, bn_key, act, bn_eps = 1, ("wn" if wn else "none"), None, "none", 1e-5
     while pos + used < len(layers):
         nxt = _cls(layers[pos + used])
         if nxt == "BatchNorm1d" and norm != "bn" and act == "none":
             if wn:
                 raise NotImplementedError("BatchNorm after a weight-normed conv")
             norm, bn_key = "bn", f"{prefix}.{idx + used}"
+            bn_eps = float(layers[pos + used].eps)
         elif nxt == "Noop" and act == "none":
             pass
         elif nxt == "ReLU" and act == "none":
@@ -125,7 +126,7 @@ def _conv_node(prefix, idx, layers, pos):
         if act != "none":
             break
     (k,), (s,), (p,), (d,) = conv.kernel_size, conv.stride, conv.padding, conv.dilation
-    return ns.Conv(key, conv.in_channels, conv.out_channels, k, s, p, d, conv.groups, norm, bn_key, act), used
+    return ns.Conv(key, conv.in_channels, conv.out_channels, k, s, p, d, conv.groups, norm, bn_key, act, bn_eps), used
 
 
 def _convert(network, prefix: str) -> List[ns.Node]:
@@ -165,13 +166,14 @@ def _convert(network, prefix: str) -> List[ns.Node]:
             wn = _cls(lin) == "WeightNormedLinear"
             linear = lin._modules["linear"] if wn else lin
             key = f"{prefix}.{pos + 3}.linear" if wn else f"{prefix}.{pos + 3}"
+            bn_eps = 1e-5
             if _cls(mid) == "BatchNorm1d":
-                norm, bn_key = "bn", f"{prefix}.{pos + 2}"
+                norm, bn_key, bn_eps = "bn", f"{prefix}.{pos + 2}", float(mid.eps)
                 if wn:
                     raise NotImplementedError("BatchNorm before a weight-normed linear")
             else:
                 norm, bn_key = ("wn" if wn else "none"), None
-            nodes.append(ns.Head(key, linear.in_features, linear.out_features, norm, bn_key))
+            nodes.append(ns.Head(key, linear.in_features, linear.out_features, norm, bn_key, bn_eps))
             pos += 4
         elif name == "Fork":
             nets = [m for n, m in layer._modules.items() if n.startswith("net")]
@@ -201,16 +203,19 @@ _MOE_ATTENTION_NETS = ["read_convolver0", "read_convolver1", "compressor0", "com
                        "xattn0", "xattn1", "xattn2", "combiner0", "combiner1", "meta"]
 
 
-_MOE_MERGED_NETS = ["readConv0", "readConv1", "alleleConv0", "alleleConv1", "expert0", "expert1", "expert2", "meta"]
+_MOE_MERGED_NETS = ["readConv0", "readConv1", "alleleConv0", "alleleConv1", "expert0", "expert1", "expert2", "meta",
+                    "readConv0Meta", "readConv1Meta"]
 
 
 def _spec_from_merged(moe) -> ns.ModelSpec:
-    """Pickled ``MoEMergedAdvanced`` (MixtureOfExpertsAdvanced.py:255-331).  Supported: the additive form
-    (useAdditive=True) without separate meta convolvers -- what MoEMergedConfig250FeatureMap.py describes."""
-    if not moe.__dict__.get("useAdditive", False):
-        raise NotImplementedError("MoEMergedAdvanced with useAdditive=False (concatenated expert input) is not supported")
-    if any(n.endswith("Meta") and m is not None for n, m in moe._modules.items()):
-        raise NotImplementedError("MoEMergedAdvanced with separate meta convolvers is not supported")
+    """Pickled ``MoEMergedAdvanced`` (MixtureOfExpertsAdvanced.py:255-331): the additive form (useAdditive=True),
+    the class default (useAdditive=False: concatenated expert input, single technology -- the reference's own
+    forward raises on a hybrid one, :436) and separate meta read convolvers (useSeparateMeta, :328-331)."""
+    use_additive = bool(moe.__dict__.get("useAdditive", False))
+    if not use_additive and moe._modules.get("readConv1") is not None:
+        raise NotImplementedError(
+            "hybrid MoEMergedAdvanced with useAdditive=False: the reference's own forward raises on it ('Boolean value "
+            "of Tensor with more than one value is ambiguous', MixtureOfExpertsAdvanced.py:436), there is nothing to match")
     nets = {}
     for name in _MOE_MERGED_NETS:
         sub = moe._modules.get(name)
@@ -224,7 +229,8 @@ def _spec_from_merged(moe) -> ns.ModelSpec:
             nets[name] = [ns.Concat()] + _convert(sub._modules["network"], f"moeMerged.{name}.network")
     first0 = next(ns.walk(nets["readConv0"]))
     c1 = next(ns.walk(nets["readConv1"])).cin if "readConv1" in nets else first0.cin
-    return ns.ModelSpec(nets, name="reference_pickle", channels=(first0.cin, c1), family="merged")
+    return ns.ModelSpec(nets, name="reference_pickle", channels=(first0.cin, c1), family="merged",
+                        use_additive=use_additive)
 
 
 def spec_from_module(wrapper) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:

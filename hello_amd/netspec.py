@@ -42,6 +42,7 @@ class Conv:
     norm: str = "wn"          # "wn" | "bn" | "none"
     bn_key: Optional[str] = None
     act: str = "relu"         # "relu" | "none" | "softplus"
+    bn_eps: float = 1e-5      # eps of the following BatchNorm1d (torch default; a pickle may carry another)
 
 
 @dataclass
@@ -67,6 +68,7 @@ class Head:
     cout: int
     norm: str = "wn"
     bn_key: Optional[str] = None
+    bn_eps: float = 1e-5
 
 
 @dataclass
@@ -110,6 +112,9 @@ class ModelSpec:
     channels: Tuple[int, int] = (6, 6)
     prefix: str = "moeMerged"
     family: str = "attention"        # "attention": MoEAttention (:71-252);  "merged": MoEMergedAdvanced (:255-484)
+    # merged family only: expert input a - (s - a) (useAdditive=True) or cat(a, s - a) along channels (the class
+    # default, MixtureOfExpertsAdvanced.py:270,372-383)
+    use_additive: bool = True
 
     def has(self, net: str) -> bool:
         return net in self.nets and self.nets[net] is not None

@@ -96,19 +96,22 @@ def _wn_weight(state, key) -> np.ndarray:
 
 
 def fold_node(node, state) -> Tuple[np.ndarray, np.ndarray]:
-    """Effective (weight, bias) of a Conv ([cout, cin/groups, k]) or Head ([cout, cin]) node."""
+    """Effective (weight, bias) of a Conv ([cout, cin/groups, k]) or Head ([cout, cin]) node.  A layer pickled
+    with ``bias=None`` has no bias entry (zeros); a BatchNorm1d with ``affine=False`` no weight / bias entries
+    (gamma 1, beta 0); its eps is the module's own (``node.bn_eps``)."""
     if node.norm == "wn":
         w = _wn_weight(state, node.key)
     else:
         w = np.asarray(state[node.key + ".weight"], dtype=np.float32)
-    b = np.asarray(state[node.key + ".bias"], dtype=np.float32)
+    b = np.asarray(state[node.key + ".bias"], dtype=np.float32) if node.key + ".bias" in state else \
+        np.zeros(w.shape[0], np.float32)
     if node.norm == "bn":
         k = node.bn_key
-        gamma = np.asarray(state[k + ".weight"], np.float32)
-        beta = np.asarray(state[k + ".bias"], np.float32)
         mean = np.asarray(state[k + ".running_mean"], np.float32)
         var = np.asarray(state[k + ".running_var"], np.float32)
-        scale = gamma / np.sqrt(var + np.float32(BN_EPS))
+        gamma = np.asarray(state[k + ".weight"], np.float32) if k + ".weight" in state else np.ones_like(mean)
+        beta = np.asarray(state[k + ".bias"], np.float32) if k + ".bias" in state else np.zeros_like(mean)
+        scale = gamma / np.sqrt(var + np.float32(getattr(node, "bn_eps", BN_EPS)))
         if isinstance(node, ns.Conv):
             # conv -> BN: scale output channels
             w = w * scale[:, None, None]

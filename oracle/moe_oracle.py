@@ -211,15 +211,20 @@ class Oracle:
 
 
 def _forward_merged(self, tensors, alleles_per_site, reads_per_allele):
-    """``MoEMergedAdvanced.forward`` (MixtureOfExpertsAdvanced.py:398-484) with useAdditive=True and no
-    separate meta convolvers: read conv -> allele sums -> allele conv (:332-342); per-site frames
-    (:369-370, :422-436); expert input a - (repeat(s) - a) (:372-383); meta softmax over dim 1 (:480)."""
+    """``MoEMergedAdvanced.forward`` (MixtureOfExpertsAdvanced.py:398-484): read conv -> allele sums -> allele conv
+    (:332-342); per-site frames (:369-370, :422-436); expert input a - (repeat(s) - a) with useAdditive, else
+    cat(a, repeat(s) - a) along channels (:372-383; a hybrid model without useAdditive raises in the reference,
+    :436, and here); separate meta read convolvers sum each site's reads directly (:344-367, :438-458); meta softmax
+    over dim 1 (:480)."""
     spec = self.spec
     aps = np.asarray(alleles_per_site, dtype=np.int64)
     frames0 = segment_sum(self._net("readConv0", np.asarray(tensors[0], dtype=F32)), reads_per_allele[0])
     a0 = self._net("alleleConv0", frames0)
     frames = {"frames0": frames0}
     hybrid = spec.has("readConv1") and tensors[1] is not None
+    additive = getattr(spec, "use_additive", True)
+    if hybrid and not additive:
+        raise RuntimeError("Boolean value of Tensor with more than one value is ambiguous")      # :436
     if hybrid:
         frames["frames1"] = segment_sum(self._net("readConv1", np.asarray(tensors[1], dtype=F32)), reads_per_allele[1])
         a1 = self._net("alleleConv1", frames["frames1"])
@@ -228,7 +233,8 @@ def _forward_merged(self, tensors, alleles_per_site, reads_per_allele):
 
     def expert(idx, allele, site):
         remaining = np.repeat(site, aps, axis=0) - allele
-        return self._net(f"expert{idx}", allele - remaining)
+        x = allele - remaining if additive else np.concatenate([allele, remaining], axis=1)
+        return self._net(f"expert{idx}", x)
 
     p0 = expert(0, a0, s0)
     self.last = dict(frames, ca0=a0)
@@ -237,7 +243,20 @@ def _forward_merged(self, tensors, alleles_per_site, reads_per_allele):
     s1 = segment_sum(a1, aps)
     s2 = self._net("siteConvCombiner", (s0, s1)) if spec.has("siteConvCombiner") else segment_sum(a2, aps)
     p1, p2 = expert(1, a1, s1), expert(2, a2, s2)
-    logits = self._net("meta", s2)
+    site_meta = s2
+    if spec.has("readConv0Meta"):
+        # preparePerSiteFramesFromReads (:344-367): every read of a site summed directly (reduceFrames)
+        site_reads = [np.add.reduceat(np.asarray(r, dtype=np.int64), np.concatenate([[0], np.cumsum(aps)])[:-1])
+                      for r in reads_per_allele]
+
+        def per_site(name, x, counts):
+            conv = self._net(name, np.asarray(x, dtype=F32))
+            off = np.concatenate([[0], np.cumsum(counts)])
+            return np.stack([conv[off[i]:off[i + 1]].sum(axis=0, dtype=F32) for i in range(len(counts))]).astype(F32)
+        m0 = per_site("readConv0Meta", tensors[0], site_reads[0])
+        m1 = per_site("readConv1Meta", tensors[1], site_reads[1])
+        site_meta = self._net("siteConvCombiner", (m0, m1)) if spec.has("siteConvCombiner") else m0 + m1
+    logits = self._net("meta", site_meta)
     logits = logits - logits.max(axis=1, keepdims=True)
     e = np.exp(logits)
     return [p0, p1, p2], (e / e.sum(axis=1, keepdims=True)).astype(F32)

@@ -370,6 +370,100 @@ def make_merged_pickle_fixture():
           f"[{res['logits'].min():.3f},{res['logits'].max():.3f}] meta {res['meta'][0]}")
 
 
+def make_merged_variant_pickles():
+    """Real reference pickles of the two MoEMergedAdvanced variants beyond the additive hybrid:
+      mini_merged_concat   single technology, the class DEFAULT useAdditive=False: the expert reads
+                           cat(allele, rest-of-site) (MixtureOfExpertsAdvanced.py:270,372-383); weight norm;
+      mini_merged_sepmeta  hybrid, additive, useSeparateMeta=True (:328-331,438-458): the meta-expert reads per-site sums
+                           of its OWN read convolvers; BatchNorm layers (weight-normed modules cannot be deep-copied by
+                           this torch), one of them with a non-default eps, one without affine parameters, and one
+                           convolution without a bias -- what a loader must read off the modules, not assume."""
+    rb = dict(kernelSizes=[3, 3], paddings=[1, 1], dilations=[1, 1])
+
+    def nets(kw):
+        def read_conv():
+            c = NNTools.SingleConvLayer(6, 8, 3, 0, 1, 1, **kw)
+            c.append({"type": "MaxPool1d", "kwargs": {"kernel_size": 3, "stride": 2, "padding": 0}})
+            return c + [NNTools.ResidualBlockFTShortcut(8, 8, strides=[1, 1], **rb, **kw),
+                        NNTools.ResidualBlockConvShortcut(8, 16, strides=[2, 1, 2], **rb, **kw)]
+
+        def allele_conv():
+            return NNTools.SingleConvLayer(16, 16, 1, 0, 1, 1, **kw) + \
+                [NNTools.ResidualBlockConvShortcut(16, 32, strides=[2, 1, 2], **rb, **kw)]
+
+        def graph_conv(cin, outputs=1):
+            c = NNTools.SingleConvLayer(cin, 32, 1, 0, 1, 1, **kw)
+            c += [NNTools.ResidualBlockConvShortcut(32, 64, strides=[2, 1, 2], **rb, **kw)]
+            return c + NNTools.terminus(64, outputs, **kw)
+        return read_conv, allele_conv, graph_conv
+
+    def finish(wrapper, name, batch, first_layer_keys, gain=1.0):
+        wrapper.eval()
+        with torch.no_grad():
+            for pname, p in wrapper.named_parameters():
+                if pname.endswith("weight_g"):
+                    p.mul_(gain * (1.0 + 0.25 * torch.rand_like(p)))
+                if pname in first_layer_keys:
+                    p.div_(128.0)
+            for bname, b in wrapper.named_buffers():
+                if bname.endswith("running_mean"):
+                    b.copy_(0.2 * torch.rand_like(b) - 0.1)
+                if bname.endswith("running_var"):
+                    b.copy_(0.5 + torch.rand_like(b))
+        path = os.path.join(HERE, name + ".wrapper.dnn")
+        torch.save(wrapper, path)
+        res = run_batched(wrapper, batch)
+        res.pop("frames0")
+        res.update(run_wrapper(wrapper, batch, synth.allele_names(batch)))
+        wrapper.providePredictions = False
+        payload = dict(reads0=batch.reads0, reads_per_allele0=batch.reads_per_allele0,
+                       alleles_per_site=batch.alleles_per_site, ref_onehot=batch.ref_onehot)
+        if batch.reads1 is not None:
+            payload.update(reads1=batch.reads1, reads_per_allele1=batch.reads_per_allele1)
+        payload.update({"exp_" + k: v for k, v in res.items()})
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **payload)
+        print(f"{name}: pickle {os.path.getsize(path) / 1024:.0f} KB, logits [{res['logits'].min():.3f},{res['logits'].max():.3f}]"
+              + (f" meta {res['meta'][0]}" if "meta" in res else ""))
+
+    torch.manual_seed(1357)
+    read_conv, allele_conv, graph_conv = nets(dict(use_weight_norm=True))
+    moe = REF.createMoEFullMergedAdvancedModel({"readConvNGS": read_conv(), "alleleConvSingleNGS": allele_conv(),
+                                                "graphConvSingleNGS": graph_conv(64)})          # no kwargs: the defaults
+    assert moe.useAdditive is False
+    finish(REF.createMoEFullMergedAdvancedModelWrapper(moe), "mini_merged_concat", synth.make_sites(5, seed=432, coverage=12),
+           {"moeMerged.readConv0.network.0.conv1d.weight_g"}, gain=1.45)
+
+    torch.manual_seed(2468)
+    read_conv, allele_conv, graph_conv = nets({})
+    meta = NNTools.SingleConvLayer(16, 32, 1, 0, 1, 1) + [NNTools.ResidualBlockConvShortcut(32, 64, strides=[2, 1, 2], **rb)] + \
+        NNTools.terminus(64, 3)
+    moe = REF.createMoEFullMergedAdvancedModel({
+        "readConvNGS": read_conv(), "readConvTGS": read_conv(), "alleleConvSingleNGS": allele_conv(),
+        "alleleConvSingleTGS": allele_conv(), "graphConvSingleNGS": graph_conv(32), "graphConvSingleTGS": graph_conv(32),
+        "graphConvHybrid": graph_conv(32), "meta": meta, "kwargs": {"useAdditive": True}}, useSeparateMeta=True)
+    assert hasattr(moe, "readConv0Meta") and moe.siteConvCombiner is None
+    with torch.no_grad():
+        for p in moe.parameters():                                 # default init leaves these models nearly constant
+            if p.dim() > 1:
+                p.mul_(1.6)
+        for n, p in moe.readConv0Meta.named_parameters():          # the meta copies are their own parameters
+            p.add_(0.02 * torch.randn_like(p))
+        for n, p in moe.readConv1Meta.named_parameters():
+            p.add_(0.02 * torch.randn_like(p))
+        for name in ("readConv0", "readConv1", "readConv0Meta", "readConv1Meta"):
+            getattr(moe, name).network[0].weight.div_(128.0)
+        moe.meta.network[-1].weight.mul_(0.08)                     # keep the softmax away from saturation
+    bns = [m for m in moe.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    bns[-2].eps = 5e-2
+    target = moe.readConv0.network[4].ffNetwork.network
+    assert isinstance(target[1], torch.nn.BatchNorm1d)
+    target[1] = torch.nn.BatchNorm1d(target[1].num_features, eps=1e-3, affine=False)   # no affine parameters, own eps
+    assert isinstance(moe.alleleConv1.network[0], torch.nn.Conv1d)
+    moe.alleleConv1.network[0].bias = None                          # a convolution without a bias
+    finish(REF.createMoEFullMergedAdvancedModelWrapper(moe), "mini_merged_sepmeta",
+           synth.make_sites(5, seed=433, coverage=12, hybrid_coverage=7), set())
+
+
 def make_addendum_pickle_fixture():
     """A real pickle of a transfer-learning model: the small single-tech architecture of mini_reference with
     two more residual blocks on every sub-network, assembled by the reference's build_on_top."""
@@ -793,6 +887,10 @@ def main():
         make_merged_pickle_fixture()
     if not only or "mini_addendum" in only:
         make_addendum_pickle_fixture()
+    if not only or "mini_merged_variants" in only:
+        make_merged_variant_pickles()
+        if only == {"mini_merged_variants"}:
+            return
     for name, cfg, norm, n_sites, wseed, kw, with_wrapper, keep_frames, need in CASES:
         if only and name not in only:
             continue

@@ -58,6 +58,54 @@ def test_merged_family_pickle_loads_and_matches_reference():
     assert prog.n_experts == 3 and prog.has_meta and not prog.uses_ref
 
 
+def _pickle_case(name):
+    spec, state = loader.load_spec(os.path.join(GOLDEN, name + ".wrapper.dnn"))
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    batch = synth.SiteBatch(z["reads0"], z["reads_per_allele0"], z["alleles_per_site"], z["ref_onehot"],
+                            z["reads1"] if "reads1" in z.files else None,
+                            z["reads_per_allele1"] if "reads_per_allele1" in z.files else None)
+    return spec, state, batch, z
+
+
+def test_merged_family_default_concatenating_expert_input():
+    """A MoEMergedAdvanced pickled with the class DEFAULT useAdditive=False (MixtureOfExpertsAdvanced.py:270): the
+    expert reads cat(allele, rest of site) along channels (:378-383)."""
+    spec, state, batch, z = _pickle_case("mini_merged_concat")
+    assert spec.family == "merged" and not spec.use_additive and not spec.hybrid_inputs
+    assert next(ns.walk(spec.nets["expert0"])).cin == 2 * 32
+    logits, meta = mo.forward_batch(mo.Oracle(spec, state), batch)
+    np.testing.assert_allclose(logits, z["exp_logits"], rtol=2e-5, atol=2e-6)
+    prog = compiler.compile_model(spec, state)
+    kinds = [o.kind for o in prog.ops]
+    assert kinds.count(compiler.OP_CONCAT) == 1 and prog.n_experts == 1 and meta is None
+
+
+def test_merged_family_separate_meta_convolvers_bn_eps_affine_and_missing_bias():
+    """useSeparateMeta (:328-331,438-458) + what the loader must read off the modules: a BatchNorm eps that is not
+    1e-5, a BatchNorm without affine parameters, a convolution pickled with bias=None."""
+    spec, state, batch, z = _pickle_case("mini_merged_sepmeta")
+    assert spec.use_additive and spec.has("readConv0Meta") and spec.has("readConv1Meta") and not spec.has("siteConvCombiner")
+    eps = sorted({round(n.bn_eps, 6) for nodes in spec.nets.values() for n in ns.walk(nodes) if n.norm == "bn"})
+    assert eps == [1e-5, 1e-3, 5e-2]
+    assert "moeMerged.alleleConv1.network.0.bias" not in state                     # bias=None
+    assert "moeMerged.readConv0.network.4.ffNetwork.network.1.weight" not in state   # affine=False
+    logits, meta = mo.forward_batch(mo.Oracle(spec, state), batch)
+    np.testing.assert_allclose(logits, z["exp_logits"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(meta, z["exp_meta"], rtol=1e-5, atol=1e-6)
+    assert 0.2 < z["exp_meta"].max() < 0.9                                          # the softmax is not saturated
+    prog = compiler.compile_model(spec, state)
+    assert prog.n_experts == 3 and prog.has_meta
+
+
+def test_hybrid_concatenating_model_is_rejected_like_the_reference_rejects_it():
+    """The reference's forward raises on a hybrid MoEMergedAdvanced without useAdditive (:436, `if perSiteFrame1` on
+    a tensor): there is nothing to match, so lowering refuses it with the citation."""
+    spec = ns.build("merged_hybrid")
+    spec.use_additive = False
+    with pytest.raises(ValueError, match="436"):
+        compiler.compile_model(spec, weights.synth_state(spec, seed=1))
+
+
 def test_transfer_learning_pickle_loads_and_matches_reference():
     """Sequential(original, addendum) sub-networks built by the reference's build_on_top."""
     spec, state = loader.load_spec(os.path.join(GOLDEN, "mini_addendum.wrapper.dnn"))
