@@ -1,0 +1,193 @@
+"""The call.py-compatible throughput driver (hello_amd/call.py): host side on CPU -- shard files,
+the reference's flag surface, FASTA reading, the final-VCF stage -- and, on the GPU, one end-to-end run over
+pre-extracted shards against the oracle chain featurizer_oracle -> moe_oracle -> vcf_oracle."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from hello_amd import call, shards, vcf
+from hello_amd.featurizer import AlignedRead
+from oracle import featurizer_oracle as fo
+from oracle import vcf_oracle as vo
+
+REFERENCE_FLAGS = ["--ibam", "--pbam", "--ref", "--workdir", "--chromosomes", "--network", "--hybrid_hotspot",
+                   "--q_threshold", "--mapq_threshold", "--num_threads", "--reconcilement_size", "--include_hp"]   # call.py:245-323
+
+
+def random_read(rng, window_start, ref_len, span, tagged=False):
+    """A read with a random CIGAR around the allele span (matches, insertions, deletions, skips, clips)."""
+    ops, n_bases, used = [], 0, 0
+    if rng.random() < 0.2:
+        k = int(rng.integers(1, 6)); ops.append((fo.BAM_CSOFT_CLIP, k)); n_bases += k
+    for _ in range(int(rng.integers(1, 5))):
+        k = int(rng.integers(5, 70)); ops.append((fo.BAM_CMATCH, k)); n_bases += k; used += k
+        u = rng.random()
+        if u < 0.2:
+            k = int(rng.integers(1, 8)); ops.append((fo.BAM_CINS, k)); n_bases += k
+        elif u < 0.4:
+            k = int(rng.integers(1, 12)); ops.append((fo.BAM_CDEL, k)); used += k
+    k = int(rng.integers(3, 20)); ops.append((fo.BAM_CMATCH, k)); n_bases += k; used += k
+    lo = max(window_start + 1, span[0] - used)
+    start = min(int(rng.integers(lo, max(lo + 1, span[1]))), window_start + ref_len - used - 1)
+    return AlignedRead("".join(rng.choice(list("ACGT"), size=n_bases)), rng.integers(2, 60, size=n_bases).tolist(), ops, start,
+                       mapq=int(rng.integers(0, 80)), orientation=int(rng.choice([-1, 1])),
+                       hp=int(rng.integers(0, 3)) if tagged else 0)
+
+
+def random_sites(rng, n, hybrid=False, tagged=False, chromosomes=("chr1", "chr2")):
+    sites = []
+    for s in range(n):
+        window_start = 1000 + 700 * s
+        ref_len = 520
+        reference = "".join(rng.choice(list("ACGT"), size=ref_len))
+        start = window_start + 240 + int(rng.integers(0, 20))
+        length = int(rng.choice([1, 1, 2, 3]))
+        ref_allele = reference[start - window_start:start - window_start + length]
+        names = [ref_allele]
+        while len(names) < int(rng.choice([1, 2, 2, 3, 4])):
+            u = rng.random()
+            cand = ("".join(rng.choice(list("ACGT"), size=length)) if u < 0.4 else
+                    ref_allele + "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 3)))) if u < 0.7 else
+                    ref_allele[:length - 1])
+            if cand not in names:
+                names.append(cand)
+        names = [names[i] for i in rng.permutation(len(names))]
+        alleles = []
+        for a in names:
+            r0 = [random_read(rng, window_start, ref_len, (start, start + length), tagged) for _ in range(int(rng.choice([0, 1, 3, 6, 11])))]
+            r1 = [random_read(rng, window_start, ref_len, (start, start + length)) for _ in range(int(rng.choice([0, 2, 5])))] if hybrid else None
+            alleles.append((a, r0, r1))
+        sites.append(shards.CandidateSite(chromosomes[s % len(chromosomes)], start, start + length, reference, window_start, alleles))
+    return sites
+
+
+def test_flag_surface_is_the_reference_callers():
+    ap = call.parser()
+    known = {o for a in ap._actions for o in a.option_strings}
+    assert set(REFERENCE_FLAGS) <= known
+    args = ap.parse_args(["--network", "m.dnn", "--workdir", "w", "--ibam", "a.bam", "--pbam", "b.bam", "--ref", "r.fa",
+                          "--num_threads", "4", "--include_hp", "--mapq_threshold", "5", "--reconcilement_size", "0",
+                          "--hybrid_hotspot", "--q_threshold", "7", "--chromosomes", "chr1,chr2"])
+    assert args.num_threads == 4 and args.include_hp and args.hybrid_hotspot
+    with pytest.raises(SystemExit, match="--shards is required"):
+        call.main(ap.parse_args(["--network", "m.dnn", "--workdir", "w", "--ibam", "a.bam"]))
+    # features directory named as call.py:33-48 names it
+    assert call.features_dir_name("/data/run1/sample.sorted.bam", None) == "features_run1___sample__sorted__bam"
+    assert call.features_dir_name(None, None) == "features"
+
+
+def test_shard_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    for hybrid in (False, True):
+        sites = random_sites(rng, 7, hybrid=hybrid, tagged=True)
+        back = shards.read_shard(shards.write_shard(str(tmp_path / f"s{int(hybrid)}.npz"), sites))
+        assert len(back) == len(sites)
+        for a, b in zip(sites, back):
+            assert (a.chromosome, a.start, a.stop, a.reference, a.window_start) == (b.chromosome, b.start, b.stop, b.reference, b.window_start)
+            assert [n for n, _, _ in a.alleles] == [n for n, _, _ in b.alleles]
+            for (_, r0, r1), (_, q0, q1) in zip(a.alleles, b.alleles):
+                assert [(r.bases, list(r.quals), [tuple(c) for c in r.cigar], r.ref_start, r.mapq, r.orientation, r.hp) for r in r0] == \
+                       [(r.bases, list(r.quals), [tuple(c) for c in r.cigar], r.ref_start, min(r.mapq, 255), r.orientation, r.hp) for r in q0]
+                assert (r1 is None) == (q1 is None) and (r1 is None or len(r1) == len(q1))
+
+
+def test_fasta_and_window_reference(tmp_path):
+    path = tmp_path / "g.fa"
+    path.write_text(">chr1 first\nACGTAC\nGTTT\n>chr2\nGGGG\nCC\n>chrUn\nNNNN\n")
+    g = call.read_fasta(str(path), ["chr1", "chr2"])
+    assert g == {"chr1": "ACGTACGTTT", "chr2": "GGGGCC"}
+    w = call.WindowReference("ACGTACGTTT", 100)
+    assert w[102:105] == "GTA" and w[109] == "T"
+    with pytest.raises(IndexError):
+        w[99]
+    seg = call.reference_segment("ACGTN" * 40, 100, 101, span=150)
+    assert seg.shape == (150, 5) and seg.sum() == 150
+    assert seg[0].tolist() == [1, 0, 0, 0, 0] and seg[4].tolist() == [0, 0, 0, 0, 1]      # window [25, 175): A ... N
+
+
+def test_final_vcf_stage_equals_the_oracle_of_prepareVcf(tmp_path):
+    """prepare_vcf on .features files: the meta-weighted-mean calls of oracle.vcf_oracle.prepare_shard (itself
+    pinned by the reference's prepareVcf.vcfRecords output), sorted, under the reference's header."""
+    from tests.util import load_vcf_reference
+    z = load_vcf_reference()
+    items = [dict(i, meta=np.asarray(i["meta"], np.float32)) for i in z["shard"]["items"]]
+    half = len(items) // 2
+    files = [vcf.write_features(str(tmp_path / f"features{k}.features"), part) for k, part in enumerate((items[half:], items[:half]))]
+    lengths = {c: len(g) for c, g in z["genomes"].items()}
+    out = call.prepare_vcf(files, str(tmp_path / "results.output.vcf"), lambda rec: z["genomes"][rec["chromosome"]], lengths)
+    lines = open(out).read().split("\n")[:-1]
+    head = [ln for ln in lines if ln.startswith("#")]
+    body = [ln for ln in lines if not ln.startswith("#")]
+    assert head[0] == "##fileformat=VCFv4.1" and head[-1].startswith("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT")
+    assert "##contig=<ID=chrA,length=%d>" % lengths["chrA"] in head
+    want = vo.prepare_shard(items, z["genomes"])[4]
+    assert sorted(body) == sorted(want)
+    keys = [(ln.split("\t")[0], int(ln.split("\t")[1])) for ln in body]
+    assert keys == sorted(keys)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,hybrid,tagged", [("single_tech", False, False), ("single_tech_hp", False, True),
+                                               ("hybrid_ensemble2", True, False)])
+def test_driver_end_to_end_matches_the_oracle_chain(tmp_path, cfg, hybrid, tagged):
+    """python -m hello_amd.call over two pre-extracted shards: per-shard .vcf + .features + sentinel logs + the final
+    VCF, against featurizer_oracle -> moe_oracle (per-site wrapper) -> vcf_oracle on the same sites."""
+    from hello_amd import loader, netspec as ns, weights
+    from oracle import moe_oracle as mo
+    spec = ns.build(cfg)
+    state = weights.synth_state(spec, seed=17)
+    model = str(tmp_path / "model.hello.npz")
+    loader.save_native(model, cfg, state)
+    rng = np.random.default_rng(23)
+    shard_sites = [random_sites(rng, 30, hybrid, tagged), random_sites(rng, 17, hybrid, tagged)]
+    os.makedirs(tmp_path / "shards")
+    for k, sites in enumerate(shard_sites):
+        shards.write_shard(str(tmp_path / "shards" / f"shard{k}.npz"), sites)
+    argv = ["--network", model, "--workdir", str(tmp_path / "work"), "--shards", str(tmp_path / "shards"), "--num_threads", "2"]
+    if tagged:
+        argv.append("--include_hp")
+    result = call.main(call.parser().parse_args(argv))
+    fdir = tmp_path / "work" / "features"
+    wrapper = mo.WrapperOracle(spec, state, provide_predictions=True)
+    n_records, mean_lines = 0, []
+    for k, sites in enumerate(shard_sites):
+        assert call.SENTINEL in open(fdir / f"features{k}.log").read()
+        got_lines = open(fdir / f"features{k}.vcf").read().split("\n")[:-1]
+        got_feats = pickle.load(open(fdir / f"features{k}.features", "rb"))
+        assert len(got_lines) == len(got_feats)
+        at = 0
+        for site in sites:
+            genome = call.WindowReference(site.reference, site.window_start)
+            fd = {}
+            for name, r0, r1 in site.alleles:
+                def enc(reads, hp):
+                    return fo.features_for_reads([fo.Read(r.bases, r.quals, r.cigar, r.ref_start, r.mapq, r.orientation, r.hp) for r in reads],
+                                                 site.reference, site.window_start, site.start, site.stop, 150, hp).astype(np.float32)
+                fd[name] = (enc(r0, tagged), enc(r1, False) if hybrid else None)
+            seg = call.reference_segment(genome, site.start, site.stop)[None].astype(np.float32)
+            mix, e0, e1, e2, meta = wrapper(fd, seg)
+            want = vo.call_alleles({k2: float(v) for k2, v in mix.items()}, site.chromosome, site.start, site.stop - site.start,
+                                   genome, string="MixtureOfExpertPrediction")
+            if want is None:
+                continue
+            line, feats = got_lines[at], got_feats[at]
+            at += 1
+            n_records += 1
+            assert (feats["chromosome"], feats["position"], feats["length"]) == (site.chromosome, site.start, site.stop - site.start)
+            np.testing.assert_allclose(feats["meta"], meta, atol=1e-4)
+            for ge, we in zip(feats["expertPredictions"], (e0, e1, e2)):
+                assert list(ge) == list(we)
+                assert np.abs(np.array(list(ge.values())) - np.array([float(v) for v in we.values()])).max() < 1e-4
+            ps = sorted((float(v) for v in mix.values()), reverse=True)
+            if len(ps) > 1 and ps[0] - ps[1] < 2e-4:
+                continue                                    # a genuinely ambiguous site may flip
+            gf, wf = line.split("\t"), want.split("\t")
+            assert gf[:5] + gf[6:] == wf[:5] + wf[6:], (line, want)
+            if 1.0 - ps[0] > 1e-2:
+                assert abs(float(gf[5]) - float(wf[5])) < 0.05
+        assert at == len(got_lines)
+    assert n_records >= 30
+    body = [ln for ln in open(result).read().split("\n")[:-1] if not ln.startswith("#")]
+    assert len(body) >= 30 and all(ln.split("\t")[7] == "HELLO" for ln in body)
