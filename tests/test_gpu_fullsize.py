@@ -15,9 +15,12 @@ TOTAL_SITES = 1_000_000
 
 def _sub_batch(batch, sites):
     parts = [batch.site_slice(int(s), int(s) + 1) for s in sites]
+    second = batch.reads1 is not None
     return synth.SiteBatch(
         np.concatenate([p.reads0 for p in parts]), np.concatenate([p.reads_per_allele0 for p in parts]),
-        np.concatenate([p.alleles_per_site for p in parts]), np.concatenate([p.ref_onehot for p in parts]))
+        np.concatenate([p.alleles_per_site for p in parts]), np.concatenate([p.ref_onehot for p in parts]),
+        np.concatenate([p.reads1 for p in parts]) if second else None,
+        np.concatenate([p.reads_per_allele1 for p in parts]) if second else None)
 
 
 def test_million_site_stream_is_reproducible_and_matches_oracle_on_samples():
@@ -66,4 +69,37 @@ def test_million_site_stream_is_reproducible_and_matches_oracle_on_samples():
     aoff1 = np.concatenate([[0], np.cumsum(pool[1].alleles_per_site)])
     back = np.concatenate([first[1][0][0, aoff1[s]:aoff1[s + 1]] for s in order])
     np.testing.assert_allclose(lg_rev[0], back, rtol=1e-5, atol=1e-5)
+    eng.close()
+
+
+@pytest.mark.parametrize("label,cfg,kw", [
+    ("C3 PacBio HiFi, cov U{8..52}, R <= 128", "single_tech", dict(coverage=(8, 52), tech="pacbio")),
+    ("C4 hybrid no-ensemble, 30x + 15x", "hybrid_no_ensemble", dict(coverage=30, hybrid_coverage=15)),
+    ("C5 haplotagged (7 channels), cov U{20..80}", "single_tech_hp", dict(coverage=(20, 80), channels=7, tech="pacbio")),
+])
+def test_full_size_batches_of_the_other_baseline_configs(label, cfg, kw):
+    """BASELINE.json's other configurations at a full 8 192-site launch (alleles straddling the fused kernel's read
+    groups in both technologies): two runs bit-identical, 24 sampled sites equal to the oracle run on those sites
+    alone, reversed site order equal up to float re-association, posteriors inside [0, 1]."""
+    from hello_amd.engine import Engine
+    from oracle import moe_oracle as mo
+    spec = ns.build(cfg)
+    state = weights.synth_state(spec, seed=33)
+    eng = Engine(spec, state, device=0)
+    batch = synth.make_sites(SITES_PER_BATCH, seed=700 + len(cfg), **kw)
+    logits, meta, post = eng.forward_batch(batch, posteriors=True)
+    again, _, post2 = eng.forward_batch(batch, posteriors=True)
+    assert np.array_equal(logits, again) and np.array_equal(post, post2)
+    assert np.isfinite(logits).all() and post.min() >= 0.0 and post.max() <= 1.0 + 1e-6
+    rng = np.random.default_rng(9)
+    sample = np.sort(rng.choice(SITES_PER_BATCH, size=24, replace=False))
+    want, _ = mo.forward_batch(mo.Oracle(spec, state, backend="torch"), _sub_batch(batch, sample), chunk_sites=4)
+    aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
+    got = np.concatenate([logits[:, aoff[s]:aoff[s + 1]] for s in sample], axis=1)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-4)
+    assert np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-want.astype(np.float64)))).max() < 1e-4
+    order = np.arange(SITES_PER_BATCH)[::-1]
+    lg_rev, _ = eng.forward_batch(_sub_batch(batch, order))
+    back = np.concatenate([logits[:, aoff[s]:aoff[s + 1]] for s in order], axis=1)
+    np.testing.assert_allclose(lg_rev, back, rtol=1e-5, atol=1e-5)
     eng.close()
