@@ -293,6 +293,8 @@ void hello_engine_destroy(hello_engine* e) {
     delete e;
 }
 
+void* hello_engine_stream(hello_engine* e) { return e ? (void*)e->own_stream : nullptr; }
+
 int hello_engine_synchronize(hello_engine* e) {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
     HIP_TRY(hipSetDevice(e->device));

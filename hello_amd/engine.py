@@ -70,6 +70,8 @@ def load_library():
     lib.hello_engine_set_profiling_filter.argtypes = [vp, i32]
     lib.hello_engine_debug_capture.argtypes = [vp, i32]
     lib.hello_engine_debug_read.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    lib.hello_engine_stream.argtypes = [vp]
+    lib.hello_engine_stream.restype = C.c_void_p
     lib.hello_engine_destroy.argtypes = [vp]
     lib.hello_engine_destroy.restype = None
     for fn in ("hello_engine_create", "hello_engine_forward", "hello_engine_posteriors",
@@ -129,6 +131,41 @@ class Engine:
         self.device = device
         self.n_experts = p.n_experts
         self.has_meta = p.has_meta
+        self._own = None                    # torch view of the engine's own stream (created on first use)
+
+    # -- stream ordering of device-path calls ---------------------------------------------------------
+    class _OnStream:
+        """Device-path calls run on the caller's current torch stream.  When that is the legacy default stream
+        (handle 0 -- which the C ABI reads as "the engine's own, non-blocking stream") the call runs on the engine's
+        stream bracketed by events: it waits for what the default stream has enqueued (the inputs) and the default
+        stream waits for it (the outputs), so the call stays asynchronous and correctly ordered."""
+
+        def __init__(self, engine, device, stream):
+            import torch
+            self.current = None
+            if not stream:                 # None, or 0 = the legacy default stream's handle
+                cur = torch.cuda.current_stream(device)
+                if cur.cuda_stream == 0:
+                    if engine._own is None:
+                        engine._own = torch.cuda.ExternalStream(engine.lib.hello_engine_stream(engine.handle), device=device)
+                    self.current, self.own = cur, engine._own
+                    stream = engine._own.cuda_stream
+                else:
+                    stream = cur.cuda_stream
+            self.handle = stream
+
+        def __enter__(self):
+            if self.current is not None:
+                self.own.wait_stream(self.current)
+            return self.handle
+
+        def __exit__(self, *exc):
+            if self.current is not None:
+                self.current.wait_stream(self.own)
+            return False
+
+    def on_stream(self, device, stream=None):
+        return Engine._OnStream(self, device, stream)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -237,8 +274,6 @@ class Engine:
             lp = logits.data_ptr()
             mp = meta.data_ptr() if meta is not None else None
             pp = post.data_ptr() if posteriors else None
-            if stream is None:
-                stream = torch.cuda.current_stream(reads0.device).cuda_stream
         else:
             if out is not None:
                 raise ValueError("preallocated outputs are a device-path feature")
@@ -248,9 +283,15 @@ class Engine:
             lp = logits.ctypes.data
             mp = meta.ctypes.data if meta is not None else None
             pp = post.ctypes.data if posteriors else None
-        _check(self.lib.hello_engine_forward(
-            self.handle, p0, rpa0.ctypes.data, p1 or None, rpa1.ctypes.data if rpa1 is not None else None,
-            aps.ctypes.data, pf or None, S, A, n0, n1, lp, mp, pp, flags, stream))
+        def launch(handle):
+            _check(self.lib.hello_engine_forward(
+                self.handle, p0, rpa0.ctypes.data, p1 or None, rpa1.ctypes.data if rpa1 is not None else None,
+                aps.ctypes.data, pf or None, S, A, n0, n1, lp, mp, pp, flags, handle))
+        if on_device:
+            with self.on_stream(reads0.device, stream) as handle:
+                launch(handle)
+        else:
+            launch(stream)
         if posteriors:
             return logits, meta, post
         return logits, meta
@@ -267,15 +308,17 @@ class Engine:
             out = torch.empty((4, P), dtype=torch.float32, device=logits.device)
             flags = HELLO_IN_DEVICE | HELLO_OUT_DEVICE
             lp, mp, op = logits.data_ptr(), (meta.data_ptr() if meta is not None else None), out.data_ptr()
-            if stream is None:
-                stream = torch.cuda.current_stream(logits.device).cuda_stream
         else:
             logits = np.ascontiguousarray(logits, dtype=np.float32)
             meta = np.ascontiguousarray(meta, dtype=np.float32) if meta is not None else None
             out = np.empty((4, P), dtype=np.float32)
             flags = 0
             lp, mp, op = logits.ctypes.data, (meta.ctypes.data if meta is not None else None), out.ctypes.data
-        _check(self.lib.hello_engine_posteriors(self.handle, lp, mp, aps.ctypes.data, S, A, P, op, flags, stream))
+        if on_device:
+            with self.on_stream(logits.device, stream) as handle:
+                _check(self.lib.hello_engine_posteriors(self.handle, lp, mp, aps.ctypes.data, S, A, P, op, flags, handle))
+        else:
+            _check(self.lib.hello_engine_posteriors(self.handle, lp, mp, aps.ctypes.data, S, A, P, op, flags, stream))
         return out
 
     def synchronize(self):

@@ -99,7 +99,7 @@ def featurize(engine: Engine, sites: Sequence[SiteReads], feature_length: int = 
     if device_output:
         import torch
         out = torch.empty((n_reads, feature_length, channels), dtype=torch.uint8, device=f"cuda:{engine.device}")
-        out_ptr, stream = out.data_ptr(), torch.cuda.current_stream(out.device).cuda_stream
+        out_ptr, stream = out.data_ptr(), None
         flags |= HELLO_OUT_DEVICE
     else:
         out = np.empty((n_reads, feature_length, channels), dtype=np.uint8)
@@ -109,8 +109,14 @@ def featurize(engine: Engine, sites: Sequence[SiteReads], feature_length: int = 
     vp = C.c_void_p
     fn.argtypes = [vp] * 16 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp]
     ptr = lambda k: p[k].ctypes.data                                              # noqa: E731
-    _check(fn(engine.handle, ptr("bases"), ptr("quals"), ptr("read_off"), ptr("cigars"), ptr("cigar_off"),
-              ptr("ref_start"), ptr("mapq"), ptr("orientation"), ptr("hp"), ptr("site_of_read"), ptr("ref"),
-              ptr("ref_off"), ptr("window_start"), ptr("asm_start"), ptr("asm_stop"),
-              n_reads, n_sites, feature_length, channels, out_ptr, flags, stream))
+    def launch(handle):
+        _check(fn(engine.handle, ptr("bases"), ptr("quals"), ptr("read_off"), ptr("cigars"), ptr("cigar_off"),
+                  ptr("ref_start"), ptr("mapq"), ptr("orientation"), ptr("hp"), ptr("site_of_read"), ptr("ref"),
+                  ptr("ref_off"), ptr("window_start"), ptr("asm_start"), ptr("asm_stop"),
+                  n_reads, n_sites, feature_length, channels, out_ptr, flags, handle))
+    if device_output:
+        with engine.on_stream(out.device) as handle:      # ordered with the caller's current torch stream
+            launch(handle)
+    else:
+        launch(None)
     return out, p["reads_per_allele"], p["alleles_per_site"]

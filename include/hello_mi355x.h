@@ -190,6 +190,12 @@ int hello_engine_featurize(hello_engine* engine,
                            int64_t n_reads, int32_t n_sites, int32_t feature_length, int32_t channels,
                            uint8_t* out, int32_t flags, void* hip_stream);
 
+/* The engine's own stream (a hipStream_t): what a call with hip_stream == NULL runs on.  It is created
+ * non-blocking, so it is NOT ordered with the legacy default stream: a caller whose other work sits on the default
+ * stream (handle 0, indistinguishable from NULL here) orders the two with events on this handle -- the Python
+ * binding does (hello_amd/engine.py). */
+void* hello_engine_stream(hello_engine* engine);
+
 /* Wait for everything the engine has enqueued on its last stream. */
 int hello_engine_synchronize(hello_engine* engine);
 
