@@ -30,10 +30,10 @@ from . import weights as wts
 ROWS_READS0, ROWS_READS1, ROWS_ALLELES, ROWS_SITES = 0, 1, 2, 3
 SEG_R0A, SEG_R1A, SEG_AS = 0, 1, 2
 BUF_NONE, BUF_READS0, BUF_READS1, BUF_REF, BUF_FIRST_SCRATCH = -1, 0, 1, 2, 3
-OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED = range(1, 9)
+OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED, OP_LAYERNORM = range(1, 10)
 FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS, FLAG_WINOGRAD = 1, 2, 4, 8, 16, 32
 OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
-            8: "readconv_fused"}
+            8: "readconv_fused", 9: "layernorm"}
 
 
 @dataclass
@@ -173,7 +173,8 @@ def _canonical_read_convolver_extras(nodes, cin, act="relu") -> int:
 
     def sig(n):
         if isinstance(n, ns.Conv):
-            return ("c", n.cin, n.cout, n.k, n.stride, n.pad, n.groups, n.act)
+            # a LayerNorm between convolutions is a layer of its own: such a read convolver is not the fused kernel's
+            return ("c", n.cin, n.cout, n.k, n.stride, n.pad, n.groups, n.act, n.norm == "ln")
         if isinstance(n, ns.MaxPool):
             return ("p", n.k, n.stride, n.pad)
         if isinstance(n, ns.Residual):
@@ -197,6 +198,7 @@ def _is_canonical_read_convolver(nodes, cin) -> bool:
 class _Lowering:
     def __init__(self, spec: ns.ModelSpec, state, fused: bool, winograd: bool = True):
         self.spec = spec
+        self.state = state
         self.folded = wts.fold(spec, state)
         self.fused = fused
         self.winograd = bool(winograd)
@@ -237,15 +239,23 @@ class _Lowering:
         lout = ns.out_length([node], x.length)
         m = winograd_outputs_per_tile(lout)
         y = self.new(x.domain, lout, node.cout)
+        act_flag = {"relu": FLAG_RELU, "softplus": FLAG_SOFTPLUS, "none": 0}[node.act]
+        layer_norm = node.norm == "ln"          # conv + bias, then LayerNorm over channels, activation, residual
         self.ops.append(Op(
-            OP_CONV1D, x.domain, src0=x.vid, dst=y.vid, res=res.vid if res is not None else BUF_NONE,
+            OP_CONV1D, x.domain, src0=x.vid, dst=y.vid, res=res.vid if (res is not None and not layer_norm) else BUF_NONE,
             cin=node.cin, cout=node.cout, k=node.k, stride=node.stride, pad=node.pad,
             lin=x.length, lout=lout,
-            flags=({"relu": FLAG_RELU, "softplus": FLAG_SOFTPLUS, "none": 0}[node.act] | (FLAG_SRC_U8 if x.u8 else 0)
-                   | (FLAG_WINOGRAD if wino else 0)),
+            flags=((0 if layer_norm else act_flag) | (FLAG_SRC_U8 if x.u8 else 0) | (FLAG_WINOGRAD if wino else 0)),
             w_off=self.blob.add(packed), b_off=self.blob.add(bias), name=node.key,
             macs_per_row=lout * node.cout * (node.cin // node.groups) * node.k,
             exec_macs_per_row=float(-(-lout // m) * (m + 2) * node.cout * node.cin) if wino else 0.0))
+        if layer_norm:
+            gamma, beta, eps = wts.layer_norm_params(node, self.state)
+            z = self.new(x.domain, lout, node.cout)
+            self.ops.append(Op(OP_LAYERNORM, x.domain, src0=y.vid, dst=z.vid, res=res.vid if res is not None else BUF_NONE,
+                               cin=node.cout, cout=node.cout, lin=lout, lout=lout, flags=act_flag, a0=float(eps),
+                               w_off=self.blob.add(gamma), b_off=self.blob.add(beta), name=node.bn_key + ".normer"))
+            return z
         return y
 
     def net(self, nodes, x, head_slot: Optional[int] = None, softmax=False):

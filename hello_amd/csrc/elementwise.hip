@@ -44,6 +44,61 @@ hipError_t launch_maxpool(const float* src, float* dst, long long rows, int lin,
     return hipGetLastError();
 }
 
+// ---- LayerNorm over channels (LayerNormModule, NNTools.py:802-828) -----------------------------------
+// One wave per position: lane i holds channels i, i + 64, ... (c <= 512); mean and biased variance by two wave
+// reductions (the two-pass form: variance of the centred values), then scale, shift, activation, residual.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ src, const float* __restrict__ res,
+                                                        float* __restrict__ dst, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, long long positions, int c,
+                                                        float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), stride = (long long)gridDim.x * 4;
+    for (long long p = wave0; p < positions; p += stride) {
+        const float* x = src + p * c;
+        float v[8];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = (lane + 64 * k < c) ? x[lane + 64 * k] : 0.f;
+            sum += v[k];
+        }
+        const float mean = wave_sum(sum) / (float)c;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = (lane + 64 * k < c) ? v[k] - mean : 0.f;
+            sq += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)c + eps);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < c) {
+                float y = (v[k] - mean) * rstd * gamma[ch] + beta[ch];
+                if (act == 1) y = fmaxf(y, 0.f);
+                else if (act == 2) y = y > 20.f ? y : __logf(1.f + __expf(y));
+                if (res) y += res[p * c + ch];
+                dst[p * c + ch] = y;
+            }
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float* src, const float* res, float* dst, const float* gamma, const float* beta,
+                            long long positions, int c, float eps, int act, hipStream_t stream) {
+    if (positions <= 0) return hipSuccess;
+    if (c <= 0 || c > 512) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(grid_for(positions, 4, 1 << 16)), dim3(256), 0, stream, src, res, dst, gamma,
+                       beta, positions, c, eps, act);
+    return hipGetLastError();
+}
+
 // ---- ragged segment sum (reduceSlots) -------------------------------------------------------
 // Rows of a segment are contiguous; each thread owns one float4 column of one segment and adds the
 // rows in order, so the result is deterministic and independent of the batch composition.

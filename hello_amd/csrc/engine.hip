@@ -144,7 +144,7 @@ int validate_model(const hello_model_desc* d) {
     };
     for (int i = 0; i < d->n_ops; ++i) {
         const hello_op& o = d->ops[i];
-        if (o.kind < HELLO_OP_CONV1D || o.kind > HELLO_OP_READCONV_FUSED)
+        if (o.kind < HELLO_OP_CONV1D || o.kind > HELLO_OP_LAYERNORM)
             return fail(HELLO_ERR_MODEL, "op %d: unknown kind %d", i, o.kind);
         if (o.domain < 0 || o.domain > 3) return fail(HELLO_ERR_MODEL, "op %d: bad domain", i);
         if (!buf_ok(o.src0, false)) return fail(HELLO_ERR_MODEL, "op %d: bad src0", i);
@@ -162,6 +162,8 @@ int validate_model(const hello_model_desc* d) {
             if ((o.lin + 2 * o.pad - o.k) / o.stride + 1 != o.lout)
                 return fail(HELLO_ERR_MODEL, "op %d: lout inconsistent", i);
         }
+        if (o.kind == HELLO_OP_LAYERNORM && (o.cin <= 0 || o.cin > 512 || o.lin <= 0 || o.w_off < 0 || o.b_off < 0 || !(o.a0 > 0.f)))
+            return fail(HELLO_ERR_MODEL, "op %d: bad LayerNorm (1..512 channels, eps > 0)", i);
         if ((o.kind == HELLO_OP_SEGSUM || o.kind == HELLO_OP_MIX || o.kind == HELLO_OP_READCONV_FUSED) &&
             (o.seg < 0 || o.seg > 2))
             return fail(HELLO_ERR_MODEL, "op %d: bad segment kind", i);
@@ -242,6 +244,9 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
         } else if (o.kind == HELLO_OP_HEAD) {
             w_end = (size_t)o.w_off + (size_t)o.cout * o.cin;
             b_end = (size_t)o.b_off + o.cout;
+        } else if (o.kind == HELLO_OP_LAYERNORM) {
+            w_end = (size_t)o.w_off + o.cin;
+            b_end = (size_t)o.b_off + o.cin;
         } else if (o.kind == HELLO_OP_READCONV_FUSED) {
             w_end = (size_t)o.w_off + hello::readconv_weight_floats(o.k, (o.flags & HELLO_FLAG_WINOGRAD) != 0, desc->window);
             b_end = (size_t)o.b_off;
@@ -324,7 +329,7 @@ int hello_engine_set_profiling(hello_engine* e, int max_forwards) {
 
 int hello_engine_set_profiling_filter(hello_engine* e, int32_t op_kind) {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
-    if (op_kind < 0 || op_kind > HELLO_OP_READCONV_FUSED) return fail(HELLO_ERR_ARG, "unknown op kind %d", op_kind);
+    if (op_kind < 0 || op_kind > HELLO_OP_LAYERNORM) return fail(HELLO_ERR_ARG, "unknown op kind %d", op_kind);
     e->prof_filter = op_kind;
     e->prof_count = 0;               // recordings made under another filter do not mix
     return HELLO_OK;
@@ -676,6 +681,11 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
             case HELLO_OP_ADD:
                 HIP_TRY(hello::launch_add((const float*)ptr(o.src0), (const float*)ptr(o.src1), (float*)ptr(o.dst),
                                           rows * o.lin * o.cin, stream));
+                break;
+            case HELLO_OP_LAYERNORM:
+                HIP_TRY(hello::launch_layernorm((const float*)ptr(o.src0), (const float*)ptr(o.res), (float*)ptr(o.dst),
+                                                e->d_weights + o.w_off, e->d_weights + o.b_off, rows * o.lin, o.cin, o.a0,
+                                                (o.flags & HELLO_FLAG_RELU) ? 1 : ((o.flags & HELLO_FLAG_SOFTPLUS) ? 2 : 0), stream));
                 break;
             case HELLO_OP_READCONV_FUSED: {
                 const bool t1 = o.seg == HELLO_SEG_READS1_TO_ALLELES;

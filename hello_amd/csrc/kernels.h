@@ -49,6 +49,10 @@ hipError_t launch_concat(const float* src0, const float* src1, float* dst, long 
 
 hipError_t launch_add(const float* src0, const float* src1, float* dst, long long n, hipStream_t stream);
 
+// LayerNorm over the c channels of every position, then activation (0 none | 1 ReLU | 2 Softplus), then + res
+hipError_t launch_layernorm(const float* src, const float* res, float* dst, const float* gamma, const float* beta,
+                            long long positions, int c, float eps, int act, hipStream_t stream);
+
 // uint8 [R][C][L] -> uint8 [R][L][C]
 hipError_t launch_rcl_to_rlc(const uint8_t* src, uint8_t* dst, long long rows, int len, int c,
                              hipStream_t stream);

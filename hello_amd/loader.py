@@ -114,6 +114,11 @@ def _conv_node(prefix, idx, layers, pos):
                 raise NotImplementedError("BatchNorm after a weight-normed conv")
             norm, bn_key = "bn", f"{prefix}.{idx + used}"
             bn_eps = float(layers[pos + used].eps)
+        elif nxt == "LayerNormModule" and norm not in ("bn", "ln") and act == "none":
+            if wn:
+                raise NotImplementedError("LayerNorm after a weight-normed conv")
+            norm, bn_key = "ln", f"{prefix}.{idx + used}"
+            bn_eps = float(layers[pos + used]._modules["normer"].eps)
         elif nxt == "Noop" and act == "none":
             pass
         elif nxt == "ReLU" and act == "none":

@@ -39,8 +39,8 @@ class Conv:
     pad: int = 0
     dilation: int = 1
     groups: int = 1
-    norm: str = "wn"          # "wn" | "bn" | "none"
-    bn_key: Optional[str] = None
+    norm: str = "wn"          # "wn" | "bn" | "ln" | "none"
+    bn_key: Optional[str] = None   # key of the BatchNorm1d -- or, for "ln", of the LayerNormModule (its LayerNorm: <key>.normer)
     act: str = "relu"         # "relu" | "none" | "softplus"
     bn_eps: float = 1e-5      # eps of the following BatchNorm1d (torch default; a pickle may carry another)
 
@@ -135,7 +135,7 @@ class ModelSpec:
 # --------------------------------------------------------------------------------------------
 class _Seq:
     def __init__(self, prefix: str, norm: str, act: str = "relu"):
-        assert norm in ("wn", "bn", "none")
+        assert norm in ("wn", "bn", "ln", "none")
         self.prefix = prefix
         self.norm = norm
         self.act = act
@@ -147,8 +147,10 @@ class _Seq:
         norm = self.norm if norm is None else norm
         if norm == "wn":
             return Conv(f"{base}.{idx}.conv1d", cin, cout, k, stride, pad, 1, groups, "wn", None, act)
-        if norm == "bn":
-            return Conv(f"{base}.{idx}", cin, cout, k, stride, pad, 1, groups, "bn", f"{base}.{idx + 1}", act)
+        if norm in ("bn", "ln"):
+            # plain conv followed by BatchNorm1d (folded at load) or LayerNormModule (NNTools.py:802-828: LayerNorm
+            # over the channels of every position -- data dependent, so it stays a layer of its own)
+            return Conv(f"{base}.{idx}", cin, cout, k, stride, pad, 1, groups, norm, f"{base}.{idx + 1}", act)
         return Conv(f"{base}.{idx}", cin, cout, k, stride, pad, 1, groups, "none", None, act)
 
     def skip(self, n: int = 1):
@@ -500,6 +502,8 @@ CONFIGS = {
     "hybrid_ensemble2": lambda **kw: hybrid_ensemble2(**kw),
     # moe_attention_config_single_tech_old_equivalent_layer_norm.py: plain convs, no normalisation, Softplus
     "single_tech_softplus": lambda **kw: single_tech(norm="none", act="softplus", **kw),
+    # the same file with its commented-out line 14 active: norm_type = "LayerNormModule" (terminus stays BatchNorm)
+    "single_tech_layernorm": lambda **kw: single_tech(norm="ln", act="softplus", **kw),
     "single_tech_addendum": lambda **kw: single_tech_addendum(**kw),
     "hybrid_no_ensemble_addendum": lambda **kw: hybrid_no_ensemble_addendum(**kw),
     "merged_single": lambda **kw: merged_single(**kw),
@@ -517,6 +521,7 @@ REFERENCE_CONFIG_MODULE = {
     "hybrid_full": "moe_attention_config_full_hybrid_old_equivalent_weight_norm",
     "hybrid_ensemble2": "moe_attention_config_full_hybrid_old_equivalent_weight_norm_ensemble2",
     "single_tech_softplus": "moe_attention_config_single_tech_old_equivalent_layer_norm",
+    "single_tech_layernorm": "moe_attention_config_single_tech_old_equivalent_layer_norm",
     "single_tech_addendum": "moe_attention_config_single_tech_old_equivalent_weight_norm_addendum",
     "hybrid_no_ensemble_addendum": "moe_attention_config_full_hybrid_old_equivalent_weight_norm_no_ensemble_addendum",
 }

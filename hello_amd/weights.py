@@ -76,6 +76,10 @@ def synth_state(spec: ns.ModelSpec, seed: int = 0, gain: float = 1.0) -> Dict[st
             else:
                 state[node.key + ".weight"] = (v * np.float32(layer_gain)).astype(np.float32)
                 state[node.key + ".bias"] = bias
+            if node.norm == "ln":
+                k = node.bn_key + ".normer"                       # LayerNormModule.normer = torch.nn.LayerNorm(cout)
+                state[k + ".weight"] = rng.uniform(0.7, 1.3, size=node.cout).astype(np.float32)
+                state[k + ".bias"] = _uniform(rng, (node.cout,), 0.1)
             if node.norm == "bn":
                 c = node.cout if isinstance(node, ns.Conv) else node.cin
                 k = node.bn_key
@@ -122,6 +126,14 @@ def fold_node(node, state) -> Tuple[np.ndarray, np.ndarray]:
             b = b + w @ shift
             w = w * scale[None, :]
     return np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32)
+
+
+def layer_norm_params(node, state) -> Tuple[np.ndarray, np.ndarray, float]:
+    """(gamma, beta, eps) of the LayerNorm that follows a Conv node with norm "ln" (NNTools.py:802-828)."""
+    k = node.bn_key + ".normer"
+    gamma = np.asarray(state[k + ".weight"], np.float32) if k + ".weight" in state else np.ones(node.cout, np.float32)
+    beta = np.asarray(state[k + ".bias"], np.float32) if k + ".bias" in state else np.zeros(node.cout, np.float32)
+    return gamma, beta, float(getattr(node, "bn_eps", 1e-5))
 
 
 def fold(spec: ns.ModelSpec, state) -> Dict[str, Tuple[np.ndarray, np.ndarray]]:

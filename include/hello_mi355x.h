@@ -80,6 +80,11 @@ typedef enum hello_op_kind {
                                  * (+0 | 2 extra blocks in k; from the bytes with FLAG_SRC_U8, else from the
                                  * pooled stem output), or on 250 bp windows (from the bytes, Winograd form);
                                  * dst rows are [36 | 61][64] per allele                                   */
+    ,
+    HELLO_OP_LAYERNORM = 9   /* LayerNormModule (NNTools.py:802-828) between a convolution and its activation:
+                              * dst[r][l][:] = act((src0[r][l][:] - mean) / sqrt(var + a0) * gamma + beta) (+ res), mean and
+                              * biased variance over the cin channels of the position; gamma at w_off, beta at b_off,
+                              * eps in a0; flags: HELLO_FLAG_RELU | HELLO_FLAG_SOFTPLUS                                */
 } hello_op_kind;
 
 #define HELLO_FLAG_RELU     1

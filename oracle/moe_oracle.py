@@ -101,17 +101,28 @@ def segment_sum(d, slots):
 # --------------------------------------------------------------------------------------------
 # sub-network interpreter  (NNTools.Network.forward, NNTools.py:633-657)
 # --------------------------------------------------------------------------------------------
-def run_net(nodes: Sequence[ns.Node], x, folded, backend="numpy"):
+def layer_norm_channels(x, gamma, beta, eps):
+    """``LayerNormModule`` on a [N, C, L] tensor (NNTools.py:802-828): torch.nn.LayerNorm over the channels of every
+    position -- mean and biased variance over C, (x - mean) / sqrt(var + eps) * gamma + beta, in float32."""
+    mean = x.mean(axis=1, keepdims=True, dtype=F32)
+    var = np.mean((x - mean) ** 2, axis=1, keepdims=True, dtype=F32)
+    return ((x - mean) / np.sqrt(var + F32(eps)) * gamma[None, :, None] + beta[None, :, None]).astype(F32)
+
+
+def run_net(nodes: Sequence[ns.Node], x, folded, backend="numpy", state=None):
     for node in nodes:
         if isinstance(node, ns.Conv):
             w, b = folded[node.key]
-            x = activation(conv1d(x, w, b, node.stride, node.pad, node.groups, backend), node.act)
+            x = conv1d(x, w, b, node.stride, node.pad, node.groups, backend)
+            if node.norm == "ln":
+                x = layer_norm_channels(x, *wts.layer_norm_params(node, state))
+            x = activation(x, node.act)
         elif isinstance(node, ns.MaxPool):
             x = max_pool1d(x, node.k, node.stride, node.pad)
         elif isinstance(node, ns.Residual):
             # ResidualBlock.forward: ffNetwork(x) + shNetwork(x)  (NNTools.py:582-583)
-            short = run_net(node.shortcut, x, folded, backend) if node.shortcut else x
-            x = run_net(node.body, x, folded, backend) + short
+            short = run_net(node.shortcut, x, folded, backend, state) if node.shortcut else x
+            x = run_net(node.body, x, folded, backend, state) + short
         elif isinstance(node, ns.Head):
             # AdaptiveAvgPool1d(1) -> Flatten -> [BatchNorm folded] -> Linear  (NNTools.py:517-566)
             w, b = folded[node.key]
@@ -140,10 +151,11 @@ class Oracle:
     def __init__(self, spec: ns.ModelSpec, state: Dict[str, np.ndarray], backend: str = "numpy"):
         self.spec = spec
         self.folded = wts.fold(spec, state)
+        self.state = state
         self.backend = backend
 
     def _net(self, name, x):
-        return run_net(self.spec.nets[name], x, self.folded, self.backend)
+        return run_net(self.spec.nets[name], x, self.folded, self.backend, self.state)
 
     def compress_and_predict(self, frames_allele, alleles_per_site, idx):
         """MixtureOfExpertsAdvanced.py:117-159.  The site-level compressor call of line 136 is

@@ -113,6 +113,26 @@ def reference_model(config_name, norm):
         return reference_merged(config_name)
     if config_name.endswith("_addendum"):
         return reference_addendum(config_name)
+    if config_name == "single_tech_layernorm":
+        # moe_attention_config_single_tech_old_equivalent_layer_norm.py with its commented-out line 14 active
+        # (module.norm_type = "LayerNormModule" instead of "Noop"); globals of the shared architecture modules restored
+        import architectures.read_convolver as rc
+        import architectures.compressor_conv_small as cc
+        import architectures.xattn_subtract as xs
+        try:
+            for m in (rc, cc, xs):
+                m.weight_norm = False
+                m.norm_type = "LayerNormModule"
+                m.activation = "Softplus"
+                m.gen_config()
+            cfg = {"read_conv0": rc.config, "compressor0": cc.config, "xattn0": xs.config}
+            wrapper = REF.createMoEFullMergedAdvancedModelWrapper(REF.create_moe_attention_model(cfg))
+        finally:
+            for m in (rc, cc, xs):
+                m.norm_type, m.activation = "BatchNorm1d", "ReLU"
+                m.gen_config()
+        wrapper.eval()
+        return wrapper
     if config_name == "single_tech_softplus":
         # the config module rewrites globals of the shared architecture modules: restore them afterwards
         import architectures.read_convolver as rc
@@ -242,6 +262,7 @@ CASES = [
     ("hybrid_no_ensemble_wide", "hybrid_no_ensemble_wide", "wn", 3, 24, dict(coverage=20, hybrid_coverage=10), True,
      False, ("multi",)),
     ("single_tech_softplus", "single_tech_softplus", "wn", 4, 23, dict(coverage=20), True, False, ("one", "multi")),
+    ("single_tech_layernorm", "single_tech_layernorm", "wn", 4, 25, dict(coverage=20), True, True, ("one", "multi")),
     ("single_tech_addendum", "single_tech_addendum", "wn", 3, 21, dict(coverage=20), True, False, ("multi",)),
     ("hybrid_no_ensemble_addendum", "hybrid_no_ensemble_addendum", "wn", 3, 22, dict(coverage=20, hybrid_coverage=10),
      True, False, ("multi",)),

@@ -95,7 +95,7 @@ def test_read_convolver_frames_match_reference(engines, fused):
 @pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_full", "hybrid_ensemble2", "hybrid_no_ensemble",
                                   "merged_single", "merged_hybrid", "merged_hybrid_250", "single_tech_addendum",
                                   "hybrid_no_ensemble_addendum", "single_tech_softplus",
-                                  "hybrid_no_ensemble_wide"])
+                                  "hybrid_no_ensemble_wide", "single_tech_layernorm"])
 def test_golden_posteriors(engines, name):
     spec, state, batch, exp = load_fixture(name)
     eng = get_engine(engines, name, spec, state, True)

@@ -156,6 +156,24 @@ def test_softplus_model_uses_the_fused_kernel_in_winograd_form_only():
         assert not compiler.compile_model(spec, state, **kw).fused_read_convolver
 
 
+def test_layernorm_model_keeps_layernorm_as_a_layer_of_its_own():
+    """LayerNormModule (NNTools.py:802-828) is data dependent: it cannot be folded into the convolution before it, so
+    the read convolver is not the fused kernel's and every conv is followed by a LAYERNORM op carrying the activation
+    (and, at the end of a residual block, the shortcut)."""
+    spec = ns.build("single_tech_layernorm")
+    prog = compiler.compile_model(spec, weights.synth_state(spec, seed=1))
+    assert not prog.fused_read_convolver
+    convs = [i for i, o in enumerate(prog.ops) if o.kind == compiler.OP_CONV1D]
+    norms = [i for i, o in enumerate(prog.ops) if o.kind == compiler.OP_LAYERNORM]
+    shortcuts = 3                                          # 1x1 strided shortcuts carry no normalisation
+    assert len(norms) == len(convs) - shortcuts == 31
+    for i in norms:
+        conv = prog.ops[i - 1]
+        assert conv.kind == compiler.OP_CONV1D and conv.dst == prog.ops[i].src0
+        assert not (conv.flags & (compiler.FLAG_RELU | compiler.FLAG_SOFTPLUS)) and conv.res == compiler.BUF_NONE
+    assert sum(prog.ops[i].res != compiler.BUF_NONE for i in norms) == 13    # one per residual block (7 + 3 + 3)
+
+
 def test_250bp_model_uses_the_fused_kernel_in_winograd_form_only():
     spec = ns.build("merged_hybrid_250")
     state = weights.synth_state(spec, seed=1)

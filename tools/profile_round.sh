@@ -11,8 +11,10 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT $SUM
 export TMPDIR=/tmp
-# 1. kernel statistics of the command the driver runs
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+# 1. kernel statistics of the command the driver runs, with the secondary legs (latency, 256-site launches, ...)
+#    switched off so that every readconv_kernel launch in the statistics is a headline launch of --sites sites:
+#    its average must agree with roofline.launch_ms of the JSON line printed by the same process
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $SUM/${TAG}_rocprofv3_kernel_stats_bench.csv
 cp $OUT/bench_under_rocprof.json $SUM/${TAG}_bench_under_rocprofv3.json
 echo "stats done"
