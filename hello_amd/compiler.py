@@ -30,10 +30,11 @@ from . import weights as wts
 ROWS_READS0, ROWS_READS1, ROWS_ALLELES, ROWS_SITES = 0, 1, 2, 3
 SEG_R0A, SEG_R1A, SEG_AS = 0, 1, 2
 BUF_NONE, BUF_READS0, BUF_READS1, BUF_REF, BUF_FIRST_SCRATCH = -1, 0, 1, 2, 3
-OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED, OP_LAYERNORM = range(1, 10)
+(OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED, OP_LAYERNORM,
+ OP_COMPRESSOR_FUSED) = range(1, 11)
 FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS, FLAG_WINOGRAD = 1, 2, 4, 8, 16, 32
 OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
-            8: "readconv_fused", 9: "layernorm"}
+            8: "readconv_fused", 9: "layernorm", 10: "compressor_fused"}
 
 
 @dataclass
@@ -90,6 +91,7 @@ class Program:
     buffers: List[Tuple[int, int]]          # (domain, floats_per_row) per physical buffer id
     weights: np.ndarray                      # float32 blob
     fused_read_convolver: bool = False
+    fused_compressor: bool = False
     winograd: bool = False           # k3/s1/p1 convolutions run in Winograd form (F(2,3) / F(3,3)) where a kernel offers it
 
     def describe(self) -> str:
@@ -207,6 +209,7 @@ class _Lowering:
         self.blob = _WeightBlob()
         self.next_vid = 1000        # virtual ids live above any physical id
         self.used_fused = False
+        self.used_fused_compressor = False
         self.uses_ref = False
 
     # -- values ----------------------------------------------------------------------------
@@ -259,6 +262,18 @@ class _Lowering:
         return y
 
     def net(self, nodes, x, head_slot: Optional[int] = None, softmax=False):
+        from . import readconv_pack
+        if (self.fused is True and self.winograd and isinstance(x, Value) and not x.u8 and (x.length, x.channels) == (36, 64)
+                and readconv_pack.compressor_blocks(nodes) in readconv_pack.COMPRESSOR_BLOCKS):
+            # the canonical allele-level compressor: one LDS-resident kernel instead of 4 + 2 blocks launches
+            blocks = readconv_pack.compressor_blocks(nodes)
+            y = self.new(x.domain, 18, 128)
+            w_off = self.blob.add(readconv_pack.pack_compressor(nodes, self.folded))
+            self.ops.append(Op(OP_COMPRESSOR_FUSED, x.domain, src0=x.vid, dst=y.vid, cin=64, cout=128, k=blocks, lin=36, lout=18,
+                               flags=FLAG_WINOGRAD | FLAG_RELU, w_off=w_off, b_off=w_off, name=nodes[0].key.rsplit(".network", 1)[0],
+                               macs_per_row=ns.macs(nodes, 36), exec_macs_per_row=readconv_pack.compressor_executed_macs(blocks)))
+            self.used_fused_compressor = True
+            return y
         for node in nodes:
             if isinstance(node, ns.Conv):
                 x = self.conv(node, x)
@@ -549,4 +564,5 @@ def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool 
         spec_name=spec.name, window=spec.window, channels0=spec.channels[0],
         channels1=spec.channels[1] if spec.hybrid_inputs else 0,
         n_experts=n_experts, has_meta=has_meta, uses_ref=low.uses_ref, ops=low.ops,
-        buffers=buffers, weights=low.blob.finish(), fused_read_convolver=low.used_fused, winograd=low.winograd)
+        buffers=buffers, weights=low.blob.finish(), fused_read_convolver=low.used_fused,
+        fused_compressor=low.used_fused_compressor, winograd=low.winograd)

@@ -144,7 +144,7 @@ int validate_model(const hello_model_desc* d) {
     };
     for (int i = 0; i < d->n_ops; ++i) {
         const hello_op& o = d->ops[i];
-        if (o.kind < HELLO_OP_CONV1D || o.kind > HELLO_OP_LAYERNORM)
+        if (o.kind < HELLO_OP_CONV1D || o.kind > HELLO_OP_COMPRESSOR_FUSED)
             return fail(HELLO_ERR_MODEL, "op %d: unknown kind %d", i, o.kind);
         if (o.domain < 0 || o.domain > 3) return fail(HELLO_ERR_MODEL, "op %d: bad domain", i);
         if (!buf_ok(o.src0, false)) return fail(HELLO_ERR_MODEL, "op %d: bad src0", i);
@@ -162,6 +162,11 @@ int validate_model(const hello_model_desc* d) {
             if ((o.lin + 2 * o.pad - o.k) / o.stride + 1 != o.lout)
                 return fail(HELLO_ERR_MODEL, "op %d: lout inconsistent", i);
         }
+        if (o.kind == HELLO_OP_COMPRESSOR_FUSED &&
+            !(o.cin == 64 && o.cout == 128 && o.lin == 36 && o.lout == 18 && hello::compressor_supports_blocks(o.k) &&
+              (o.flags & HELLO_FLAG_WINOGRAD) && o.w_off >= 0))
+            return fail(HELLO_ERR_MODEL, "op %d: the fused compressor maps [36][64] rows to [18][128] with 2 or 3 identity blocks, "
+                                         "Winograd form", i);
         if (o.kind == HELLO_OP_LAYERNORM && (o.cin <= 0 || o.cin > 512 || o.lin <= 0 || o.w_off < 0 || o.b_off < 0 || !(o.a0 > 0.f)))
             return fail(HELLO_ERR_MODEL, "op %d: bad LayerNorm (1..512 channels, eps > 0)", i);
         if ((o.kind == HELLO_OP_SEGSUM || o.kind == HELLO_OP_MIX || o.kind == HELLO_OP_READCONV_FUSED) &&
@@ -247,6 +252,9 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
         } else if (o.kind == HELLO_OP_LAYERNORM) {
             w_end = (size_t)o.w_off + o.cin;
             b_end = (size_t)o.b_off + o.cin;
+        } else if (o.kind == HELLO_OP_COMPRESSOR_FUSED) {
+            w_end = (size_t)o.w_off + hello::compressor_weight_floats(o.k);
+            b_end = (size_t)o.b_off;
         } else if (o.kind == HELLO_OP_READCONV_FUSED) {
             w_end = (size_t)o.w_off + hello::readconv_weight_floats(o.k, (o.flags & HELLO_FLAG_WINOGRAD) != 0, desc->window);
             b_end = (size_t)o.b_off;
@@ -329,7 +337,7 @@ int hello_engine_set_profiling(hello_engine* e, int max_forwards) {
 
 int hello_engine_set_profiling_filter(hello_engine* e, int32_t op_kind) {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
-    if (op_kind < 0 || op_kind > HELLO_OP_LAYERNORM) return fail(HELLO_ERR_ARG, "unknown op kind %d", op_kind);
+    if (op_kind < 0 || op_kind > HELLO_OP_COMPRESSOR_FUSED) return fail(HELLO_ERR_ARG, "unknown op kind %d", op_kind);
     e->prof_filter = op_kind;
     e->prof_count = 0;               // recordings made under another filter do not mix
     return HELLO_OK;
@@ -682,6 +690,16 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 HIP_TRY(hello::launch_add((const float*)ptr(o.src0), (const float*)ptr(o.src1), (float*)ptr(o.dst),
                                           rows * o.lin * o.cin, stream));
                 break;
+            case HELLO_OP_COMPRESSOR_FUSED: {
+                hello::CompressorArgs a{};
+                a.frames = (const float*)ptr(o.src0);
+                a.dst = (float*)ptr(o.dst);
+                a.w = e->d_weights + o.w_off;
+                a.n_items = rows;
+                a.blocks = o.k;
+                HIP_TRY(hello::launch_compressor_fused(a, stream));
+                break;
+            }
             case HELLO_OP_LAYERNORM:
                 HIP_TRY(hello::launch_layernorm((const float*)ptr(o.src0), (const float*)ptr(o.res), (float*)ptr(o.dst),
                                                 e->d_weights + o.w_off, e->d_weights + o.b_off, rows * o.lin, o.cin, o.a0,
@@ -718,7 +736,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
         if (op_index == e->debug_op) {
             // snapshot of this op's output before a later op reuses the buffer
             const size_t per_row = o.kind == HELLO_OP_CONCAT ? (size_t)o.lout * (o.cin + o.c1)
-                                   : (o.kind == HELLO_OP_CONV1D || o.kind == HELLO_OP_READCONV_FUSED) ? (size_t)o.lout * o.cout
+                                   : (o.kind == HELLO_OP_CONV1D || o.kind == HELLO_OP_READCONV_FUSED || o.kind == HELLO_OP_COMPRESSOR_FUSED) ? (size_t)o.lout * o.cout
                                    : (o.kind == HELLO_OP_MAXPOOL ? (size_t)o.lout * o.cin : (size_t)o.lin * o.cin);
             const size_t n = (size_t)rows * per_row;
             if (n * sizeof(float) > e->d_debug.cap) {

@@ -89,6 +89,20 @@ hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
 hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames, int n_alleles,
                                     int frame_rows, hipStream_t stream);
 
+// ---- fused allele-level compressor (readconv_fused.hip) ---------------------------------------------------
+// architectures/compressor_conv_small.py (and ExpertAlleleConvolver*.py): 1x1 64->64, strided block 64->128 with
+// its 1x1 shortcut, `blocks` identity residual blocks at 128 channels; [items][36][64] -> [items][18][128].
+struct CompressorArgs {
+    const float* frames;       // [items][36][64]
+    float* dst;                // [items][18][128]
+    const float* w;            // packed block, hello_amd/readconv_pack.py pack_compressor
+    long long n_items;
+    int blocks;                // identity residual blocks after the strided one: 2 | 3
+};
+int compressor_weight_floats(int blocks);
+bool compressor_supports_blocks(int blocks);
+hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream);
+
 // ---- pileup-tensor producer (featurize.hip) ----------------------------------------------------------
 struct FeaturizeArgs {
     const uint8_t* bases;            // all reads' bases, concatenated (ASCII)

@@ -192,8 +192,8 @@ __device__ __forceinline__ int img_off(int row, int chunk) {     // float offset
     if constexpr (SW == SW_OLD) {
         return row * C + 4 * (chunk ^ swz<C>(row));
     } else if constexpr (SW == SW_3) {
-        static_assert(C == 64, "SW_3 images have 64 channels");
-        return row * 64 + 4 * (chunk ^ (2 * ((row / 3) & 7)));
+        static_assert(C % 64 == 0, "SW_3 images have whole bank rows of channels (64 | 128): the XOR stays inside a row's first 16 chunks");
+        return row * C + 4 * (chunk ^ (2 * ((row / 3) & 7)));
     } else if constexpr (C == 64) {
         return row * 64 + 4 * (chunk ^ (2 * ((row >> 1) & 7)));
     } else {
@@ -207,7 +207,7 @@ __device__ __forceinline__ int img_off(int row, int chunk) {     // float offset
 // division by 3 of a lane-varying value (16 t + j + i / 3, and 16 t vanishes under & 7)
 template <int C, int SW>
 __device__ __forceinline__ int img_off_triple(int t, int j, int i, int chunk) {
-    if constexpr (SW == SW_3) return (48 * t + 3 * j + i) * 64 + 4 * (chunk ^ (2 * ((j + i / 3) & 7)));
+    if constexpr (SW == SW_3) return (48 * t + 3 * j + i) * C + 4 * (chunk ^ (2 * ((j + i / 3) & 7)));
     else return img_off<C, SW>(48 * t + 3 * j + i, chunk);
 }
 
@@ -431,9 +431,10 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
             constexpr int first0 = ((16 * t0 + RS_OUT - 1) / RS_OUT) * RS_OUT, last0 = ((16 * t0 + RS_OUT) / RS_OUT) * RS_OUT - 1;
             constexpr int first1 = ((16 * t1 + RS_OUT - 1) / RS_OUT) * RS_OUT, last1 = ((16 * t1 + RS_OUT) / RS_OUT) * RS_OUT - 1;
             if constexpr (tap0 == 0 && first0 > 0 && first0 <= 16 * t0 + 15) x0 = (j == first0 - 16 * t0) ? zero4 : x0;
-            if constexpr (tap0 == KT - 1 && last0 <= 16 * t0 + 15 && last0 < RS_OUT * CF::G - 1) x0 = (j == last0 - 16 * t0) ? zero4 : x0;
+            // (a stride-2 layer over rows of even length never reads past its row's end: 2 (L/2 - 1) + 1 = L - 1)
+            if constexpr (STRIDE == 1 && tap0 == KT - 1 && last0 <= 16 * t0 + 15 && last0 < RS_OUT * CF::G - 1) x0 = (j == last0 - 16 * t0) ? zero4 : x0;
             if constexpr (tap1 == 0 && first1 > 0 && first1 <= 16 * t1 + 15) x1 = (j == first1 - 16 * t1) ? zero4 : x1;
-            if constexpr (tap1 == KT - 1 && last1 <= 16 * t1 + 15 && last1 < RS_OUT * CF::G - 1) x1 = (j == last1 - 16 * t1) ? zero4 : x1;
+            if constexpr (STRIDE == 1 && tap1 == KT - 1 && last1 <= 16 * t1 + 15 && last1 < RS_OUT * CF::G - 1) x1 = (j == last1 - 16 * t1) ? zero4 : x1;
         }
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[0], x0[0], a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0], x1[0], a1, 0, 0, 0);
@@ -637,20 +638,21 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
 // MFMAs per wave and layer, evenly (F(2,3): 9 tiles split 5 / 4, 144 on average).  No read boundaries to patch on
 // the input side (the zero rows are the padding); a read's 24th triple ends ON the zero row, whose output is
 // stored as zero.
-template <class CF, int C, int MODE, bool LAST>
+// The allele-level compressor kernel below instantiates the same layer at 128 channels over 8 items of 18 rows (8 waves):
+// RS (rows per item), the image swizzle and the compact-stacking flag are template parameters defaulting to the read
+// convolver's geometry.
+template <class CF, int C, int MODE, bool LAST, int RS = (C == 64 ? CF::RS2 : CF::RS1), int SW = (C == 32 ? SW_W : SW_3),
+          bool EDGE = (C != 32)>
 __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float* __restrict__ out, f32x4 (&w)[2][5],
                                             const float* __restrict__ wl, const float* __restrict__ next_wl,
                                             const float* __restrict__ bias, int wave, int lane) {
     static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE, "block convolutions only (the strided block's second "
                   "conv finds its shortcut in the output image, like a residual)");
-    static_assert(C == 64 ? CF::F33 : (C == 32 && CF::F33_32), "image of whole tiles of 16 triples");
-    static_assert(CF::NW == 4, "4 waves: 4 channel blocks, or 2 channel blocks x 2 position groups");
+    static_assert(RS % 3 == 0 && (RS * CF::G) % 48 == 0, "image of whole tiles of 16 triples");
     constexpr int M = C / 16, NCB = C / 16, NPG = CF::NW / NCB;              // input groups; waves = blocks x position groups
-    constexpr int RS = C == 64 ? CF::RS2 : CF::RS1;
+    static_assert(NPG >= 1 && NCB * NPG == CF::NW && (RS * CF::G / 48) % NPG == 0, "waves = channel blocks x position groups");
     constexpr int NT = RS * CF::G / 48 / NPG;                                // 3 tiles of 16 triples per wave
-    constexpr int TPR = RS / 3;                                              // triples per read (12 | 24)
-    constexpr int SW = C == 64 ? SW_3 : SW_W;
-    constexpr bool EDGE = C == 64;                                           // reads stacked without zero rows between them
+    constexpr int TPR = RS / 3;                                              // triples per read (12 | 24; 6 per allele)
     constexpr int TOFF = NPG * 48 * C;                                       // floats between a wave's tiles (a period of the swizzle)
     constexpr int NU = M * NT;
     const int cb = wave % NCB, pg = wave / NCB, j = lane & 15, q = lane >> 4;
@@ -659,12 +661,12 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
 
     // rows 48 pg + 3j + i, i = 0..4, input group m.  SW_3: i = 0..2 share the swizzle of row 3j, i = 3, 4 that of
     // row 3j + 3 (two pointers per group); SW_W (32 channels): one pointer per row
-    constexpr int NP = C == 64 ? 2 : 5;
+    constexpr int NP = SW == SW_3 ? 2 : 5;
     const float* pin[M][NP];
 #pragma unroll
     for (int m = 0; m < M; ++m)
 #pragma unroll
-        for (int i = 0; i < NP; ++i) pin[m][i] = in + img_off_triple<C, SW>(pg, j, (C == 64 ? 3 * i : i), 4 * m + q);
+        for (int i = 0; i < NP; ++i) pin[m][i] = in + img_off_triple<C, SW>(pg, j, (SW == SW_3 ? 3 * i : i), 4 * m + q);
     const float* const zrow = in + 4 * q;                                    // the leading zero row
     // flat rows 3T, 3T+1, 3T+2 = image rows 3T+1, 3T+2, 3T+3
     float* po[3];
@@ -692,7 +694,7 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
         }
         static_for<0, 5>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const float* ptr = (C == 64 ? pin[m][i / 3] + (i % 3) * 64 : pin[m][i < NP ? i : 0]) + k * TOFF;
+            const float* ptr = (SW == SW_3 ? pin[m][i / 3] + (i % 3) * C : pin[m][i < NP ? i : 0]) + k * TOFF;
             if constexpr (EDGE && i == 0) ptr = first ? zrow : ptr;
             if constexpr (EDGE && i == 4) ptr = last ? zrow : ptr;
             ring[u & 1][i] = *(const f32x4*)ptr;
@@ -1442,6 +1444,136 @@ hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_of
     if (n_alleles <= 0) return hipSuccess;
     hipLaunchKernelGGL(readconv_finalize_kernel, dim3(n_alleles), dim3(192), 0, stream, partial, slot_off, frames,
                        frame_rows * 16);
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// Fused allele-level compressor (architectures/compressor_conv_small.py:8-55; MixtureOfExpertsAdvanced.py:125):
+//     [36][64] per item -> 1x1 64->64 + ReLU -> strided block 64->128 (k3 s2 + ReLU, k3 s1 + ReLU, + 1x1 s2 shortcut)
+//     -> NB x ResidualBlock(128) -> [18][128]
+// One workgroup of 8 waves carries 8 items (alleles, or site sums) through all 4 + 2 NB convolutions with the
+// activations in LDS (two images of 74.75 KB: one workgroup per CU, two waves per SIMD), using the read convolver's
+// layer routines at twice the channel counts: the 64-channel image is 8 x 36 = 288 rows = 18 tiles of 16 rows, the
+// 128-channel image 8 x 18 = 144 rows = 3 tiles of 16 triples, both stacked without rows between the items (the taps
+// that would cross an item boundary read zero); every k3/s1 convolution runs in Winograd F(3,3) form (a wave owns one
+// of the 8 channel blocks and walks 8 input groups x 3 tiles).  Weights stream from L2 per layer, 1.5 MB per workgroup.
+namespace cc {
+struct Cfg {
+    static constexpr int ACT = rc::ACT_RELU;
+    static __device__ __forceinline__ float act(float x) { return fmaxf(x, 0.f); }
+    static constexpr int G = 8;                        // items per workgroup
+    static constexpr int NW = 8;                       // waves per workgroup
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int L0 = 36, L1 = 18;             // rows per item at 64 / 128 channels
+    static constexpr int NSREG = 3 * (L1 * G / 48);    // shortcut tiles a wave keeps in registers (triple order)
+    static constexpr int BUF_FLOATS = rc::cmax((L0 * G + 2) * 64, (L1 * G + 2) * 128);
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4 + 64;
+    // packed weight block (floats): per conv [COUT/16][KT][CIN/16][64 lanes][4] (+ bias[COUT]); the F(3,3) convs
+    // [COUT/16][CIN/16][5][64 lanes][4] (+ bias)
+    static constexpr int W11 = 4 * 1 * 4 * 256, WS = 8 * 3 * 4 * 256, WSC = 8 * 1 * 4 * 256, WB = 8 * 8 * 5 * 256;
+    static constexpr int OFF_11 = 0, OFF_S = OFF_11 + W11 + 64, OFF_SC = OFF_S + WS + 128, OFF_B = OFF_SC + WSC + 128;
+    static constexpr int off_conv(int i) { return OFF_B + i * (WB + 128); }    // 0: the strided block's second conv; then the blocks'
+    static constexpr int total(int blocks) { return off_conv(1 + 2 * blocks); }
+};
+}  // namespace cc
+
+int compressor_weight_floats(int blocks) { return cc::Cfg::total(blocks); }
+bool compressor_supports_blocks(int blocks) { return blocks == 2 || blocks == 3; }
+
+template <int NB>
+__global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(CompressorArgs a) {
+    using CF = cc::Cfg;
+    constexpr int G = CF::G, L0 = CF::L0, L1 = CF::L1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const bufA = smem;
+    float* const bufB = smem + CF::BUF_FLOATS;
+    float* const dump = smem + 2 * CF::BUF_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long item0 = (long long)blockIdx.x * G;
+    const int n_here = (int)((a.n_items - item0) < G ? (a.n_items - item0) : G);
+    const float* __restrict__ W = a.w;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 w11[4];
+    load_weights<4>(w11, W + CF::OFF_11, wave % 4, lane);
+    // the items' frames -> bufA as a 64-channel image walked one row per lane (SW_OLD), row 0 = leading zero row
+    {
+        const f32x4* src = (const f32x4*)(a.frames + item0 * (L0 * 64));
+        for (int f = tid; f < G * L0 * 16; f += CF::THREADS) {
+            const int item = f / (L0 * 16);
+            const f32x4 v = item < n_here ? src[f] : zero4;
+            *(f32x4*)(bufA + img_off<64, SW_OLD>(1 + (f >> 4), f & 15)) = v;
+        }
+        // row 0 of both 64-channel images: the padding row of the first item (the 1x1 convolution writes rows >= 1)
+        if (tid < 16) ((f32x4*)bufA)[tid] = zero4;
+        else if (tid < 32) ((f32x4*)bufB)[tid - 16] = zero4;
+    }
+    __syncthreads();
+    f32x4 sreg[CF::NSREG];
+    // 1x1 64 -> 64 + ReLU (4 channel blocks x 2 position groups), written for the stride-2 walk of the next layer (SW_W)
+    conv_layer<CF, 64, 64, 1, 1, 0, L0, L0, L0, L0 * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L0 * G, false, SW_OLD, SW_W>(
+        bufA, bufB, w11, nullptr, W + CF::OFF_11 + CF::W11, sreg, 0u, dump, wave, lane);
+    f32x4 ws[12], wsc[4];
+    load_weights<12>(ws, W + CF::OFF_S, wave, lane);
+    load_weights<4>(wsc, W + CF::OFF_SC, wave, lane);
+    __syncthreads();
+    // bufA becomes the 128-channel image: rows 0 and 18 G + 1 are its zero rows
+    if (tid < 64) ((f32x4*)bufA)[(tid & 31) + (tid >> 5) * (L1 * G + 1) * 32] = zero4;
+    // strided block: k3 s2 64 -> 128 + ReLU (tap 0 of an item's first row reads zero, not the previous item's last row)
+    conv_layer<CF, 64, 128, 3, 2, 1, L0, L1, L1, L1 * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L1 * G, true, SW_W, SW_3>(
+        bufB, bufA, ws, nullptr, W + CF::OFF_S + CF::WS, sreg, 0u, dump, wave, lane);
+    // its 1x1 s2 shortcut, in the row order the F(3,3) epilogue of the block's second conv holds its outputs in
+    conv_layer<CF, 64, 128, 1, 2, 0, L0, L1, L1, CF::NSREG, MODE_TO_REGS, false, GEOM_WTRIPLE, 16, L1 * G, false, SW_W, SW_3>(
+        bufB, nullptr, wsc, nullptr, W + CF::OFF_SC + CF::WSC, sreg, 0u, dump, wave, lane);
+    f32x4 w3[2][5];
+    auto slice = [&](int off) { return W + off + wave * (8 * 5 * 256) + lane * 4; };   // this wave's block, this lane
+#pragma unroll
+    for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(slice(CF::off_conv(0)) + c * 256);
+    __syncthreads();
+    if (tid < 64) ((f32x4*)bufB)[(tid & 31) + (tid >> 5) * (L1 * G + 1) * 32] = zero4;
+    {
+        const int j = lane & 15, q = lane >> 4;                   // the shortcut moves into the output image (see readconv_kernel)
+#pragma unroll
+        for (int t = 0; t < CF::NSREG; ++t)
+            *(f32x4*)(bufB + img_off_triple<128, SW_3>(t / 3, j, (t % 3) + 1, 4 * wave + q)) = sreg[t];
+    }
+    wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L1>(bufA, bufB, w3, slice(CF::off_conv(0)), slice(CF::off_conv(1)),
+                                                        W + CF::off_conv(0) + CF::WB, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        const int off_a = CF::off_conv(1 + 2 * blk), off_b = CF::off_conv(2 + 2 * blk);
+        wino3_layer<CF, 128, MODE_PLAIN, false, L1>(bufB, bufA, w3, slice(off_a), slice(off_b), W + off_a + CF::WB, wave, lane);
+        __syncthreads();
+        if (blk < NB - 1)
+            wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L1>(bufA, bufB, w3, slice(off_b), slice(CF::off_conv(3 + 2 * blk)),
+                                                                W + off_b + CF::WB, wave, lane);
+        else
+            wino3_layer<CF, 128, MODE_RESID_INPLACE, true, L1>(bufA, bufB, w3, slice(off_b), nullptr, W + off_b + CF::WB, wave, lane);
+        __syncthreads();
+    }
+    f32x4* dst = (f32x4*)(a.dst + item0 * (L1 * 128));
+    for (int f = tid; f < n_here * L1 * 32; f += CF::THREADS)
+        dst[f] = *(const f32x4*)(bufB + img_off<128, SW_3>(1 + (f >> 5), f & 31));
+}
+
+hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream) {
+    if (a.n_items <= 0) return hipSuccess;
+    if (!compressor_supports_blocks(a.blocks) || !a.frames || !a.dst || !a.w) return hipErrorInvalidValue;
+    static bool configured_on[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured_on[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)compressor_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cc::Cfg::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)compressor_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, cc::Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured_on[dev] = true;
+    }
+    const unsigned grid = (unsigned)((a.n_items + cc::Cfg::G - 1) / cc::Cfg::G);
+    if (a.blocks == 2) hipLaunchKernelGGL(compressor_kernel<2>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(compressor_kernel<3>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 

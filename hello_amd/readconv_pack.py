@@ -163,3 +163,52 @@ def pack(nodes, folded, cin=None, winograd: bool = False, window: int = 150) -> 
     trunk = 6 * (w32d + 32) + (6144 + 64) + (2048 + 64) + (w64d + 64) + 6 * (w64d + 64)
     assert blob.size == trunk + (384 + 16) + (kt * 256 + 16) + (2 * kt * 256 + 32) + 2 * len(extras) * (w64d + 64), blob.size
     return blob
+
+
+# ------------------------------------------------------------------------------------------------
+# fused allele-level compressor (compressor_kernel in readconv_fused.hip)
+# ------------------------------------------------------------------------------------------------
+COMPRESSOR_BLOCKS = (2, 3)    # identity residual blocks the kernel is instantiated for (architectures/compressor_conv_small.py
+                              # has 2, ExpertAlleleConvolver250FeatureMap.py 3)
+
+
+def compressor_blocks(nodes) -> int:
+    """-1 unless ``nodes`` is the canonical compressor -- Conv 1x1 64->64 + ReLU, the strided residual block 64->128
+    (k3 s2 p1 + ReLU, k3 s1 p1 + ReLU, 1x1 s2 shortcut), then identity residual blocks at 128 channels, no LayerNorm --
+    otherwise the number of identity blocks."""
+    def conv_is(n, cin, cout, k, stride, pad, act):
+        return (isinstance(n, ns.Conv) and (n.cin, n.cout, n.k, n.stride, n.pad, n.dilation, n.groups, n.act) ==
+                (cin, cout, k, stride, pad, 1, 1, act) and n.norm != "ln")
+    if len(nodes) < 3 or not conv_is(nodes[0], 64, 64, 1, 1, 0, "relu"):
+        return -1
+    st = nodes[1]
+    if not (isinstance(st, ns.Residual) and len(st.body) == 2 and len(st.shortcut) == 1 and
+            conv_is(st.body[0], 64, 128, 3, 2, 1, "relu") and conv_is(st.body[1], 128, 128, 3, 1, 1, "relu") and
+            conv_is(st.shortcut[0], 64, 128, 1, 2, 0, "none")):
+        return -1
+    for blk in nodes[2:]:
+        if not (isinstance(blk, ns.Residual) and len(blk.body) == 2 and not blk.shortcut and
+                all(conv_is(c, 128, 128, 3, 1, 1, "relu") for c in blk.body)):
+            return -1
+    return len(nodes) - 2
+
+
+def pack_compressor(nodes, folded) -> np.ndarray:
+    """1x1 conv, strided conv, shortcut in the direct layout of ``_pack_conv``; the strided block's second conv and the
+    identity blocks' convs in the F(3,3) layout of ``_pack_conv_f33``; each followed by its bias (cc::Cfg offsets)."""
+    assert compressor_blocks(nodes) in COMPRESSOR_BLOCKS
+    st = nodes[1]
+    parts = [_pack_conv(*folded[nodes[0].key]), _pack_conv(*folded[st.body[0].key]), _pack_conv(*folded[st.shortcut[0].key]),
+             _pack_conv_f33(*folded[st.body[1].key])]
+    for blk in nodes[2:]:
+        parts += [_pack_conv_f33(*folded[blk.body[0].key]), _pack_conv_f33(*folded[blk.body[1].key])]
+    blob = np.concatenate(parts)
+    n = len(nodes) - 2
+    assert blob.size == (4096 + 64) + (24576 + 128) + (8192 + 128) + (1 + 2 * n) * (81920 + 128), blob.size
+    return blob
+
+
+def compressor_executed_macs(blocks: int) -> float:
+    """MACs the kernel's MFMAs execute per item: direct 1x1 / strided / shortcut convs, F(3,3) (5 contractions per 3
+    positions) for the 1 + 2 blocks k3/s1 convolutions."""
+    return 36 * 64 * 64 + 18 * 128 * 192 + 18 * 128 * 64 + (1 + 2 * blocks) * 6 * 5 * 128 * 128

@@ -92,6 +92,32 @@ def test_read_convolver_frames_match_reference(engines, fused):
     print(f"frames vs reference, fused={fused}: worst |d| / scale = {worst:.2e}")
 
 
+@pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_no_ensemble", "merged_single", "single_tech_hp"])
+def test_fused_compressor_output_matches_oracle(engines, name):
+    """Kernel-level parity of the fused allele-level compressor (one LDS-resident kernel for the 1x1 conv, the strided
+    block with its shortcut and the residual blocks): its [items][18][128] output, read back through the debug capture,
+    against the oracle's compressor output on the same batch (the oracle itself is pinned to the reference's logits and
+    frames on these fixtures) -- items at both ends of a workgroup's image and a partly filled last workgroup included."""
+    from hello_amd import compiler
+    from oracle import moe_oracle as mo
+    spec, state, batch, _ = load_fixture(name)
+    eng = get_engine(engines, name, spec, state, True)
+    assert eng.program.fused_compressor
+    op = next(i for i, o in enumerate(eng.program.ops) if o.kind == compiler.OP_COMPRESSOR_FUSED)
+    eng.capture_op_output(op)
+    eng.forward_batch(batch)
+    got = eng.read_op_output().reshape(-1, 18, 128).transpose(0, 2, 1)
+    eng.capture_op_output(None)
+    oracle = mo.Oracle(spec, state)
+    mo.forward_batch(oracle, batch, chunk_sites=batch.n_sites)
+    want = oracle.last["ca0"]
+    assert got.shape == want.shape
+    if name in ("single_tech_batched", "merged_single"):
+        assert got.shape[0] % 8 != 0                                    # 13 / 9 items: the last workgroup is partly filled
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
+
+
 @pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_full", "hybrid_ensemble2", "hybrid_no_ensemble",
                                   "merged_single", "merged_hybrid", "merged_hybrid_250", "single_tech_addendum",
                                   "hybrid_no_ensemble_addendum", "single_tech_softplus",

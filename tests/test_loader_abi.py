@@ -147,6 +147,32 @@ def test_canonical_models_use_the_fused_trunk_and_small_scratch():
         assert prog.weights.dtype == np.float32 and prog.weights.size % 4 == 0 or True
 
 
+def test_canonical_compressor_is_one_fused_op_with_the_kernels_weight_layout():
+    from hello_amd import readconv_pack as rp
+    spec = ns.build("hybrid_full")
+    state = weights.synth_state(spec, seed=1)
+    assert rp.compressor_blocks(spec.nets["compressor0"]) == 2
+    assert rp.compressor_blocks(ns.build("merged_hybrid_250").nets["alleleConv0"]) == 3      # accepted shape, other row length
+    assert rp.compressor_blocks(ns.build("single_tech_layernorm").nets["compressor0"]) == -1
+    assert rp.compressor_blocks(spec.nets["xattn0"]) == -1
+    blob = rp.pack_compressor(spec.nets["compressor0"], weights.fold(spec, state))
+    assert blob.size == 4160 + 24704 + 8320 + 5 * 82048
+    # the 1x1 block: lane l of channel block cb, input group m holds W[16 cb + (l & 15)][16 m + 4 (l >> 4) + t]
+    w, b = weights.fold(spec, state)[spec.nets["compressor0"][0].key]
+    got = blob[:4096].reshape(4, 1, 4, 64, 4)
+    for cb, m, lane in ((0, 0, 0), (3, 2, 37), (1, 3, 63)):
+        np.testing.assert_array_equal(got[cb, 0, m, lane], w[16 * cb + (lane & 15), 16 * m + 4 * (lane >> 4):16 * m + 4 * (lane >> 4) + 4, 0])
+    np.testing.assert_array_equal(blob[4096:4160], b)
+    prog = compiler.compile_model(spec, state)
+    fused = [o for o in prog.ops if o.kind == compiler.OP_COMPRESSOR_FUSED]
+    assert prog.fused_compressor and len(fused) == 2 and all((o.lin, o.cin, o.lout, o.cout, o.k) == (36, 64, 18, 128, 2) for o in fused)
+    assert all(o.exec_macs_per_row == rp.compressor_executed_macs(2) < o.macs_per_row == 5_160_960 for o in fused)
+    for kw in (dict(winograd=False), dict(fused=False), dict(fused="trunk")):                 # layer by layer otherwise
+        assert not compiler.compile_model(spec, state, **kw).fused_compressor
+    # 250 bp models: rows of 61 positions, not the kernel's geometry
+    assert not compiler.compile_model(ns.build("merged_hybrid_250"), weights.synth_state(ns.build("merged_hybrid_250"), seed=1)).fused_compressor
+
+
 def test_softplus_model_uses_the_fused_kernel_in_winograd_form_only():
     spec = ns.build("single_tech_softplus")
     state = weights.synth_state(spec, seed=1)
