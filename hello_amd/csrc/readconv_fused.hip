@@ -1499,11 +1499,21 @@ __global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(Compres
     load_weights<4>(w11, W + CF::OFF_11, wave % 4, lane);
     // the items' frames -> bufA as a 64-channel image walked one row per lane (SW_OLD), row 0 = leading zero row
     {
+        // ONE round trip to memory: every thread requests its 9 float4 first and stores them afterwards (a load-store loop
+        // would pay the memory latency once per iteration, and no second workgroup of the CU hides it here)
         const f32x4* src = (const f32x4*)(a.frames + item0 * (L0 * 64));
-        for (int f = tid; f < G * L0 * 16; f += CF::THREADS) {
-            const int item = f / (L0 * 16);
-            const f32x4 v = item < n_here ? src[f] : zero4;
-            *(f32x4*)(bufA + img_off<64, SW_OLD>(1 + (f >> 4), f & 15)) = v;
+        constexpr int NLD = G * L0 * 16 / CF::THREADS;
+        static_assert(NLD * CF::THREADS == G * L0 * 16, "the input image divides evenly over the threads");
+        f32x4 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int f = tid + CF::THREADS * k;
+            v[k] = (f / (L0 * 16)) < n_here ? src[f] : zero4;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int f = tid + CF::THREADS * k;
+            *(f32x4*)(bufA + img_off<64, SW_OLD>(1 + (f >> 4), f & 15)) = v[k];
         }
         // row 0 of both 64-channel images: the padding row of the first item (the 1x1 convolution writes rows >= 1)
         if (tid < 16) ((f32x4*)bufA)[tid] = zero4;

@@ -252,6 +252,41 @@ def test_error_paths(engines):
     eng.forward_batch(batch)
 
 
+def test_debug_capture_and_profiling_filter_error_paths(engines):
+    """The diagnostic entry points of the C ABI refuse what they cannot serve and leave the engine usable."""
+    from hello_amd import compiler
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=21)
+    eng = get_engine(engines, "fresh_single_tech", spec, state, True)
+    batch = synth.make_sites(5, seed=6, coverage=12)
+    head = next(i for i, o in enumerate(eng.program.ops) if o.kind == compiler.OP_HEAD)
+    with pytest.raises(RuntimeError, match="HEAD"):
+        eng.capture_op_output(head)
+    with pytest.raises(RuntimeError, match="out of range"):
+        eng.capture_op_output(len(eng.program.ops))
+    eng.capture_op_output(0)
+    with pytest.raises(RuntimeError, match="no forward has run"):
+        eng.read_op_output()
+    eng.forward_batch(batch)
+    frames = eng.read_op_output()
+    assert frames.size == batch.n_alleles * 36 * 64 and np.isfinite(frames).all()
+    eng.capture_op_output(None)
+    # per-op timing restricted to one op kind: the other ops report 0, the filtered one a positive time
+    eng.set_profiling(3, only="readconv_fused")
+    for _ in range(3):
+        eng.forward_batch(batch)
+    rows, n = eng.op_times_ms()
+    assert n == 3 and rows[0][0] == "readconv_fused" and rows[0][2] > 0 and all(r[2] == 0 for r in rows[1:])
+    eng.set_profiling(2)
+    for _ in range(2):
+        eng.forward_batch(batch)
+    rows, n = eng.op_times_ms()
+    assert n == 2 and all(r[2] > 0 for r in rows)
+    eng.set_profiling(0)
+    with pytest.raises(KeyError):
+        eng.set_profiling(1, only="no_such_op")
+
+
 def test_malformed_programs_are_rejected_at_creation():
     """hello_engine_create checks what a forward would otherwise read out of bounds or misinterpret."""
     from hello_amd import compiler
