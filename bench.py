@@ -352,7 +352,7 @@ def main():
         "pcie_h2d_gbs": round(float(np.mean([b.reads0.numel() for b in piece_batches])) / launch_s / 1e9, 3),
     }
 
-    device_resident = latency = small = parity = None
+    device_resident = latency = small = parity = two_engines = None
     if world == 1 and not args.no_secondary:
         stream = torch.cuda.current_stream(dev).cuda_stream
         # ---- device-resident rate: pileups already in HBM, outputs left there (no PCIe in the loop) --------------
@@ -405,6 +405,34 @@ def main():
             del res
         except Exception as exc:
             print(f"device-resident leg failed: {exc!r}", file=sys.stderr)
+
+        # ---- the same host-to-host stream with TWO engines alternating (own scratch and compute stream each): the
+        # second engine's kernels fill the tails of the first one's launches (9th round of the compressor's workgroups,
+        # last round of the read convolver's).  Not the headline: concurrent kernels stretch each other's durations,
+        # which would blur the per-kernel roofline above.
+        two_engines = None
+        try:
+            eng2 = Engine(spec, state, device=dev_index)
+            pipe2 = HostPipeline(engines=[eng, eng2], posteriors=True)
+            done = 0
+            for i in range(6):
+                done += len(pipe2.submit(pinned[i % len(pinned)], tag=i))
+            done += len(pipe2.flush())
+            torch.cuda.synchronize(dev)
+            n_two = 60
+            t1 = time.perf_counter()
+            got = 0
+            for i in range(n_two):
+                got += len(pipe2.submit(pinned[i % len(pinned)], tag=i))
+            got += len(pipe2.flush())
+            torch.cuda.synchronize(dev)
+            dt_two = time.perf_counter() - t1
+            assert got == n_two
+            two_engines = {"value": round(args.sites * n_two / dt_two, 1), "unit": "sites/s", "engines": 2, "launches": n_two,
+                           "sites_per_launch": args.sites, "note": "HostPipeline(engines=[e1, e2]), host to host"}
+            eng2.close()
+        except Exception as exc:
+            print(f"two-engine leg failed: {exc!r}", file=sys.stderr)
 
         # ---- latency: the reference's deployment form is ONE site per call (caller_calling.py:872-891) ------------
         try:
@@ -515,6 +543,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "device_resident": device_resident,
+            "two_engines": two_engines,
             "latency": latency,
             "parity": parity,
             "small_batch": small,

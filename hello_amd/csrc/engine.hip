@@ -110,6 +110,7 @@ struct hello_engine {
     int32_t *roff0 = nullptr, *roff1 = nullptr, *aoff = nullptr, *site_of_allele = nullptr;
     int32_t *allele_of_read0 = nullptr, *allele_of_read1 = nullptr;
     int32_t *group_slot0 = nullptr, *group_slot1 = nullptr, *slot_off0 = nullptr, *slot_off1 = nullptr;
+    hello::ReadConvPlan plan0{1, 0, 0}, plan1{1, 0, 0};      // how the fused read convolver's launches cover the reads
     int64_t* pair_off = nullptr;
 };
 
@@ -392,9 +393,12 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
                                bool two_tech, hipStream_t stream) {
     // reads one workgroup of the fused read convolver walks (per technology: it depends on the batch size)
     const int win = hello::readconv_supports_window(e->desc.window) ? e->desc.window : 150;
-    const int GW0 = hello::readconv_reads_per_group(win) * hello::readconv_groups_per_workgroup(R0, win);
-    const int GW1 = hello::readconv_reads_per_group(win) * hello::readconv_groups_per_workgroup(R1, win);
-    const int64_t n_groups0 = (R0 + GW0 - 1) / GW0, n_groups1 = two_tech ? (R1 + GW1 - 1) / GW1 : 0;
+    const int G = hello::readconv_reads_per_group(win);
+    const hello::ReadConvPlan plan0 = hello::readconv_plan(R0, win);
+    const hello::ReadConvPlan plan1 = two_tech ? hello::readconv_plan(R1, win) : hello::ReadConvPlan{1, 0, 0};
+    const int64_t n_groups0 = plan0.bulk_wgs + plan0.rest_wgs, n_groups1 = plan1.bulk_wgs + plan1.rest_wgs;   // workgroups
+    e->plan0 = plan0;
+    e->plan1 = plan1;
     size_t bytes = 0;
     auto add = [&](size_t count, size_t elem) { bytes += (count * elem + 15) & ~size_t(15); };
     add(A + 1, 4); add(A + 1, 4); add(S + 1, 4); add(A, 4);          // roff0 roff1 aoff site_of_allele
@@ -426,7 +430,7 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
     int64_t* h_poff = carve<int64_t>(hc, S + 1);
 
     auto build_reads = [&](const int32_t* rpa, int64_t R, int32_t* roff, int32_t* aor, int32_t* gslot,
-                           int32_t* soff, int64_t n_groups, int G, const char* which) -> int {
+                           int32_t* soff, const hello::ReadConvPlan& plan, const char* which) -> int {
         int64_t acc = 0;
         for (int32_t a = 0; a < A; ++a) {
             if (rpa[a] <= 0)
@@ -442,35 +446,44 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
         roff[A] = (int32_t)acc;
         if (acc != R)
             return fail(HELLO_ERR_SHAPE, "sum(%s) = %lld != n_reads = %lld", which, (long long)acc, (long long)R);
-        // partial-sum slots of the fused read convolver: one slot per (workgroup, allele) incidence (G = reads
-        // per workgroup), numbered in (workgroup, allele) order == (allele, workgroup) order because both are
-        // monotone in the read index
-        int64_t slot = 0;
-        int32_t a_lo = 0;
-        // slot_off[a] = first slot of allele a; group_slot[g] = first slot of group g
+        // partial-sum slots of the fused read convolver: one slot per (workgroup, allele) incidence, numbered in
+        // (workgroup, allele) order == (allele, workgroup) order because both are monotone in the read index.
+        // Workgroup w of the plan: the bulk workgroups hold groups_per_wg groups of G reads each, the rest (second
+        // launch) one group each.  gslot[w] = first slot of workgroup w; soff[a] = first slot of allele a.
+        const int64_t n_wgs = plan.bulk_wgs + plan.rest_wgs;
+        const int64_t bulk_reads = plan.rest_wgs ? plan.bulk_wgs * plan.groups_per_wg * G : R;
         for (int32_t a = 0; a <= A; ++a) soff[a] = 0;
-        for (int64_t g = 0; g < n_groups; ++g) {
-            gslot[g] = (int32_t)slot;
-            const int64_t r_lo = g * G, r_hi = (r_lo + G < R) ? r_lo + G : R;
+        int64_t slot = 0;
+        for (int64_t w = 0; w < n_wgs; ++w) {
+            int64_t r_lo, r_hi;
+            if (w < plan.bulk_wgs) {
+                r_lo = w * plan.groups_per_wg * G;
+                r_hi = r_lo + (int64_t)plan.groups_per_wg * G;
+                if (r_hi > bulk_reads) r_hi = bulk_reads;
+            } else {
+                r_lo = bulk_reads + (w - plan.bulk_wgs) * G;
+                r_hi = r_lo + G < R ? r_lo + G : R;
+            }
+            if (r_lo >= r_hi) return fail(HELLO_ERR_ARG, "internal: empty workgroup in the read-convolver plan");
+            gslot[w] = (int32_t)slot;
             const int32_t first = aor[r_lo], last = aor[r_hi - 1];
+            for (int32_t a = first; a <= last; ++a) soff[a + 1] += 1;      // counts first, prefix sum below
             slot += (last - first + 1);
-            (void)a_lo;
         }
-        gslot[n_groups] = (int32_t)slot;
-        // an allele's slots: one per group it intersects
+        gslot[n_wgs] = (int32_t)slot;
         int64_t s = 0;
         for (int32_t a = 0; a < A; ++a) {
+            const int32_t count = soff[a + 1];
             soff[a] = (int32_t)s;
-            const int64_t g_first = roff[a] / G, g_last = (roff[a + 1] - 1) / G;
-            s += (g_last - g_first + 1);
+            s += count;
         }
         soff[A] = (int32_t)s;
         if (s != slot) return fail(HELLO_ERR_ARG, "internal: slot accounting mismatch");
         return 0;
     };
-    if (int rc = build_reads(rpa0, R0, h_roff0, h_aor0, h_gs0, h_so0, n_groups0, GW0, "reads_per_allele0")) return rc;
+    if (int rc = build_reads(rpa0, R0, h_roff0, h_aor0, h_gs0, h_so0, plan0, "reads_per_allele0")) return rc;
     if (two_tech) {
-        if (int rc = build_reads(rpa1, R1, h_roff1, h_aor1, h_gs1, h_so1, n_groups1, GW1, "reads_per_allele1")) return rc;
+        if (int rc = build_reads(rpa1, R1, h_roff1, h_aor1, h_gs1, h_so1, plan1, "reads_per_allele1")) return rc;
     } else {
         h_gs1[0] = 0;
     }
@@ -722,12 +735,31 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.n_reads = t1 ? R1 : R0;
                 a.window = d.window;
                 a.softplus = (o.flags & HELLO_FLAG_SOFTPLUS) ? 1 : 0;
-                a.groups_per_wg = hello::readconv_groups_per_workgroup(a.n_reads, d.window);
                 a.extra_blocks = o.k;
                 a.winograd = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
                 if ((size_t)o.w_off + hello::readconv_weight_floats(o.k, a.winograd, d.window) > e->n_weight_floats)
                     return fail(HELLO_ERR_MODEL, "op %d: fused read-convolver weight block truncated", op_index);
-                HIP_TRY(hello::launch_readconv_fused(a, stream));
+                {
+                    // the plan of stage_batch_indices: the bulk in whole rounds of n-group workgroups, then the rest as
+                    // one-group workgroups in a second launch of the same kernel over the remaining reads
+                    const hello::ReadConvPlan& plan = t1 ? e->plan1 : e->plan0;
+                    const int G = hello::readconv_reads_per_group(d.window);
+                    const long long total = a.n_reads;
+                    const long long bulk_reads = plan.rest_wgs ? plan.bulk_wgs * plan.groups_per_wg * G : total;
+                    a.groups_per_wg = plan.groups_per_wg;
+                    a.n_reads = bulk_reads;
+                    HIP_TRY(hello::launch_readconv_fused(a, stream));
+                    if (plan.rest_wgs) {
+                        hello::ReadConvArgs b = a;
+                        if (b.reads) b.reads += bulk_reads * d.window * o.cin;
+                        else b.pooled += bulk_reads * (long long)o.lin * 32;
+                        b.allele_of_read += bulk_reads;
+                        b.slot_of_group += plan.bulk_wgs;
+                        b.groups_per_wg = 1;
+                        b.n_reads = total - bulk_reads;
+                        HIP_TRY(hello::launch_readconv_fused(b, stream));
+                    }
+                }
                 HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,
                                                         (float*)ptr(o.dst), A, hello::readconv_frame_rows(d.window), stream));
                 break;

@@ -82,6 +82,15 @@ bool readconv_supports_window(int window);
 int readconv_reads_per_group(int window);
 int readconv_frame_rows(int window);       // positions per read after the read convolver: 36 | 61
 int readconv_groups_per_workgroup(long long n_reads, int window);
+// How a launch covers its groups of reads: `bulk_wgs` workgroups of `groups_per_wg` groups (whole rounds of the
+// device's resident workgroup slots), then -- in a second launch of the same kernel -- `rest_wgs` workgroups of ONE
+// group for what is left, so the partial last round costs one group's time instead of `groups_per_wg`.
+struct ReadConvPlan {
+    int groups_per_wg;
+    long long bulk_wgs;      // each groups_per_wg groups (the last one possibly fewer when rest_wgs == 0)
+    long long rest_wgs;      // each one group (the last one possibly fewer reads)
+};
+ReadConvPlan readconv_plan(long long n_reads, int window);
 int readconv_weight_floats(int extra_blocks, bool winograd, int window);   // 150 bp + Winograd: residual trunk in F(3,3) form
 bool readconv_supports_extra_blocks(int extra_blocks);
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);

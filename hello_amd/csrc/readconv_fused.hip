@@ -174,6 +174,41 @@ int readconv_groups_per_workgroup(long long n_reads, int window) {
     return best;
 }
 
+// Two launches of the same kernel instead of one: the bulk in whole rounds of the resident workgroup slots, each
+// workgroup walking n groups, and the remainder as one-group workgroups -- the partial last round then costs one
+// group's time whatever n is, so n can be large (fewer partial slots, one prologue per n groups) without a coarse tail.
+// n = the count in 1..8 minimising  rounds x n (x 0.988 for n > 1: the shared prologue) + ceil(rest / slots);
+// largest n on ties.  Batches smaller than one round of n-group workgroups keep the single launch of
+// readconv_groups_per_workgroup.
+ReadConvPlan readconv_plan(long long n_reads, int window) {
+    static const long long slots = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return 2LL * cus;
+    }();
+    const int G = readconv_reads_per_group(window);
+    const long long groups = (n_reads + G - 1) / G;
+    ReadConvPlan best{1, groups, 0};
+    double best_cost = 1e300;
+    for (int n = 1; n <= 8; ++n) {
+        const long long rounds = (groups / n) / slots;              // whole rounds of whole n-group workgroups
+        if (rounds == 0) continue;
+        const long long bulk = rounds * slots, rest = groups - bulk * n;
+        const double cost = (double)rounds * n * (n > 1 ? 0.988 : 1.0) + (double)((rest + slots - 1) / slots);
+        if (cost <= best_cost) {
+            best_cost = cost;
+            best = ReadConvPlan{n, bulk, rest};
+        }
+    }
+    if (best_cost == 1e300) {                                        // less than one round: the single-launch rule
+        const int n = readconv_groups_per_workgroup(n_reads, window);
+        best = ReadConvPlan{n, (groups + n - 1) / n, 0};
+    }
+    return best;
+}
+
 // chunk swizzles: 16-byte chunk index of a row XORed with a function of the row
 template <int C>
 __device__ __forceinline__ int swz(int row) {
@@ -1551,18 +1586,18 @@ __global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(Compres
     wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L1>(bufA, bufB, w3, slice(CF::off_conv(0)), slice(CF::off_conv(1)),
                                                         W + CF::off_conv(0) + CF::WB, wave, lane);
     __syncthreads();
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-        const int off_a = CF::off_conv(1 + 2 * blk), off_b = CF::off_conv(2 + 2 * blk);
+    static_for<0, NB>([&](auto bc) {
+        constexpr int blk = decltype(bc)::value;
+        constexpr int off_a = CF::off_conv(1 + 2 * blk), off_b = CF::off_conv(2 + 2 * blk);
         wino3_layer<CF, 128, MODE_PLAIN, false, L1>(bufB, bufA, w3, slice(off_a), slice(off_b), W + off_a + CF::WB, wave, lane);
         __syncthreads();
-        if (blk < NB - 1)
+        if constexpr (blk < NB - 1)
             wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L1>(bufA, bufB, w3, slice(off_b), slice(CF::off_conv(3 + 2 * blk)),
                                                                 W + off_b + CF::WB, wave, lane);
         else
             wino3_layer<CF, 128, MODE_RESID_INPLACE, true, L1>(bufA, bufB, w3, slice(off_b), nullptr, W + off_b + CF::WB, wave, lane);
         __syncthreads();
-    }
+    });
     f32x4* dst = (f32x4*)(a.dst + item0 * (L1 * 128));
     for (int f = tid; f < n_here * L1 * 32; f += CF::THREADS)
         dst[f] = *(const f32x4*)(bufB + img_off<128, SW_3>(1 + (f >> 5), f & 31));
