@@ -87,3 +87,38 @@ def test_shard_sizes_and_rank_cpus():
         seen += cpus
     if len(allowed) >= 4:
         assert len(set(seen)) == len(seen)          # ranks do not share CPUs when there are enough
+
+
+def test_bench_rank_pieces_cover_the_global_stream_exactly():
+    """bench.py's multi-rank plan: the global step batch (launches cycling the pool) cut by partition_sites into one
+    contiguous range per rank, handed out as (pool batch, site lo, site hi) pieces: every site of the stream exactly
+    once, in order, and the sizes every rank computes locally add up."""
+    sys.path.insert(0, ROOT)
+    import bench
+    pool = [synth.make_sites(n, seed=70 + i, coverage=12) for i, n in enumerate((90, 75, 110))]
+    counts = [dict(reads_per_site=shard.reads_per_site(b), alleles_per_site=b.alleles_per_site) for b in pool]
+    for world in (1, 2, 3, 8):
+        launches = 4 * world
+        seq = [i % 3 for i in range(launches)]
+        total_sites = sum(pool[k].n_sites for k in seq)
+        covered, sizes0 = [], None
+        for rank in range(world):
+            pieces, sizes = bench.rank_pieces(counts, launches, rank, world)
+            sizes0 = sizes0 or sizes
+            assert sizes == sizes0                                   # the same plan on every rank
+            assert sum(hi - lo for _, lo, hi in pieces) == sizes[rank][0]
+            assert sum(int(pool[k].alleles_per_site[lo:hi].sum()) for k, lo, hi in pieces) == sizes[rank][1]
+            covered += pieces
+        # concatenating the ranks' pieces walks the launch sequence front to back without gaps or overlaps
+        pos, it = 0, iter(seq)
+        k_cur, at = next(it), 0
+        for k, lo, hi in covered:
+            if at == pool[k_cur].n_sites:
+                k_cur, at = next(it), 0
+            assert k == k_cur and lo == at
+            at = hi
+            pos += hi - lo
+        assert pos == total_sites == sum(s for s, _ in sizes0)
+        reads = [sum(int(counts[k]["reads_per_site"][lo:hi].sum()) for k, lo, hi in bench.rank_pieces(counts, launches, r, world)[0])
+                 for r in range(world)]
+        assert max(reads) - min(reads) <= 2 * max(int(c["reads_per_site"].max()) for c in counts)     # balanced by reads
