@@ -344,7 +344,11 @@ def main():
         "formulas": {"frac": "2 * executed MAC per read * reads per launch / launch_ms / 157.3 TFLOP/s",
                      "algorithmic_frac": "2 * 5 076 096 MAC per read * reads per launch / launch_ms / 157.3 TFLOP/s "
                                          "(exceeds 1 because Winograd executes fewer MFMA FLOPs than the direct form)"},
-        "launch_ms": round(dom_ms, 4), "launches_timed": int(n_fw), "reads_per_launch": round(reads_per_launch, 1),
+        # `launch` = one forward's run of the dominant kernel: since round 2 that is TWO launches of readconv_kernel (whole
+        # rounds of 8-group workgroups, then one-group workgroups: readconv_plan) followed by its small finalize kernel;
+        # launch_ms is the device time from the first launch's start to the finalize's end (two HIP events)
+        "launch_ms": round(dom_ms, 4), "launches_timed": int(n_fw), "kernel_launches_per_forward": 2 if dom_op.kind == 8 else 1,
+        "reads_per_launch": round(reads_per_launch, 1),
         "flop_per_launch": float(dom_flops), "executed_flop_per_launch": float(dom_exec),
         "arithmetic": "fp32; k3/s1 convolutions in Winograd form (residual trunk and allele stage F(3,3), stem F(2,3))" if eng.program.winograd else "fp32, direct form",
         "whole_launch_algorithmic_frac": round(flops_launch / launch_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),

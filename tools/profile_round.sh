@@ -9,6 +9,7 @@ TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
+rm -rf $OUT $SUM
 mkdir -p $OUT $SUM
 export TMPDIR=/tmp
 # 1. kernel statistics of the command the driver runs, with the secondary legs (latency, 256-site launches, ...)

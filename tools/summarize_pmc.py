@@ -23,7 +23,7 @@ def summarise(path):
     for k, counters in acc.items():
         if not k.startswith(("readconv", "conv1d", "segsum", "mix", "head", "posteriors")):
             continue
-        out[k] = {c: {"mean": sum(v) / len(v), "dispatches": len(v)} for c, v in counters.items()}
+        out[k] = {c: {"mean": sum(v) / len(v), "sum": sum(v), "dispatches": len(v)} for c, v in counters.items()}
     return out
 
 
@@ -31,12 +31,18 @@ def main():
     if sys.argv[1] == "--traffic":
         d = sys.argv[2]
         load = lambda name: json.load(open(os.path.join(d, next(f for f in os.listdir(d) if f.endswith(f"pmc_{name}.txt")))))   # noqa: E731
-        fetch = load("FETCH_SIZE")["readconv_kernel"]["FETCH_SIZE"]["mean"]
-        write = load("WRITE_SIZE")["readconv_kernel"]["WRITE_SIZE"]["mean"]
+        # readconv_kernel is launched twice per forward (bulk + remainder, readconv_plan): per-forward figures are the
+        # kernel's SUM over the pass divided by the number of forwards (= dispatches of its finalize kernel)
+        def per_forward(name, counter):
+            t = load(name)
+            return t["readconv_kernel"][counter]["sum"] / t["readconv_finalize_kernel"][counter]["dispatches"]
+        fetch = per_forward("FETCH_SIZE", "FETCH_SIZE")
+        write = per_forward("WRITE_SIZE", "WRITE_SIZE")
         sq = load("SQ_VALU_MFMA_BUSY_CYCLES")["readconv_kernel"]
-        g = lambda c: sq[c]["mean"]                                                                                               # noqa: E731
+        g = lambda c: sq[c]["sum"]                                                                                                # noqa: E731
         print(json.dumps({
-            "kernel": "hello::readconv_kernel (bench.py headline loop, 8 192 sites / 246 k reads per launch)",
+            "kernel": "hello::readconv_kernel (bench.py headline loop, 8 192 sites / 246 k reads per forward; two launches per "
+                      "forward: 7 680 workgroups of 8 groups, then 60 of one group)",
             "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
             "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 on gfx950 (FETCH_SIZE tallies 128-B requests at 64 B); separate --pmc passes",
             "bytes_per_launch": (2 * fetch + write) * 1024,
