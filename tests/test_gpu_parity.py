@@ -155,6 +155,26 @@ def test_fresh_batches_match_oracle(engines, cfg, kw):
     np.testing.assert_allclose(logits, want, **LOGIT_TOL)
 
 
+def test_two_launch_plan_matches_oracle_on_every_allele(engines):
+    """A batch large enough for the fused read convolver's two-launch plan (whole rounds of 8-group workgroups, then
+    one-group workgroups over the remaining reads): 700 sites = 21 k reads -> 512 workgroups x 8 groups + ~1 150 of one
+    group, with an allele's reads straddling the seam between the two launches.  EVERY allele against the oracle."""
+    from oracle import moe_oracle as mo
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=21)
+    batch = synth.make_sites(700, seed=17, coverage=30)
+    assert batch.reads0.shape[0] // 4 >= 512 * 8                       # enough groups for one whole round of 8-group workgroups
+    seam = 512 * 8 * 4                                                # first read of the second launch
+    roff = np.concatenate([[0], np.cumsum(batch.reads_per_allele0)])
+    a = int(np.searchsorted(roff, seam, side="right") - 1)
+    assert roff[a] < seam < roff[a + 1]                               # the seam falls inside allele a
+    eng = get_engine(engines, "fresh_single_tech", spec, state, True)
+    logits, _ = eng.forward_batch(batch)
+    want, _ = mo.forward_batch(mo.Oracle(spec, state, backend="torch"), batch, chunk_sites=50)
+    np.testing.assert_allclose(logits, want, **LOGIT_TOL)
+    assert abs(logits[0, a] - want[0, a]) < 2e-4
+
+
 def test_device_pointers_and_determinism(engines):
     import torch
     spec = ns.build("single_tech")
