@@ -111,6 +111,7 @@ struct hello_engine {
     int32_t *allele_of_read0 = nullptr, *allele_of_read1 = nullptr;
     int32_t *group_slot0 = nullptr, *group_slot1 = nullptr, *slot_off0 = nullptr, *slot_off1 = nullptr;
     hello::ReadConvPlan plan0{1, 0, 0}, plan1{1, 0, 0};      // how the fused read convolver's launches cover the reads
+    bool wide_trunk[2] = {false, false};                      // technology t's fused op is the 2x-channel trunk kernel
     int64_t* pair_off = nullptr;
 };
 
@@ -181,7 +182,12 @@ int validate_model(const hello_model_desc* d) {
         if (o.kind == HELLO_OP_READCONV_FUSED) {
             if (!hello::readconv_supports_window(d->window))
                 return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver takes 150 or 250 bp windows, not %d", i, d->window);
-            if (o.lout != hello::readconv_frame_rows(d->window) || o.cout != 64)
+            const bool wide = o.cout == 128;       // the 2x-channel trunk: pooled [71][64] rows in, [36][128] frames out
+            if (wide && !(d->window == 150 && o.cin == 64 && o.lin == 71 && o.lout == 36 && o.k == 0 &&
+                          (o.flags & HELLO_FLAG_WINOGRAD) && !(o.flags & (HELLO_FLAG_SRC_U8 | HELLO_FLAG_SOFTPLUS))))
+                return fail(HELLO_ERR_MODEL, "op %d: the wide read-convolver trunk maps pooled [71][64] rows to [36][128] frames "
+                                             "(150 bp, Winograd form, ReLU, no extra blocks)", i);
+            if (!wide && (o.lout != hello::readconv_frame_rows(d->window) || o.cout != 64))
                 return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver yields [%d][64] frames", i,
                             hello::readconv_frame_rows(d->window));
             if ((o.flags & HELLO_FLAG_SOFTPLUS) &&
@@ -257,8 +263,10 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
             w_end = (size_t)o.w_off + hello::compressor_weight_floats(o.k);
             b_end = (size_t)o.b_off;
         } else if (o.kind == HELLO_OP_READCONV_FUSED) {
-            w_end = (size_t)o.w_off + hello::readconv_weight_floats(o.k, (o.flags & HELLO_FLAG_WINOGRAD) != 0, desc->window);
+            w_end = (size_t)o.w_off + (o.cout == 128 ? hello::readconv_wide_weight_floats()
+                                                     : hello::readconv_weight_floats(o.k, (o.flags & HELLO_FLAG_WINOGRAD) != 0, desc->window));
             b_end = (size_t)o.b_off;
+            if (o.cout == 128) e->wide_trunk[o.seg == HELLO_SEG_READS1_TO_ALLELES ? 1 : 0] = true;
         }
         if (w_end > e->n_weight_floats || b_end > e->n_weight_floats) {
             delete e;
@@ -394,8 +402,11 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
     // reads one workgroup of the fused read convolver walks (per technology: it depends on the batch size)
     const int win = hello::readconv_supports_window(e->desc.window) ? e->desc.window : 150;
     const int G = hello::readconv_reads_per_group(win);
-    const hello::ReadConvPlan plan0 = hello::readconv_plan(R0, win);
-    const hello::ReadConvPlan plan1 = two_tech ? hello::readconv_plan(R1, win) : hello::ReadConvPlan{1, 0, 0};
+    if ((e->wide_trunk[0] || e->wide_trunk[1]) && hello::readconv_wide_reads_per_group() != G)
+        return fail(HELLO_ERR_ARG, "internal: the wide trunk's group size differs from the read convolver's");
+    const hello::ReadConvPlan plan0 = e->wide_trunk[0] ? hello::readconv_wide_plan(R0) : hello::readconv_plan(R0, win);
+    const hello::ReadConvPlan plan1 = !two_tech ? hello::ReadConvPlan{1, 0, 0}
+                                      : e->wide_trunk[1] ? hello::readconv_wide_plan(R1) : hello::readconv_plan(R1, win);
     const int64_t n_groups0 = plan0.bulk_wgs + plan0.rest_wgs, n_groups1 = plan1.bulk_wgs + plan1.rest_wgs;   // workgroups
     e->plan0 = plan0;
     e->plan1 = plan1;
@@ -610,7 +621,8 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
         const int G = hello::readconv_reads_per_group(d.window);
         const int64_t Rmax = R0 > R1 ? R0 : R1;
         const size_t slots = (size_t)A + (size_t)((Rmax + G - 1) / G) + 1;
-        if (int rc = ensure(e->d_partial, slots * hello::readconv_frame_rows(d.window) * 64 * sizeof(float))) return rc;
+        const size_t frame_ch = (e->wide_trunk[0] || e->wide_trunk[1]) ? 128 : 64;
+        if (int rc = ensure(e->d_partial, slots * hello::readconv_frame_rows(d.window) * frame_ch * sizeof(float))) return rc;
     }
     // experts without a head (ensemble of two: third expert is all-zero logits, :244) stay zero
     if (d.n_experts == 3) HIP_TRY(hipMemsetAsync(d_logits, 0, logit_bytes, stream));
@@ -737,7 +749,9 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.softplus = (o.flags & HELLO_FLAG_SOFTPLUS) ? 1 : 0;
                 a.extra_blocks = o.k;
                 a.winograd = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
-                if ((size_t)o.w_off + hello::readconv_weight_floats(o.k, a.winograd, d.window) > e->n_weight_floats)
+                const bool wide = o.cout == 128;
+                if ((size_t)o.w_off + (wide ? hello::readconv_wide_weight_floats() : hello::readconv_weight_floats(o.k, a.winograd, d.window)) >
+                    e->n_weight_floats)
                     return fail(HELLO_ERR_MODEL, "op %d: fused read-convolver weight block truncated", op_index);
                 {
                     // the plan of stage_batch_indices: the bulk in whole rounds of n-group workgroups, then the rest as
@@ -748,20 +762,20 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                     const long long bulk_reads = plan.rest_wgs ? plan.bulk_wgs * plan.groups_per_wg * G : total;
                     a.groups_per_wg = plan.groups_per_wg;
                     a.n_reads = bulk_reads;
-                    HIP_TRY(hello::launch_readconv_fused(a, stream));
+                    HIP_TRY(wide ? hello::launch_readconv_wide(a, stream) : hello::launch_readconv_fused(a, stream));
                     if (plan.rest_wgs) {
                         hello::ReadConvArgs b = a;
                         if (b.reads) b.reads += bulk_reads * d.window * o.cin;
-                        else b.pooled += bulk_reads * (long long)o.lin * 32;
+                        else b.pooled += bulk_reads * (long long)o.lin * o.cin;
                         b.allele_of_read += bulk_reads;
                         b.slot_of_group += plan.bulk_wgs;
                         b.groups_per_wg = 1;
                         b.n_reads = total - bulk_reads;
-                        HIP_TRY(hello::launch_readconv_fused(b, stream));
+                        HIP_TRY(wide ? hello::launch_readconv_wide(b, stream) : hello::launch_readconv_fused(b, stream));
                     }
                 }
                 HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,
-                                                        (float*)ptr(o.dst), A, hello::readconv_frame_rows(d.window), stream));
+                                                        (float*)ptr(o.dst), A, o.lout, o.cout, stream));
                 break;
             }
         }

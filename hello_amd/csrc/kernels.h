@@ -91,12 +91,20 @@ struct ReadConvPlan {
     long long rest_wgs;      // each one group (the last one possibly fewer reads)
 };
 ReadConvPlan readconv_plan(long long n_reads, int window);
+ReadConvPlan readconv_wide_plan(long long n_reads);   // every workgroup one group, one launch
 int readconv_weight_floats(int extra_blocks, bool winograd, int window);   // 150 bp + Winograd: residual trunk in F(3,3) form
 bool readconv_supports_extra_blocks(int extra_blocks);
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
 // frames[a] = sum of the partial slots of allele a, in slot order
+// frames[a] = sum of allele a's partial slots; `channels` per position (64; 128 for the wide trunk)
 hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames, int n_alleles,
-                                    int frame_rows, hipStream_t stream);
+                                    int frame_rows, int channels, hipStream_t stream);
+// Residual trunk of the 2x-channel read convolver (read_convolver_wide.py after its max pool) + segment sum:
+// `pooled` = [R][71][64] rows of a layer-by-layer stem, partial slots [36][128]; one group of
+// readconv_wide_reads_per_group() reads per workgroup (groups_per_wg must be 1), Winograd form only.
+int readconv_wide_weight_floats();
+int readconv_wide_reads_per_group();
+hipError_t launch_readconv_wide(const ReadConvArgs& a, hipStream_t stream);
 
 // ---- fused allele-level compressor (readconv_fused.hip) ---------------------------------------------------
 // architectures/compressor_conv_small.py (and ExpertAlleleConvolver*.py): 1x1 64->64, strided block 64->128 with

@@ -1460,7 +1460,7 @@ hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
 
 // frames[a] = sum over the allele's partial slots, in slot (= read) order
 __global__ void readconv_finalize_kernel(const float* __restrict__ partial, const int32_t* __restrict__ slot_off,
-                                         float* __restrict__ frames, int frame_f4) {      // frame_f4 = positions * 16
+                                         float* __restrict__ frames, int frame_f4) {      // frame_f4 = positions * channels / 4
     const int al = blockIdx.x;
     const int lo = slot_off[al], hi = slot_off[al + 1];
     for (int f = threadIdx.x; f < frame_f4; f += blockDim.x) {
@@ -1475,10 +1475,11 @@ __global__ void readconv_finalize_kernel(const float* __restrict__ partial, cons
 }
 
 hipError_t launch_readconv_finalize(const float* partial, const int32_t* slot_off, float* frames, int n_alleles,
-                                    int frame_rows, hipStream_t stream) {
+                                    int frame_rows, int channels, hipStream_t stream) {
     if (n_alleles <= 0) return hipSuccess;
+    if (channels <= 0 || (channels % 4)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(readconv_finalize_kernel, dim3(n_alleles), dim3(192), 0, stream, partial, slot_off, frames,
-                       frame_rows * 16);
+                       frame_rows * (channels / 4));
     return hipGetLastError();
 }
 
@@ -1619,6 +1620,225 @@ hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream) 
     const unsigned grid = (unsigned)((a.n_items + cc::Cfg::G - 1) / cc::Cfg::G);
     if (a.blocks == 2) hipLaunchKernelGGL(compressor_kernel<2>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
     else hipLaunchKernelGGL(compressor_kernel<3>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+
+// =====================================================================================================================
+// Residual trunk of the 2x-channel ("_wide") read convolver (architectures/read_convolver_wide.py: the layers after the
+// max pool) + reads->alleles segment sum:
+//     [71][64] per read -> 3 x ResidualBlock(64) -> strided block 64->128 (k3 s2 + ReLU, k3 s1 + ReLU, + 1x1 s2 shortcut)
+//     -> 3 x ResidualBlock(128) -> [36][128] per read -> per-allele partial sums
+// 18.8 M of the wide read convolver's 20.2 M MAC per read; its stem (6|7 -> 32 -> 32 -> 64 + max pool) runs layer by layer
+// ahead of this kernel and hands over the pooled rows.  The images are the compressor kernel's: one workgroup of 8 waves
+// carries 4 reads with two 74.75 KB images in LDS (one workgroup per CU, two waves per SIMD).  The 64-channel image is
+// the read convolver's 32-channel geometry at twice the channels (reads stacked with ONE shared zero row, row stride 72:
+// 288 rows = 6 tiles of 16 triples, 4 channel blocks x 2 position groups of waves), the 128-channel image the compact
+// one (4 x 36 = 144 rows = 3 tiles of 16 triples, 8 channel blocks); every k3/s1 convolution runs in Winograd F(3,3)
+// form.  The F(3,3) layers walk their images three rows per lane (SW_3) and the stride-2 convolutions two (SW_W), whose
+// tiles are 32 rows apart -- not a period of SW_3 -- so the strided block reads a re-swizzled copy of its input.
+namespace wt {
+struct Cfg {
+    static constexpr int ACT = rc::ACT_RELU;
+    static __device__ __forceinline__ float act(float x) { return fmaxf(x, 0.f); }
+    static constexpr int G = 4;                        // reads per workgroup
+    static constexpr int NW = 8;                       // waves per workgroup
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int L1 = 71, RS1 = 72;            // positions / row stride per read at 64 channels
+    static constexpr int L2 = 36;                      // positions per read at 128 channels (compact)
+    static constexpr int NSREG = 3 * (L2 * G / 48);    // shortcut tiles a wave keeps in registers (triple order)
+    // the last triple of the 64-channel image reads rows up to RS1 G + 1 (its fifth input feeds the zero row's output only)
+    static constexpr int BUF_FLOATS = rc::cmax((RS1 * G + 2) * 64, (L2 * G + 2) * 128);
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4 + 64;
+    // packed weight block (floats): the F(3,3) convs [COUT/16][CIN/16][5][64 lanes][4] + bias[COUT]; the strided conv and
+    // its shortcut [COUT/16][KT][CIN/16][64 lanes][4] + bias
+    static constexpr int WA = 4 * 4 * 5 * 256, WS = 8 * 3 * 4 * 256, WSC = 8 * 1 * 4 * 256, WB = 8 * 8 * 5 * 256;
+    static constexpr int off_a(int i) { return i * (WA + 64); }               // 6 convs 64 -> 64
+    static constexpr int OFF_S = 6 * (WA + 64), OFF_SC = OFF_S + WS + 128, OFF_B = OFF_SC + WSC + 128;
+    static constexpr int off_b(int i) { return OFF_B + i * (WB + 128); }      // 0: the strided block's second conv; then 6 convs 128 -> 128
+    static constexpr int W_TOTAL = OFF_B + 7 * (WB + 128);
+};
+}  // namespace wt
+
+int readconv_wide_weight_floats() { return wt::Cfg::W_TOTAL; }
+int readconv_wide_reads_per_group() { return wt::Cfg::G; }
+ReadConvPlan readconv_wide_plan(long long n_reads) {
+    return ReadConvPlan{1, (n_reads + wt::Cfg::G - 1) / wt::Cfg::G, 0};
+}
+
+__global__ __launch_bounds__(wt::Cfg::THREADS, 2) void readconv_wide_trunk_kernel(ReadConvArgs a) {
+    using CF = wt::Cfg;
+    constexpr int G = CF::G, L1 = CF::L1, RS1 = CF::RS1, L2 = CF::L2, THREADS = CF::THREADS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const X = smem;
+    float* const H = smem + CF::BUF_FLOATS;
+    int* const s_allele = (int*)(smem + 2 * CF::BUF_FLOATS);                 // G ints
+    float* const dump = smem + 2 * CF::BUF_FLOATS + 12;                       // 16 spare bytes of the same 64-byte block
+    const int tid0 = threadIdx.x;
+    const int wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const float* __restrict__ W = a.w;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // one group of G reads per workgroup (no sum carried across groups: the registers are the 128-channel layers'),
+    // one partial slot per (group, allele) incidence
+    const int tid = tid0, wave = wave0, lane = tid0 & 63;
+    const int cb4 = wave % 4;
+    const long long read0 = (long long)blockIdx.x * G;
+    const int n_here = (int)((a.n_reads - read0) < G ? (a.n_reads - read0) : G);
+    f32x4 w3[2][5];
+    auto slice64 = [&](int off) { return W + off + cb4 * (4 * 5 * 256) + lane * 4; };      // this wave's block, this lane
+    auto slice128 = [&](int off) { return W + off + wave * (8 * 5 * 256) + lane * 4; };
+#pragma unroll
+    for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(slice64(CF::off_a(0)) + c * 256);
+    if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
+    {
+        // the group's pooled rows in ONE round trip: every thread requests its float4 first and stores them afterwards
+        const f32x4* src = (const f32x4*)(a.pooled + read0 * (long long)(L1 * 64));
+        constexpr int NLD = (G * L1 * 16 + THREADS - 1) / THREADS;
+        const int n4 = n_here * L1 * 16;
+        f32x4 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int f = tid + THREADS * k;
+            v[k] = f < n4 ? src[f] : zero4;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int f = tid + THREADS * k;
+            if (f < G * L1 * 16) {
+                const int rd = f / (L1 * 16), rem = f - rd * (L1 * 16);
+                *(f32x4*)(X + img_off<64, SW_3>(1 + rd * RS1 + (rem >> 4), rem & 15)) = v[k];
+            }
+        }
+        // the shared zero rows 0, 72, ..., 288 of X; row 0 of H (the layers store H's other zero rows themselves)
+        if (tid < 16 * (G + 1)) *(f32x4*)(X + img_off<64, SW_3>((tid >> 4) * RS1, tid & 15)) = zero4;
+        else if (tid < 16 * (G + 2)) ((f32x4*)H)[tid - 16 * (G + 1)] = zero4;
+    }
+    __syncthreads();
+
+    // ---- 3 x ResidualBlock(64) ----------------------------------------------------------------------
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+        const int off_a = CF::off_a(2 * blk), off_b = CF::off_a(2 * blk + 1);
+        wino3_layer<CF, 64, MODE_PLAIN, false, RS1, SW_3, false>(X, H, w3, slice64(off_a), slice64(off_b), W + off_a + CF::WA, wave, lane);
+        __syncthreads();
+        if (blk < 2)
+            wino3_layer<CF, 64, MODE_RESID_INPLACE, false, RS1, SW_3, false>(H, X, w3, slice64(off_b), slice64(CF::off_a(2 * blk + 2)),
+                                                                             W + off_b + CF::WA, wave, lane);
+        else
+            wino3_layer<CF, 64, MODE_RESID_INPLACE, true, RS1, SW_3, false>(H, X, w3, slice64(off_b), nullptr, W + off_b + CF::WA, wave, lane);
+        __syncthreads();
+    }
+
+    // ---- strided block 64 -> 128 -----------------------------------------------------------------------
+    f32x4 ws[12], wsc[4];
+    load_weights<12>(ws, W + CF::OFF_S, wave, lane);
+    load_weights<4>(wsc, W + CF::OFF_SC, wave, lane);
+    // X (walked three rows per lane so far) -> H in the two-rows-per-lane swizzle the stride-2 convolutions walk
+    {
+        constexpr int NCP = ((RS1 * G + 1) * 16 + THREADS - 1) / THREADS;
+#pragma unroll
+        for (int k = 0; k < NCP; ++k) {
+            const int f = tid + THREADS * k;
+            if (f < (RS1 * G + 1) * 16)
+                *(f32x4*)(H + img_off<64, SW_W>(f >> 4, f & 15)) = *(const f32x4*)(X + img_off<64, SW_3>(f >> 4, f & 15));
+        }
+    }
+    __syncthreads();
+    f32x4 sreg[CF::NSREG];
+    // X becomes the 128-channel image: rows 0 and 36 G + 1 are its zero rows
+    if (tid < 64) ((f32x4*)X)[(tid & 31) + (tid >> 5) * (L2 * G + 1) * 32] = zero4;
+    conv_layer<CF, 64, 128, 3, 2, 1, RS1, L2, L2, L2 * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L2 * G, false, SW_W, SW_3>(
+        H, X, ws, nullptr, W + CF::OFF_S + CF::WS, sreg, 0u, dump, wave, lane);
+    // the 1x1 s2 shortcut, in the row order the F(3,3) epilogue of the block's second conv holds its outputs in
+    conv_layer<CF, 64, 128, 1, 2, 0, RS1, L2, L2, CF::NSREG, MODE_TO_REGS, false, GEOM_WTRIPLE, 16, L2 * G, false, SW_W, SW_3>(
+        H, nullptr, wsc, nullptr, W + CF::OFF_SC + CF::WSC, sreg, 0u, dump, wave, lane);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(slice128(CF::off_b(0)) + c * 256);
+    __syncthreads();
+    if (tid < 64) ((f32x4*)H)[(tid & 31) + (tid >> 5) * (L2 * G + 1) * 32] = zero4;
+    {
+        const int j = lane & 15, q = lane >> 4;               // the shortcut moves into the output image (see readconv_kernel)
+#pragma unroll
+        for (int t = 0; t < CF::NSREG; ++t)
+            *(f32x4*)(H + img_off_triple<128, SW_3>(t / 3, j, (t % 3) + 1, 4 * wave + q)) = sreg[t];
+    }
+    wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L2>(X, H, w3, slice128(CF::off_b(0)), slice128(CF::off_b(1)),
+                                                        W + CF::off_b(0) + CF::WB, wave, lane);
+    __syncthreads();
+
+    // ---- 3 x ResidualBlock(128) ----------------------------------------------------------------------
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+        // an opaque zero ties the per-lane addresses to the block: recomputed per block instead of kept (spilled) across blocks
+        int oz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+        const int lane_b = lane + oz, wave_b = __builtin_amdgcn_readfirstlane(wave + oz);
+        auto slice = [&](int off) { return W + off + wave_b * (8 * 5 * 256) + lane_b * 4; };
+        const int off_a = CF::off_b(1 + 2 * blk), off_b = CF::off_b(2 + 2 * blk);
+        wino3_layer<CF, 128, MODE_PLAIN, false, L2>(H, X, w3, slice(off_a), slice(off_b), W + off_a + CF::WB, wave_b, lane_b);
+        __syncthreads();
+        if (blk < 2)
+            wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L2>(X, H, w3, slice(off_b), slice(CF::off_b(3 + 2 * blk)),
+                                                                W + off_b + CF::WB, wave_b, lane_b);
+        else
+            wino3_layer<CF, 128, MODE_RESID_INPLACE, true, L2>(X, H, w3, slice(off_b), nullptr, W + off_b + CF::WB, wave_b, lane_b);
+        __syncthreads();
+    }
+
+    // ---- the group's reads, summed per allele in read order; a slot per allele of the group ------------
+    const int slot0 = a.slot_of_group[blockIdx.x];
+    const int first_allele = s_allele[0];
+    int cur = first_allele;
+    constexpr int NF = (L2 * 32 + THREADS - 1) / THREADS;     // float4 elements of a [36][128] frame per thread
+    f32x4 carry[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) carry[i] = zero4;
+    auto flush = [&]() {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = tid + THREADS * i;
+            if (f < L2 * 32)
+                *(f32x4*)(a.partial + ((long long)(slot0 + cur - first_allele) * L2 + (f >> 5)) * 128 + 4 * (f & 31)) = carry[i];
+            carry[i] = zero4;
+        }
+    };
+    for (int rd = 0; rd < n_here; ++rd) {
+        const int al = s_allele[rd];
+        if (al != cur) {                                      // uniform
+            flush();
+            cur = al;
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = tid + THREADS * i;
+            if (f < L2 * 32) {
+                const f32x4 v = *(const f32x4*)(H + img_off<128, SW_3>(1 + rd * L2 + (f >> 5), f & 31));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) carry[i][e] += v[e];
+            }
+        }
+    }
+    flush();
+}
+
+hipError_t launch_readconv_wide(const ReadConvArgs& a, hipStream_t stream) {
+    if (a.n_reads <= 0) return hipSuccess;
+    if (!a.pooled || a.reads || !a.w || !a.partial || !a.winograd || a.window != 150 || a.extra_blocks != 0 || a.softplus ||
+        a.groups_per_wg != 1)
+        return hipErrorInvalidValue;
+    static bool configured_on[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured_on[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)readconv_wide_trunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           wt::Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured_on[dev] = true;
+    }
+    const long long per_wg = (long long)wt::Cfg::G * a.groups_per_wg;
+    const unsigned grid = (unsigned)((a.n_reads + per_wg - 1) / per_wg);
+    hipLaunchKernelGGL(readconv_wide_trunk_kernel, dim3(grid), dim3(wt::Cfg::THREADS), wt::Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 

@@ -212,3 +212,53 @@ def compressor_executed_macs(blocks: int) -> float:
     """MACs the kernel's MFMAs execute per item: direct 1x1 / strided / shortcut convs, F(3,3) (5 contractions per 3
     positions) for the 1 + 2 blocks k3/s1 convolutions."""
     return 36 * 64 * 64 + 18 * 128 * 192 + 18 * 128 * 64 + (1 + 2 * blocks) * 6 * 5 * 128 * 128
+
+
+# ---- the 2x-channel ("_wide") read convolver: residual trunk kernel (readconv_wide_trunk_kernel) ---------------------
+def wide_trunk_nodes(nodes, cin):
+    """The 7 residual blocks after the stem if ``nodes`` is the 2x-channel read convolver
+    (architectures/read_convolver_wide.py: 6|7 -> 32 -> 32 -> 64, max pool, 3 x ResidualBlock(64), strided 64 -> 128,
+    3 x ResidualBlock(128), ReLU, no LayerNorm), else None."""
+    def conv_is(n, ci, co, k, stride, pad, act):
+        return (isinstance(n, ns.Conv) and (n.cin, n.cout, n.k, n.stride, n.pad, n.dilation, n.groups, n.act) ==
+                (ci, co, k, stride, pad, 1, 1, act) and n.norm != "ln")
+    if len(nodes) != TRUNK_FIRST_NODE + 7 or cin not in (6, 7):
+        return None
+    stem = nodes[:TRUNK_FIRST_NODE]
+    if not (conv_is(stem[0], cin, 32, 3, 1, 0, "relu") and conv_is(stem[1], 32, 32, 3, 1, 0, "relu") and
+            conv_is(stem[2], 32, 64, 3, 1, 0, "relu") and isinstance(stem[3], ns.MaxPool) and
+            (stem[3].k, stem[3].stride, stem[3].pad) == (3, 2, 0)):
+        return None
+    blocks = nodes[TRUNK_FIRST_NODE:]
+
+    def identity(blk, c):
+        return (isinstance(blk, ns.Residual) and len(blk.body) == 2 and not blk.shortcut and
+                all(conv_is(x, c, c, 3, 1, 1, "relu") for x in blk.body))
+    st = blocks[3]
+    if not (all(identity(b, 64) for b in blocks[:3]) and all(identity(b, 128) for b in blocks[4:]) and
+            isinstance(st, ns.Residual) and len(st.body) == 2 and len(st.shortcut) == 1 and
+            conv_is(st.body[0], 64, 128, 3, 2, 1, "relu") and conv_is(st.body[1], 128, 128, 3, 1, 1, "relu") and
+            conv_is(st.shortcut[0], 64, 128, 1, 2, 0, "none")):
+        return None
+    return blocks
+
+
+def pack_wide_trunk(blocks, folded) -> np.ndarray:
+    """wt::Cfg offsets: 6 convs 64->64 in the F(3,3) layout, the strided conv and its shortcut in the direct layout, the
+    strided block's second conv and 6 convs 128->128 in the F(3,3) layout; each followed by its bias."""
+    parts = []
+    for blk in blocks[:3]:
+        parts += [_pack_conv_f33(*folded[blk.body[0].key]), _pack_conv_f33(*folded[blk.body[1].key])]
+    st = blocks[3]
+    parts += [_pack_conv(*folded[st.body[0].key]), _pack_conv(*folded[st.shortcut[0].key]), _pack_conv_f33(*folded[st.body[1].key])]
+    for blk in blocks[4:]:
+        parts += [_pack_conv_f33(*folded[blk.body[0].key]), _pack_conv_f33(*folded[blk.body[1].key])]
+    blob = np.concatenate(parts)
+    assert blob.size == 6 * (20480 + 64) + (24576 + 128) + (8192 + 128) + 7 * (81920 + 128), blob.size
+    return blob
+
+
+def wide_trunk_executed_macs() -> float:
+    """MACs the trunk kernel's MFMAs execute per read: F(3,3) (5 contractions per 3 positions; 24 triples per read at 64
+    channels incl. the shared zero row, 12 at 128), direct strided conv and shortcut."""
+    return 6 * 24 * 5 * 64 * 64 + 36 * 128 * 192 + 36 * 128 * 64 + 7 * 12 * 5 * 128 * 128

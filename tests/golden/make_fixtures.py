@@ -530,7 +530,7 @@ def make_addendum_pickle_fixture():
 
 
 FRAME_CASES = ["single_tech_hp", "single_tech_deep", "hybrid_no_ensemble", "merged_single", "merged_hybrid_250",
-               "single_tech_softplus", "single_tech_addendum", "single_tech_bn"]
+               "single_tech_softplus", "single_tech_addendum", "single_tech_bn", "hybrid_no_ensemble_wide"]
 
 
 def make_frames_fixture():

@@ -328,18 +328,35 @@ def test_malformed_programs_are_rejected_at_creation():
         Engine(spec, state, program=prog)
 
 
-def test_wide_model_runs_layer_by_layer_and_matches_oracle(engines):
-    """The *_wide configuration (2x channels) is outside the fused kernel's shape: it must take the generic
-    conv path (including the 128-channel workgroup tile) and still agree with the oracle."""
+def test_wide_model_fused_trunk_matches_oracle(engines):
+    """The *_wide configuration (2x channels): stem layer by layer, residual trunk + segment sum in the wide trunk kernel
+    (one group of 4 reads per workgroup, alleles of 1..40 reads straddling groups, a partial last group), everything
+    else on the generic conv path (including the 128-channel workgroup tile).  Logits against the oracle, the trunk
+    kernel's per-allele frames [36][128] against the oracle's, and against the same engine run entirely layer by layer."""
+    from hello_amd import compiler
     from oracle import moe_oracle as mo
     spec = ns.build("hybrid_no_ensemble_wide")
     state = weights.synth_state(spec, seed=23)
-    batch = synth.make_sites(6, seed=12, coverage=12, hybrid_coverage=8)
+    batch = synth.make_sites(9, seed=12, coverage=12, hybrid_coverage=8)
     eng = get_engine(engines, "wide", spec, state, True)
-    assert not eng.program.fused_read_convolver
-    logits, _ = eng.forward_batch(batch)
-    want, _ = mo.forward_batch(mo.Oracle(spec, state), batch, chunk_sites=6)
+    assert eng.program.fused_read_convolver
+    trunk_ops = [i for i, o in enumerate(eng.program.ops) if o.kind == compiler.OP_READCONV_FUSED]
+    assert len(trunk_ops) == 2 and all((eng.program.ops[i].cin, eng.program.ops[i].cout) == (64, 128) for i in trunk_ops)
+    oracle = mo.Oracle(spec, state)
+    want, _ = mo.forward_batch(oracle, batch, chunk_sites=len(batch.alleles_per_site))
+    frames_want = [np.asarray(oracle.last["frames0"]), np.asarray(oracle.last["frames1"])]      # per technology [A, 128, 36]
+    for tech, op in enumerate(trunk_ops):
+        eng.capture_op_output(op)
+        logits, _ = eng.forward_batch(batch)
+        got = eng.read_op_output().reshape(-1, 36, 128)
+        scale = float(np.abs(frames_want[tech]).max())
+        np.testing.assert_allclose(got, frames_want[tech].transpose(0, 2, 1), rtol=2e-5, atol=2e-5 * scale)
+    eng.capture_op_output(None)
     np.testing.assert_allclose(logits, want, **LOGIT_TOL)
+    layered = get_engine(engines, "wide_layered", spec, state, False)
+    assert not layered.program.fused_read_convolver
+    logits_l, _ = layered.forward_batch(batch)
+    np.testing.assert_allclose(logits, logits_l, **LOGIT_TOL)
 
 
 def _direct_segment_sum(d, slots):

@@ -211,10 +211,23 @@ def test_250bp_model_uses_the_fused_kernel_in_winograd_form_only():
         assert not compiler.compile_model(spec, state, **kw).fused_read_convolver
 
 
-def test_wide_model_falls_back_to_layer_by_layer():
+def test_wide_model_takes_the_trunk_kernel_behind_a_layered_stem():
+    """2x channels: three stem convs + max pool as layers, then the wide trunk kernel on the pooled [71][64] rows."""
+    from hello_amd import readconv_pack
     spec = ns.build("hybrid_no_ensemble_wide")
-    prog = compiler.compile_model(spec, weights.synth_state(spec, seed=1))
-    assert not prog.fused_read_convolver
+    state = weights.synth_state(spec, seed=1)
+    prog = compiler.compile_model(spec, state)
+    assert prog.fused_read_convolver
+    fused = [i for i, o in enumerate(prog.ops) if o.kind == compiler.OP_READCONV_FUSED]
+    assert len(fused) == 2
+    for i in fused:
+        o = prog.ops[i]
+        assert (o.cin, o.cout, o.lin, o.lout, o.k) == (64, 128, 71, 36, 0)
+        assert o.flags & compiler.FLAG_WINOGRAD and not (o.flags & compiler.FLAG_SRC_U8)
+        assert [p.kind for p in prog.ops[i - 4:i]] == [compiler.OP_CONV1D] * 3 + [compiler.OP_MAXPOOL]
+        assert o.macs_per_row == 18_800_640 and o.exec_macs_per_row == readconv_pack.wide_trunk_executed_macs()
+    for kw in (dict(winograd=False), dict(fused=False), dict(fused="trunk")):
+        assert not compiler.compile_model(spec, state, **kw).fused_read_convolver
 
 
 def test_library_exports_every_declared_symbol():
