@@ -364,16 +364,24 @@ class _Lowering:
             # Winograd form only
             fusable = self.fused is True and self.winograd and extras == 0 and not (softplus and spec.window != 150)
         wide_blocks = readconv_pack.wide_trunk_nodes(nodes, cin)
-        if self.fused is True and self.winograd and spec.window == 150 and wide_blocks is not None and readconv_pack.AVAILABLE:
-            # the 2x-channel read convolver: stem layer by layer, then ONE kernel for the residual trunk + segment sum
-            pooled = self.net(nodes[:readconv_pack.TRUNK_FIRST_NODE], x)
-            assert (pooled.length, pooled.channels) == (71, 64)
+        if (self.fused in (True, "trunk") and self.winograd and spec.window == 150 and wide_blocks is not None
+                and readconv_pack.AVAILABLE):
+            # the 2x-channel read convolver: ONE kernel from the bytes (stem, residual trunk, segment sum), or with
+            # fused="trunk" the stem layer by layer and the kernel entered at the pooled rows
             y = self.new(ROWS_ALLELES, 36, 128)
-            w_off = self.blob.add(readconv_pack.pack_wide_trunk(wide_blocks, self.folded))
-            self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=pooled.vid, dst=y.vid, cin=64, cout=128, k=0, lin=71,
-                               lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name + ".trunk", flags=FLAG_WINOGRAD,
-                               macs_per_row=ns.macs(wide_blocks, 71),
-                               exec_macs_per_row=readconv_pack.wide_trunk_executed_macs()))
+            w_off = self.blob.add(readconv_pack.pack_wide(nodes, wide_blocks, self.folded))
+            if self.fused == "trunk":
+                pooled = self.net(nodes[:readconv_pack.TRUNK_FIRST_NODE], x)
+                assert (pooled.length, pooled.channels) == (71, 64)
+                self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=pooled.vid, dst=y.vid, cin=64, cout=128, k=0, lin=71,
+                                   lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name + ".trunk", flags=FLAG_WINOGRAD,
+                                   macs_per_row=ns.macs(wide_blocks, 71),
+                                   exec_macs_per_row=readconv_pack.wide_trunk_executed_macs()))
+            else:
+                self.ops.append(Op(OP_READCONV_FUSED, ROWS_ALLELES, src0=buf, dst=y.vid, cin=cin, cout=128, k=0, lin=spec.window,
+                                   lout=36, seg=seg, w_off=w_off, b_off=w_off, name=name, flags=FLAG_SRC_U8 | FLAG_WINOGRAD,
+                                   macs_per_row=ns.macs(nodes, spec.window),
+                                   exec_macs_per_row=readconv_pack.wide_executed_macs(cin)))
             self.used_fused = True
             return y
         if fusable:

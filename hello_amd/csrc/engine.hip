@@ -183,10 +183,11 @@ int validate_model(const hello_model_desc* d) {
             if (!hello::readconv_supports_window(d->window))
                 return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver takes 150 or 250 bp windows, not %d", i, d->window);
             const bool wide = o.cout == 128;       // the 2x-channel trunk: pooled [71][64] rows in, [36][128] frames out
-            if (wide && !(d->window == 150 && o.cin == 64 && o.lin == 71 && o.lout == 36 && o.k == 0 &&
-                          (o.flags & HELLO_FLAG_WINOGRAD) && !(o.flags & (HELLO_FLAG_SRC_U8 | HELLO_FLAG_SOFTPLUS))))
-                return fail(HELLO_ERR_MODEL, "op %d: the wide read-convolver trunk maps pooled [71][64] rows to [36][128] frames "
-                                             "(150 bp, Winograd form, ReLU, no extra blocks)", i);
+            const bool wide_shape = (o.flags & HELLO_FLAG_SRC_U8) ? ((o.cin == 6 || o.cin == 7) && o.lin == 150) : (o.cin == 64 && o.lin == 71);
+            if (wide && !(d->window == 150 && wide_shape && o.lout == 36 && o.k == 0 && (o.flags & HELLO_FLAG_WINOGRAD) &&
+                          !(o.flags & HELLO_FLAG_SOFTPLUS)))
+                return fail(HELLO_ERR_MODEL, "op %d: the wide read convolver maps pileup bytes [150][6|7] or pooled [71][64] rows to "
+                                             "[36][128] frames (150 bp, Winograd form, ReLU, no extra blocks)", i);
             if (!wide && (o.lout != hello::readconv_frame_rows(d->window) || o.cout != 64))
                 return fail(HELLO_ERR_MODEL, "op %d: the fused read convolver yields [%d][64] frames", i,
                             hello::readconv_frame_rows(d->window));

@@ -1647,26 +1647,158 @@ struct Cfg {
     static constexpr int L1 = 71, RS1 = 72;            // positions / row stride per read at 64 channels
     static constexpr int L2 = 36;                      // positions per read at 128 channels (compact)
     static constexpr int NSREG = 3 * (L2 * G / 48);    // shortcut tiles a wave keeps in registers (triple order)
-    // the last triple of the 64-channel image reads rows up to RS1 G + 1 (its fifth input feeds the zero row's output only)
-    static constexpr int BUF_FLOATS = rc::cmax((RS1 * G + 2) * 64, (L2 * G + 2) * 128);
-    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4 + 64;
+    // the last triple of the 64-channel image reads rows up to RS1 G + 1 (its fifth input feeds the zero row's output only);
+    // the stem's 32-channel stacks are WINDOW G rows, the second one shifted down a row (+ the row its last pair overhangs)
+    static constexpr int WINDOW = 150, SROWS = WINDOW * G;
+    static constexpr int BUF_FLOATS = rc::cmax(rc::cmax((RS1 * G + 2) * 64, (L2 * G + 2) * 128), (SROWS + 2) * 32);
+    static constexpr int ST1 = ((SROWS + 15) / 16 + NW - 1) / NW * NW;     // conv1 tiles of 16 rows, whole rounds of the waves
+    static constexpr int U8_BYTES = ((ST1 * 16 + 8) * 7 + 15) / 16 * 16;   // every conv1 tile reads in bounds
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4 + 64 + U8_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup's images + byte staging fit the CU's LDS");
     // packed weight block (floats): the F(3,3) convs [COUT/16][CIN/16][5][64 lanes][4] + bias[COUT]; the strided conv and
     // its shortcut [COUT/16][KT][CIN/16][64 lanes][4] + bias
     static constexpr int WA = 4 * 4 * 5 * 256, WS = 8 * 3 * 4 * 256, WSC = 8 * 1 * 4 * 256, WB = 8 * 8 * 5 * 256;
     static constexpr int off_a(int i) { return i * (WA + 64); }               // 6 convs 64 -> 64
     static constexpr int OFF_S = 6 * (WA + 64), OFF_SC = OFF_S + WS + 128, OFF_B = OFF_SC + WSC + 128;
     static constexpr int off_b(int i) { return OFF_B + i * (WB + 128); }      // 0: the strided block's second conv; then 6 convs 128 -> 128
-    static constexpr int W_TOTAL = OFF_B + 7 * (WB + 128);
+    static constexpr int W_TRUNK = OFF_B + 7 * (WB + 128);
+    // the stem: conv1 [2 blocks][6 steps][64 lanes] + bias[32]; conv2 and conv3 as F(2,3) taps [COUT/16][4][2][64 lanes][4] + bias
+    static constexpr int OFF_S1 = W_TRUNK, W_S1 = 2 * rc::S1_STEPS * 64;
+    static constexpr int OFF_S2 = OFF_S1 + W_S1 + 32, W_S2 = 2 * 4 * 2 * 256;
+    static constexpr int OFF_S3 = OFF_S2 + W_S2 + 32, W_S3 = 4 * 4 * 2 * 256;
+    static constexpr int W_TOTAL = OFF_S3 + W_S3 + 64;
+};
+// what wino_layer needs to walk the stem's stacked rows (150 per read, no rows between reads) as one sequence of pairs
+struct StemCfg {
+    static constexpr int ACT = rc::ACT_RELU;
+    static __device__ __forceinline__ float act(float x) { return fmaxf(x, 0.f); }
+    static constexpr int G = Cfg::G, NW = Cfg::NW;
+    static constexpr int RS1 = Cfg::WINDOW, RS2 = Cfg::WINDOW;
+    static constexpr bool COMPACT = false;
 };
 }  // namespace wt
 
-int readconv_wide_weight_floats() { return wt::Cfg::W_TOTAL; }
+// ---- wide stem conv1: pileup bytes -> 32 channels (valid convolution over the stacked reads), as stem_conv1 with both
+// 16-channel blocks per wave: tiles wave, wave + 8, ...; position r is stored at row r of a 32-channel SW_W image.
+__device__ __forceinline__ void wide_stem_conv1(const unsigned char* __restrict__ s_u8, float* __restrict__ out,
+                                                const float* __restrict__ W, int ch, float* __restrict__ dump, int wave,
+                                                int lane) {
+    using CF = wt::Cfg;
+    constexpr int S = rc::S1_STEPS, NK = CF::ST1 / CF::NW;
+    const int j = lane & 15, q = lane >> 4;
+    float w1[2][S];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int st = 0; st < S; ++st) w1[blk][st] = W[(blk * S + st) * 64 + lane];
+    f32x4 b4[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) b4[blk] = *(const f32x4*)(W + 2 * S * 64 + blk * 16 + 4 * q);
+    const unsigned char* base = s_u8 + (16 * wave + j) * ch + q;             // tile `wave`, row j, byte q
+    const int round_bytes = CF::NW * 16 * ch;
+    unsigned char cur[S], nxt[S];
+#pragma unroll
+    for (int st = 0; st < S; ++st) cur[st] = base[4 * st];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        if (k + 1 < NK) {
+#pragma unroll
+            for (int st = 0; st < S; ++st) nxt[st] = base[(k + 1) * round_bytes + 4 * st];
+        }
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0][st], (float)cur[st], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[1][st], (float)cur[st], a1, 0, 0, 0);
+        }
+        const int r = 16 * (wave + CF::NW * k) + j;
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = CF::act(a0[e] + b4[0][e]);
+            v1[e] = CF::act(a1[e] + b4[1][e]);
+        }
+        *(f32x4*)(r < CF::SROWS ? out + img_off<32, SW_W>(r, q) : dump) = v0;
+        *(f32x4*)(r < CF::SROWS ? out + img_off<32, SW_W>(r, 4 + q) : dump) = v1;
+#pragma unroll
+        for (int st = 0; st < S; ++st) cur[st] = nxt[st];
+    }
+}
+
+// ---- wide stem conv3 (32 -> 64, valid) + ReLU + MaxPool1d(3, 2) in Winograd F(2,3) form, as stem_conv3_pool_wino:
+// lane row j of a tile holds the pair of conv3 positions (2P, 2P+1), P = 15 t + j, pooled output P = max(y0, y1, y0 of
+// lane j+1); 5 tiles per read.  Wave (read, half) computes channel blocks 2 half, 2 half + 1 of its read's 5 tiles.
+// conv2 (wino_layer) stored position p of the stack at row p + 1.  Output: the trunk's 64-channel image (SW_3).
+__device__ __forceinline__ void wide_stem_conv3_pool(const float* __restrict__ in, float* __restrict__ out,
+                                                     const float* __restrict__ W3, float* __restrict__ dump, int wave,
+                                                     int lane, int n_here) {
+    using CF = wt::Cfg;
+    constexpr int NTR = (CF::L1 + 14) / 15;
+    const int j = lane & 15, q = lane >> 4;
+    const int rd = wave >> 1, half = wave & 1;
+    f32x4 w[2][4][2];                                                        // [block][component][input group]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) w[b][c][m] = *(const f32x4*)(W3 + ((((2 * half + b) * 4 + c) * 2 + m) * 64 + lane) * 4);
+    f32x4 b4[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) b4[b] = *(const f32x4*)(W3 + CF::W_S3 + (2 * half + b) * 16 + 4 * q);
+    const int row0 = CF::WINDOW * rd + 1 + 2 * j;                             // row of d0 of this lane's pair in tile 0
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ring[2][2][4];
+    auto issue = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ring[t & 1][m][i] = *(const f32x4*)(in + img_off<32, SW_W>(row0 + 30 * t + i, 4 * m + q));
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NTR>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (t + 1 < NTR) issue(std::integral_constant<int, t + 1>{});
+        f32x4 a[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const f32x4(&d)[4] = ring[t & 1][m];
+            const f32x4 v[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool first = (m == 0) && (e == 0);
+                        a[b][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[b][c][m][e], v[c][e], first ? (c == 1 ? b4[b] : zero4) : a[b][c],
+                                                                       0, 0, 0);
+                    }
+        }
+        const int pos = 15 * t + j;
+        const bool ok = (j <= 14) && (rd < n_here) && (pos < CF::L1);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 y0 = (a[b][0] + a[b][1]) + a[b][2];                  // the bias rides in a[1]
+            const f32x4 y1 = (a[b][1] - a[b][2]) - a[b][3];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = CF::act(fmaxf(fmaxf(y0[e], y1[e]), row_shl(y0[e], 1)));
+            float* ptr = out + img_off<64, SW_3>(1 + rd * CF::RS1 + pos, 4 * (2 * half + b) + q);
+            *(f32x4*)(ok ? ptr : dump) = v;
+        }
+    });
+}
+
+int readconv_wide_weight_floats() { return wt::Cfg::W_TOTAL; }     // trunk block, then the stem block
 int readconv_wide_reads_per_group() { return wt::Cfg::G; }
 ReadConvPlan readconv_wide_plan(long long n_reads) {
     return ReadConvPlan{1, (n_reads + wt::Cfg::G - 1) / wt::Cfg::G, 0};
 }
 
-__global__ __launch_bounds__(wt::Cfg::THREADS, 2) void readconv_wide_trunk_kernel(ReadConvArgs a) {
+template <bool STEM>
+__global__ __launch_bounds__(wt::Cfg::THREADS, 2) void readconv_wide_kernel(ReadConvArgs a) {
     using CF = wt::Cfg;
     constexpr int G = CF::G, L1 = CF::L1, RS1 = CF::RS1, L2 = CF::L2, THREADS = CF::THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1691,7 +1823,47 @@ __global__ __launch_bounds__(wt::Cfg::THREADS, 2) void readconv_wide_trunk_kerne
 #pragma unroll
     for (int c = 0; c < 5; ++c) w3[0][c] = *(const f32x4*)(slice64(CF::off_a(0)) + c * 256);
     if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
-    {
+    if constexpr (STEM) {
+        // the stem, from the uint8 pileups: conv1 bytes -> X (32-channel stack), conv2 X -> H, conv3 + max pool H -> X
+        // (now the trunk's 64-channel image)
+        unsigned char* const s_u8 = (unsigned char*)(smem + 2 * CF::BUF_FLOATS + 16);
+        const int ch = a.channels;
+        const int n_bytes = n_here * CF::WINDOW * ch;
+        const unsigned char* src = a.reads + read0 * CF::WINDOW * ch;
+        constexpr int NDW = (CF::U8_BYTES / 4 + THREADS - 1) / THREADS;      // the group's bytes in ONE round trip
+        if ((reinterpret_cast<unsigned long long>(src) & 3ull) == 0) {
+            unsigned v[NDW];
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) {
+                const int d = tid + THREADS * k;
+                unsigned x = 0;
+                if (4 * d + 4 <= n_bytes) {
+                    x = ((const unsigned*)src)[d];
+                } else if (4 * d < n_bytes) {                                // the last, partial dword (7-channel reads)
+                    for (int b = 0; b < n_bytes - 4 * d; ++b) x |= (unsigned)src[4 * d + b] << (8 * b);
+                }
+                v[k] = x;
+            }
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) {
+                const int d = tid + THREADS * k;
+                if (4 * d < CF::U8_BYTES) ((unsigned*)s_u8)[d] = v[k];
+            }
+        } else {
+            for (int i = tid; i < CF::U8_BYTES; i += THREADS) s_u8[i] = (i < n_bytes) ? src[i] : (unsigned char)0;
+        }
+        f32x4 ws2[8];
+        load_weights<8>(ws2, W + CF::OFF_S2, wave % 2, lane);
+        __syncthreads();
+        wide_stem_conv1(s_u8, X, W + CF::OFF_S1, ch, dump, wave, lane);
+        __syncthreads();
+        wino_layer<wt::StemCfg, 32, MODE_PLAIN, false>(X, H, ws2, nullptr, W + CF::OFF_S2 + CF::W_S2, 0u, dump, wave, lane);
+        __syncthreads();
+        if (tid < 16 * (G + 1)) *(f32x4*)(X + img_off<64, SW_3>((tid >> 4) * RS1, tid & 15)) = zero4;   // the shared zero rows
+        wide_stem_conv3_pool(H, X, W + CF::OFF_S3, dump, wave, lane, n_here);
+        __syncthreads();
+        if (tid < 16) ((f32x4*)H)[tid] = zero4;                              // row 0 of H as the trunk's 64-channel image
+    } else {
         // the group's pooled rows in ONE round trip: every thread requests its float4 first and stores them afterwards
         const f32x4* src = (const f32x4*)(a.pooled + read0 * (long long)(L1 * 64));
         constexpr int NLD = (G * L1 * 16 + THREADS - 1) / THREADS;
@@ -1824,21 +1996,23 @@ __global__ __launch_bounds__(wt::Cfg::THREADS, 2) void readconv_wide_trunk_kerne
 
 hipError_t launch_readconv_wide(const ReadConvArgs& a, hipStream_t stream) {
     if (a.n_reads <= 0) return hipSuccess;
-    if (!a.pooled || a.reads || !a.w || !a.partial || !a.winograd || a.window != 150 || a.extra_blocks != 0 || a.softplus ||
-        a.groups_per_wg != 1)
+    if ((!a.pooled == !a.reads) || !a.w || !a.partial || !a.winograd || a.window != 150 || a.extra_blocks != 0 || a.softplus ||
+        a.groups_per_wg != 1 || (a.reads && a.channels != 6 && a.channels != 7))
         return hipErrorInvalidValue;
     static bool configured_on[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured_on[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)readconv_wide_trunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)readconv_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            wt::Cfg::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)readconv_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wt::Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         configured_on[dev] = true;
     }
-    const long long per_wg = (long long)wt::Cfg::G * a.groups_per_wg;
-    const unsigned grid = (unsigned)((a.n_reads + per_wg - 1) / per_wg);
-    hipLaunchKernelGGL(readconv_wide_trunk_kernel, dim3(grid), dim3(wt::Cfg::THREADS), wt::Cfg::LDS_BYTES, stream, a);
+    const unsigned grid = (unsigned)((a.n_reads + wt::Cfg::G - 1) / wt::Cfg::G);
+    if (a.reads) hipLaunchKernelGGL(readconv_wide_kernel<true>, dim3(grid), dim3(wt::Cfg::THREADS), wt::Cfg::LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(readconv_wide_kernel<false>, dim3(grid), dim3(wt::Cfg::THREADS), wt::Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 

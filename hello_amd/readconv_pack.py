@@ -243,6 +243,38 @@ def wide_trunk_nodes(nodes, cin):
     return blocks
 
 
+def _pack_first_conv_wide(w: np.ndarray, b: np.ndarray, steps: int = 6) -> np.ndarray:
+    """``_pack_first_conv`` for 32 output channels: [2 blocks][steps][64 lanes], then bias[32]."""
+    cout, cin, k = w.shape
+    assert cout == 32 and k == 3 and 3 * cin <= 4 * steps
+    flat = np.zeros((cout, 4 * steps), np.float32)
+    flat[:, :3 * cin] = w.transpose(0, 2, 1).reshape(cout, 3 * cin)
+    lanes = np.arange(64)
+    packed = flat[(16 * np.arange(2)[:, None, None] + (lanes & 15)[None, None, :]),
+                  (4 * np.arange(steps)[None, :, None] + (lanes >> 4)[None, None, :])]           # [blk][step][lane]
+    return np.concatenate([packed.ravel(), b.astype(np.float32).ravel()])
+
+
+def pack_wide(nodes, blocks, folded) -> np.ndarray:
+    """Trunk block (``pack_wide_trunk``) followed by the stem block: conv1 in the bytes form, conv2 and conv3 as their
+    four Winograd F(2,3) taps (wt::Cfg::OFF_S1 / OFF_S2 / OFF_S3)."""
+    stem = nodes[:3]
+    parts = [pack_wide_trunk(blocks, folded), _pack_first_conv_wide(*folded[stem[0].key])]
+    for conv in stem[1:]:
+        w, b = folded[conv.key]
+        parts.append(_pack_conv(winograd_taps(w), b))
+    blob = np.concatenate(parts)
+    assert blob.size == parts[0].size + (768 + 32) + (4096 + 32) + (8192 + 64), blob.size
+    return blob
+
+
+def wide_executed_macs(cin: int) -> float:
+    """MACs the whole wide kernel's MFMAs execute per read: ``wide_trunk_executed_macs`` + the stem (conv1 40 tiles of
+    16 rows x 24 k x 32 channels per 4 reads; conv2 19 tiles of 16 pairs, conv3 5 tiles of 16 pairs per read, 4
+    contractions per pair)."""
+    return wide_trunk_executed_macs() + 40 * 16 * 24 * 32 / 4 + 19 * 16 * 4 * 32 * 32 / 4 + 5 * 16 * 4 * 32 * 64
+
+
 def pack_wide_trunk(blocks, folded) -> np.ndarray:
     """wt::Cfg offsets: 6 convs 64->64 in the F(3,3) layout, the strided conv and its shortcut in the direct layout, the
     strided block's second conv and 6 convs 128->128 in the F(3,3) layout; each followed by its bias."""

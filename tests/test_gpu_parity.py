@@ -328,24 +328,27 @@ def test_malformed_programs_are_rejected_at_creation():
         Engine(spec, state, program=prog)
 
 
-def test_wide_model_fused_trunk_matches_oracle(engines):
-    """The *_wide configuration (2x channels): stem layer by layer, residual trunk + segment sum in the wide trunk kernel
-    (one group of 4 reads per workgroup, alleles of 1..40 reads straddling groups, a partial last group), everything
-    else on the generic conv path (including the 128-channel workgroup tile).  Logits against the oracle, the trunk
-    kernel's per-allele frames [36][128] against the oracle's, and against the same engine run entirely layer by layer."""
+@pytest.mark.parametrize("fused", [True, "trunk"])
+def test_wide_model_matches_oracle(engines, fused):
+    """The *_wide configuration (2x channels): the wide kernel from the bytes (stem, residual trunk, segment sum; one group
+    of 4 reads per workgroup, alleles of 1..40 reads straddling groups, a partial last group), or entered at the pooled
+    rows behind a layer-by-layer stem; everything else on the generic conv path (including the 128-channel workgroup
+    tile).  Logits against the oracle, the kernel's per-allele frames [36][128] against the oracle's, and against the
+    same engine run entirely layer by layer."""
     from hello_amd import compiler
     from oracle import moe_oracle as mo
     spec = ns.build("hybrid_no_ensemble_wide")
     state = weights.synth_state(spec, seed=23)
     batch = synth.make_sites(9, seed=12, coverage=12, hybrid_coverage=8)
-    eng = get_engine(engines, "wide", spec, state, True)
+    eng = get_engine(engines, "wide", spec, state, fused)
     assert eng.program.fused_read_convolver
-    trunk_ops = [i for i, o in enumerate(eng.program.ops) if o.kind == compiler.OP_READCONV_FUSED]
-    assert len(trunk_ops) == 2 and all((eng.program.ops[i].cin, eng.program.ops[i].cout) == (64, 128) for i in trunk_ops)
+    ops = [i for i, o in enumerate(eng.program.ops) if o.kind == compiler.OP_READCONV_FUSED]
+    assert len(ops) == 2 and all(eng.program.ops[i].cout == 128 for i in ops)
+    assert all(bool(eng.program.ops[i].flags & compiler.FLAG_SRC_U8) == (fused is True) for i in ops)
     oracle = mo.Oracle(spec, state)
     want, _ = mo.forward_batch(oracle, batch, chunk_sites=len(batch.alleles_per_site))
     frames_want = [np.asarray(oracle.last["frames0"]), np.asarray(oracle.last["frames1"])]      # per technology [A, 128, 36]
-    for tech, op in enumerate(trunk_ops):
+    for tech, op in enumerate(ops):
         eng.capture_op_output(op)
         logits, _ = eng.forward_batch(batch)
         got = eng.read_op_output().reshape(-1, 36, 128)
@@ -353,10 +356,34 @@ def test_wide_model_fused_trunk_matches_oracle(engines):
         np.testing.assert_allclose(got, frames_want[tech].transpose(0, 2, 1), rtol=2e-5, atol=2e-5 * scale)
     eng.capture_op_output(None)
     np.testing.assert_allclose(logits, want, **LOGIT_TOL)
-    layered = get_engine(engines, "wide_layered", spec, state, False)
+    layered = get_engine(engines, "wide", spec, state, False)
     assert not layered.program.fused_read_convolver
     logits_l, _ = layered.forward_batch(batch)
     np.testing.assert_allclose(logits, logits_l, **LOGIT_TOL)
+
+
+def test_wide_model_seven_channels_and_short_last_group(engines):
+    """The wide kernel's byte path with 7-channel reads (rows of 7 bytes: the staging copy's partial last dword) and
+    read counts that leave the last workgroup 1, 2 and 3 reads."""
+    from oracle import moe_oracle as mo
+    wide = dict(norm="wn", w=2)
+    nets = ns._nets("moeMerged", {
+        "read_convolver0": (ns.read_convolver, dict(in_channels=7, **wide)),
+        "read_convolver1": (ns.read_convolver, dict(in_channels=7, **wide)),
+        "compressor0": (ns.compressor, wide), "compressor1": (ns.compressor, wide),
+        "combiner0": (ns.conv_combiner, wide), "combiner1": (ns.conv_combiner, wide),
+        "xattn2": (ns.xattn_subtract, wide)})
+    spec = ns.ModelSpec(nets, name="hybrid_no_ensemble_wide_hp", channels=(7, 7), prefix="moeMerged")
+    state = weights.synth_state(spec, seed=29)
+    eng = get_engine(engines, "wide7", spec, state, True)
+    assert eng.program.fused_read_convolver
+    oracle = mo.Oracle(spec, state)
+    for seed in (1, 2, 3, 4):
+        batch = synth.make_sites(2 + seed, seed=40 + seed, coverage=9 + seed, hybrid_coverage=5 + seed, channels=7, channels1=7)
+        assert batch.reads0.shape[2] == 7 and batch.reads1.shape[2] == 7
+        logits, _ = eng.forward_batch(batch)
+        want, _ = mo.forward_batch(oracle, batch, chunk_sites=len(batch.alleles_per_site))
+        np.testing.assert_allclose(logits, want, **LOGIT_TOL)
 
 
 def _direct_segment_sum(d, slots):

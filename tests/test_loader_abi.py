@@ -211,22 +211,31 @@ def test_250bp_model_uses_the_fused_kernel_in_winograd_form_only():
         assert not compiler.compile_model(spec, state, **kw).fused_read_convolver
 
 
-def test_wide_model_takes_the_trunk_kernel_behind_a_layered_stem():
-    """2x channels: three stem convs + max pool as layers, then the wide trunk kernel on the pooled [71][64] rows."""
+def test_wide_model_takes_the_wide_kernel():
+    """2x channels: one kernel from the bytes (stem, residual trunk, segment sum); with fused="trunk" the three stem convs
+    + max pool as layers and the same kernel entered at the pooled [71][64] rows."""
     from hello_amd import readconv_pack
     spec = ns.build("hybrid_no_ensemble_wide")
     state = weights.synth_state(spec, seed=1)
     prog = compiler.compile_model(spec, state)
     assert prog.fused_read_convolver
-    fused = [i for i, o in enumerate(prog.ops) if o.kind == compiler.OP_READCONV_FUSED]
+    fused = [o for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED]
     assert len(fused) == 2
-    for i in fused:
-        o = prog.ops[i]
+    for o in fused:
+        assert (o.cin, o.cout, o.lin, o.lout, o.k) == (6, 128, 150, 36, 0)
+        assert o.flags & compiler.FLAG_WINOGRAD and o.flags & compiler.FLAG_SRC_U8
+        assert o.macs_per_row == 4 * 5_076_096 - 3 * 148 * 6 * 32 and o.exec_macs_per_row == readconv_pack.wide_executed_macs(6)
+    trunk = compiler.compile_model(spec, state, fused="trunk")
+    assert trunk.fused_read_convolver
+    idx = [i for i, o in enumerate(trunk.ops) if o.kind == compiler.OP_READCONV_FUSED]
+    assert len(idx) == 2
+    for i in idx:
+        o = trunk.ops[i]
         assert (o.cin, o.cout, o.lin, o.lout, o.k) == (64, 128, 71, 36, 0)
         assert o.flags & compiler.FLAG_WINOGRAD and not (o.flags & compiler.FLAG_SRC_U8)
-        assert [p.kind for p in prog.ops[i - 4:i]] == [compiler.OP_CONV1D] * 3 + [compiler.OP_MAXPOOL]
+        assert [p.kind for p in trunk.ops[i - 4:i]] == [compiler.OP_CONV1D] * 3 + [compiler.OP_MAXPOOL]
         assert o.macs_per_row == 18_800_640 and o.exec_macs_per_row == readconv_pack.wide_trunk_executed_macs()
-    for kw in (dict(winograd=False), dict(fused=False), dict(fused="trunk")):
+    for kw in (dict(winograd=False), dict(fused=False)):
         assert not compiler.compile_model(spec, state, **kw).fused_read_convolver
 
 
