@@ -76,6 +76,8 @@ def test_million_site_stream_is_reproducible_and_matches_oracle_on_samples():
     ("C3 PacBio HiFi, cov U{8..52}, R <= 128", "single_tech", dict(coverage=(8, 52), tech="pacbio")),
     ("C4 hybrid no-ensemble, 30x + 15x", "hybrid_no_ensemble", dict(coverage=30, hybrid_coverage=15)),
     ("C5 haplotagged (7 channels), cov U{20..80}", "single_tech_hp", dict(coverage=(20, 80), channels=7, tech="pacbio")),
+    ("hybrid no-ensemble wide (2x channels: readconv_wide_kernel), 30x + 15x", "hybrid_no_ensemble_wide",
+     dict(coverage=30, hybrid_coverage=15)),
 ])
 def test_full_size_batches_of_the_other_baseline_configs(label, cfg, kw):
     """BASELINE.json's other configurations at a full 8 192-site launch (alleles straddling the fused kernel's read

@@ -326,6 +326,18 @@ def test_malformed_programs_are_rejected_at_creation():
     next(o for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED).k = 1   # only 0 or 2 extra blocks exist
     with pytest.raises(RuntimeError, match="extra blocks"):
         Engine(spec, state, program=prog)
+    # the wide read convolver's op: 150 bp bytes or pooled [71][64] rows in, [36][128] frames out, nothing else
+    wide = ns.build("hybrid_no_ensemble_wide")
+    wstate = weights.synth_state(wide, seed=3)
+    for field, value in (("lin", 148), ("k", 2), ("cin", 5)):
+        prog = compiler.compile_model(wide, wstate)
+        setattr(next(o for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED), field, value)
+        with pytest.raises(RuntimeError, match="wide read convolver"):
+            Engine(wide, wstate, program=prog)
+    prog = compiler.compile_model(wide, wstate)
+    prog.weights = prog.weights[:len(prog.weights) // 2]
+    with pytest.raises(RuntimeError, match="past the end of the blob"):
+        Engine(wide, wstate, program=prog)
 
 
 @pytest.mark.parametrize("fused", [True, "trunk"])
