@@ -182,11 +182,101 @@ static void launch_kc(const ConvArgs& a, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL((conv1d_mfma_kernel<NCB, SrcT, VEC, 32>), grid, dim3(256), 0, stream, a);
 }
 
+// ---- the same convolution for SMALL launches --------------------------------------------------------------------
+// Fewer 128-position workgroups than a quarter of the CUs: the launch waits for one wave's chain through K behind two
+// barriers per chunk (17 - 38 us whatever the batch).  Here a workgroup owns 16 positions x 16 channels
+// (v_mfma_f32_16x16x4_f32) and its four waves split the K groups (a group = 16 input channels of one tap): no staging, one
+// barrier.  Lane (j, q) loads the float4 of channels 16 m + 4 q .. + 3 of its position's tap and of its output channel's
+// weights (K index = tap * cin + channel: a group is 16 consecutive floats of a weight row) straight from global
+// memory, eight groups per round trip; waves 1..3 hand their accumulator to wave 0 through LDS, added in wave order.
+template <int ACT, bool RES>
+__global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs a) {
+    constexpr int DEPTH = 8;
+    __shared__ __attribute__((aligned(16))) f32x4 s_red[3][64];
+    const unsigned gy = (unsigned)(a.cout / 16);
+    const unsigned tb = blockIdx.x / gy, cy = blockIdx.x - tb * gy;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int cb = (int)cy * 16;
+    const long long mg = (long long)tb * 16 + j;
+    const bool live = mg < a.m_total;
+    const long long item = live ? mg / a.lout : 0;
+    const int p = live ? (int)(mg - item * a.lout) : 0;
+    const int pos0 = p * a.stride - a.pad;
+    const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.src, 0, (int)((a.m_total / a.lout) * (long long)a.lin * a.cin * 4), 0x00020000);
+    const int gpt = a.cin / 16;                                              // groups per tap
+    const int groups = a.k * gpt, per_wave = (groups + 3) / 4;
+    const int g0 = wave * per_wave, g1 = g0 + per_wave < groups ? g0 + per_wave : groups;
+    const float* wrow = (const float*)a.w + (long long)(cb + j) * a.kpad + 4 * q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) acc = *(const f32x4*)(a.bias + cb + 4 * q);
+    for (int gb = g0; gb < g1; gb += DEPTH) {
+        f32x4 x[DEPTH], w[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            const int g = gb + i;
+            if (g < g1) {
+                const int tap = g / gpt, m = g - tap * gpt, pos = pos0 + tap;
+                const unsigned off = (live && pos >= 0 && pos < a.lin) ? (unsigned)((((int)item * a.lin + pos) * a.cin + 16 * m + 4 * q) * 4)
+                                                                       : 0x80000000u;
+                x[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc, off, 0, 0));
+                w[i] = *(const f32x4*)(wrow + 16 * g);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            if (gb + i < g1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][e], x[i][e], acc, 0, 0, 0);
+            }
+        }
+    }
+    if (wave > 0) s_red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave > 0 || !live) return;
+#pragma unroll
+    for (int wv = 0; wv < 3; ++wv) acc += s_red[wv][lane];
+    f32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = acc[e];
+        out[e] = ACT == 1 ? fmaxf(v, 0.f) : (ACT == 2 ? (v > 20.f ? v : __logf(1.f + __expf(v))) : v);
+    }
+    const long long o = mg * a.cout + cb + 4 * q;
+    if constexpr (RES) out += *(const f32x4*)(a.res + o);
+    *(f32x4*)(a.dst + o) = out;
+}
+
 hipError_t launch_conv1d(const ConvArgs& a, hipStream_t stream) {
     if (a.m_total <= 0) return hipSuccess;
     const unsigned gx = (unsigned)((a.m_total + BM - 1) / BM);
     const bool two = (a.cout_pad % 64) == 0;
     const bool vec = !a.src_u8 && (a.cin % 4 == 0);
+    {
+        static const long long cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                n = 256;
+            return (long long)n;
+        }();
+        const long long big_wgs = (long long)gx * (a.cout_pad / (vec && (a.cout_pad % 128) == 0 ? 128 : (two ? 64 : 32)));
+        const long long act_bytes = (a.m_total / a.lout) * (long long)a.lin * a.cin * 4;
+        if (!a.src_u8 && (a.cin % 16) == 0 && (a.cout % 16) == 0 && a.lout > 0 && (a.m_total % a.lout) == 0 && big_wgs * 4 <= cus &&
+            act_bytes < (1LL << 31)) {
+            const dim3 sgrid((unsigned)((a.m_total + 15) / 16 * (a.cout / 16)));
+            const int variant = (a.relu < 0 || a.relu > 2 ? 0 : a.relu) * 2 + (a.res ? 1 : 0);
+            switch (variant) {
+                case 0: hipLaunchKernelGGL((conv1d_small_kernel<0, false>), sgrid, dim3(256), 0, stream, a); break;
+                case 1: hipLaunchKernelGGL((conv1d_small_kernel<0, true>), sgrid, dim3(256), 0, stream, a); break;
+                case 2: hipLaunchKernelGGL((conv1d_small_kernel<1, false>), sgrid, dim3(256), 0, stream, a); break;
+                case 3: hipLaunchKernelGGL((conv1d_small_kernel<1, true>), sgrid, dim3(256), 0, stream, a); break;
+                case 4: hipLaunchKernelGGL((conv1d_small_kernel<2, false>), sgrid, dim3(256), 0, stream, a); break;
+                case 5: hipLaunchKernelGGL((conv1d_small_kernel<2, true>), sgrid, dim3(256), 0, stream, a); break;
+            }
+            return hipGetLastError();
+        }
+    }
     if (vec && (a.cout_pad % 128) == 0) {
         // 128 channels per workgroup: the activation tile is gathered once for four channel blocks
         launch_kc<4, float, true>(a, dim3(gx, a.cout_pad / 128), stream);

@@ -25,6 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 constexpr int BMP = 64;    // Winograd tiles (pairs or triples of positions) per workgroup
 constexpr int BN = 64;     // channels per workgroup
+constexpr int SMALL_LAUNCH_DIVISOR = 4;   // the small kernel serves launches of at most (CUs / this) 64 x 64 workgroups
 }  // namespace
 
 // M = outputs per Winograd tile: 2 -> F(2,3), 4 components; 3 -> F(3,3), 5 components (points 0, 1, -1, 2, inf):
@@ -214,6 +215,122 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     }
 }
 
+// ---- the same convolution for SMALL launches --------------------------------------------------------------------
+// When the tiles of a launch make fewer 64 x 64 workgroups than a quarter of the CUs, what the launch waits for is one
+// wave's chain: a 32 x 32 block over K = NT x cin is cin/8 chunks of NT x 4 MFMAs of 64 cycles behind two barriers each
+// (36 us at 256 channels, whatever the batch).  Here a WORKGROUP owns 16 tiles x 16 channels (v_mfma_f32_16x16x4_f32)
+// and its four waves split the input channels: a sixteenth of the chain, no staging and one barrier -- lane (j, q)
+// loads the float4 of channels 16 m + 4 q .. + 3 of its tile's NT taps and of its output channel's NT transformed taps
+// straight from global memory (the weights in the layout the large kernel packs: a 16-channel group is two 8-channel
+// groups), two groups ahead; one b128 feeds four MFMAs per component.  D[channel][tile]: lane (j, q) ends with
+// channels 4 q .. 4 q + 3 of tile j; waves 1..3 hand their accumulators to wave 0 through LDS, added in wave order.
+template <int M, int ACT, bool RES>
+__global__ __launch_bounds__(256) void conv1d_wino_small_kernel(ConvArgs a) {
+    constexpr int NT = M + 2;
+    __shared__ __attribute__((aligned(16))) f32x4 s_red[3][NT][64];
+    const int L = a.lin, PP = (L + M - 1) / M;
+    const unsigned gy = (unsigned)(a.cout / 16);
+    const unsigned tb = blockIdx.x / gy, cy = blockIdx.x - tb * gy;          // neighbours share their 16 tiles (L2)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int cb = (int)cy * 16;                                             // this workgroup's 16 output channels
+    const unsigned mp_total = a.wino_rows * (unsigned)PP;
+    const unsigned T = tb * 16u + (unsigned)j;
+    const bool live = T < mp_total;
+    const unsigned item = live ? T / (unsigned)PP : 0u;
+    const int p = live ? (int)(T - item * (unsigned)PP) : 0;
+    // activations through a buffer descriptor: taps outside the row (and dead tiles) read zeros
+    const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.src, 0, (int)((long long)a.wino_rows * L * a.cin * 4), 0x00020000);
+    unsigned act_off[NT];
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+        const int pos = M * p - 1 + tap;
+        act_off[tap] = (live && pos >= 0 && pos < L) ? (unsigned)((((int)item * L + pos) * a.cin + 4 * q) * 4) : 0x80000000u;
+    }
+    const float* wrow = a.w + (long long)(cb + j) * a.kpad + (q >> 1) * (NT * 8) + 4 * (q & 1);
+    const int groups = a.cin / 16, per_wave = (groups + 3) / 4;
+    const int g0 = wave * per_wave, g1 = g0 + per_wave < groups ? g0 + per_wave : groups;   // this wave's input groups
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) acc[1] = *(const f32x4*)(a.bias + cb + 4 * q);            // the bias rides in component 1
+
+    f32x4 d[3][NT], w[3][NT];                                                // operands of groups m, m + 1, m + 2
+    auto request = [&](int m, f32x4 (&dd)[NT], f32x4 (&ww)[NT]) {
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap)
+            dd[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc, act_off[tap], m * 64, 0));
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ww[c] = *(const f32x4*)(wrow + (long long)m * (2 * NT * 8) + c * 8);
+    };
+    if (g0 < g1) request(g0, d[0], w[0]);
+    if (g0 + 1 < g1) request(g0 + 1, d[1], w[1]);
+    for (int m = g0; m < g1; m += 3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {                                        // group m + r sits in slot r
+            if (m + r < g1) {
+                if (m + r + 2 < g1) request(m + r + 2, d[(r + 2) % 3], w[(r + 2) % 3]);
+                const f32x4(&x)[NT] = d[r];
+                f32x4 v[NT];
+                if constexpr (M == 2) {
+                    v[0] = x[0] - x[2];
+                    v[1] = x[1] + x[2];
+                    v[2] = x[2] - x[1];
+                    v[3] = x[1] - x[3];
+                } else {
+                    const f32x4 s31 = x[3] - x[1];
+                    v[0] = 2.f * (x[0] - x[2]) + s31;
+                    v[1] = s31 - (x[1] + x[2]);
+                    v[2] = 3.f * (x[1] - x[2]) + s31;
+                    v[3] = s31;
+                    v[4] = (x[4] - x[2]) - 2.f * s31;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < NT; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][c][e], v[c][e], acc[c], 0, 0, 0);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) s_red[wave - 1][c][lane] = acc[c];
+    }
+    __syncthreads();
+    if (wave > 0 || !live) return;
+#pragma unroll
+    for (int wv = 0; wv < 3; ++wv)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] += s_red[wv][c][lane];
+
+    f32x4 y[M];
+    if constexpr (M == 2) {
+        y[0] = (acc[0] + acc[1]) + acc[2];
+        y[1] = (acc[1] - acc[2]) - acc[3];
+    } else {
+        const f32x4 sum = acc[1] + acc[2], dif = acc[1] - acc[2];
+        y[0] = (acc[0] + sum) + acc[3];
+        y[1] = 2.f * acc[3] + dif;
+        y[2] = (4.f * acc[3] + sum) + acc[4];
+    }
+    const long long o = ((long long)item * L + M * p) * a.cout + cb + 4 * q;
+#pragma unroll
+    for (int u = 0; u < M; ++u) {
+        if (M * p + u >= L) break;                                           // F(2,3) over an odd row length
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = y[u][e];
+            out[e] = ACT == 1 ? fmaxf(x, 0.f) : (ACT == 2 ? (x > 20.f ? x : __logf(1.f + __expf(x))) : x);
+        }
+        if constexpr (RES) out += *(const f32x4*)(a.res + o + u * a.cout);
+        *(f32x4*)(a.dst + o + u * a.cout) = out;
+    }
+}
+
 bool conv1d_wino_supported(const ConvArgs& a) {
     return a.k == 3 && a.stride == 1 && a.pad == 1 && a.lin == a.lout && !a.src_u8 && (a.cin % 8) == 0 &&
            (a.cout % BN) == 0;
@@ -235,6 +352,27 @@ hipError_t launch_conv1d_wino(const ConvArgs& args, hipStream_t stream) {
     // SIMD (4 accumulator tiles per wave, 132 VGPRs) 3.41 ms; 128 pairs (8 tiles, two waves per SIMD) 3.60 ms with
     // 16-channel chunks and 3.84 ms with 8-channel chunks; 8 waves x 128 channels with double-buffered LDS 4.26 ms
     const int variant = (m == 3 ? 6 : 0) + (a.relu < 0 || a.relu > 2 ? 0 : a.relu) * 2 + (a.res ? 1 : 0);
+    // small launches: 16 x 16 blocks per wave, no LDS (conv1d_wino_small_kernel)
+    static const long long cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return (long long)n;
+    }();
+    const long long big_wgs = (tiles + BMP - 1) / BMP * (a.cout / BN);
+    if (big_wgs * SMALL_LAUNCH_DIVISOR <= cus && (a.cin % 16) == 0 && (long long)a.m_total * a.cin * 4 < (1LL << 31)) {
+        const dim3 sgrid((unsigned)((tiles + 15) / 16 * (a.cout / 16)));
+        switch (variant) {
+#define HELLO_WINO_SMALL_CASE(V, MM, ACT, RES) \
+    case V: hipLaunchKernelGGL((conv1d_wino_small_kernel<MM, ACT, RES>), sgrid, dim3(256), 0, stream, a); break;
+            HELLO_WINO_SMALL_CASE(0, 2, 0, false) HELLO_WINO_SMALL_CASE(1, 2, 0, true) HELLO_WINO_SMALL_CASE(2, 2, 1, false)
+            HELLO_WINO_SMALL_CASE(3, 2, 1, true) HELLO_WINO_SMALL_CASE(4, 2, 2, false) HELLO_WINO_SMALL_CASE(5, 2, 2, true)
+            HELLO_WINO_SMALL_CASE(6, 3, 0, false) HELLO_WINO_SMALL_CASE(7, 3, 0, true) HELLO_WINO_SMALL_CASE(8, 3, 1, false)
+            HELLO_WINO_SMALL_CASE(9, 3, 1, true) HELLO_WINO_SMALL_CASE(10, 3, 2, false) HELLO_WINO_SMALL_CASE(11, 3, 2, true)
+#undef HELLO_WINO_SMALL_CASE
+        }
+        return hipGetLastError();
+    }
     switch (variant) {
 #define HELLO_WINO_CASE(V, MM, ACT, RES) \
     case V: hipLaunchKernelGGL((conv1d_wino_kernel<MM, ACT, RES>), grid, dim3(256), 0, stream, a); break;

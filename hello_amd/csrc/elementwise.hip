@@ -292,15 +292,43 @@ __global__ void posteriors_kernel(const float* __restrict__ logits, const float*
         m[2] = meta[3 * s + 2];
     }
     long long pidx = pair_off[s];
+    // log(p tk + (1 - p)(1 - tk) + 1e-10) is log(p + 1e-10) for an allele of the pair and log((1 - p) + 1e-10) otherwise
+    // (p * 1 + (1 - p) * 0 == p exactly): both are taken once per (expert, allele) instead of once per pair -- every
+    // logit requested before the first is used -- and summed per pair in the same allele order: the same bits as the
+    // literal form, which serves sites of more than MAXA alleles
+    constexpr int MAXA = 8;
+    float in_pair[3][MAXA], off_pair[3][MAXA];
+    if (na <= MAXA) {
+        float lg[3][MAXA];
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k) lg[e][k] = (e < n_experts && k < na) ? logits[(long long)e * n_alleles + a0 + k] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k) {
+                const float p = (e < n_experts) ? sigmoidf_(lg[e][k]) : 0.f;
+                in_pair[e][k] = logf(p + 1e-10f);
+                off_pair[e][k] = logf((1.f - p) + 1e-10f);
+            }
+    }
     for (int i = 0; i < na; ++i) {
         for (int j = i; j < na; ++j, ++pidx) {
             float pe[3];
+#pragma unroll
             for (int e = 0; e < 3; ++e) {
                 float acc = 0.f;
-                for (int k = 0; k < na; ++k) {
-                    const float p = (e < n_experts) ? sigmoidf_(logits[(long long)e * n_alleles + a0 + k]) : 0.f;
-                    const float tk = (k == i || k == j) ? 1.f : 0.f;
-                    acc += logf(p * tk + (1.f - p) * (1.f - tk) + 1e-10f);
+                if (na <= MAXA) {
+#pragma unroll
+                    for (int k = 0; k < MAXA; ++k)
+                        if (k < na) acc += (k == i || k == j) ? in_pair[e][k] : off_pair[e][k];
+                } else {
+                    for (int k = 0; k < na; ++k) {
+                        const float p = (e < n_experts) ? sigmoidf_(logits[(long long)e * n_alleles + a0 + k]) : 0.f;
+                        const float tk = (k == i || k == j) ? 1.f : 0.f;
+                        acc += logf(p * tk + (1.f - p) * (1.f - tk) + 1e-10f);
+                    }
                 }
                 pe[e] = expf(acc);
             }

@@ -676,11 +676,13 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ in, float* 
 // The allele-level compressor kernel below instantiates the same layer at 128 channels over 8 items of 18 rows (8 waves):
 // RS (rows per item), the image swizzle and the compact-stacking flag are template parameters defaulting to the read
 // convolver's geometry.
+// PARTIAL: only the wave's first `live_tiles` tiles hold items (a partly filled workgroup of a small launch): the
+// others are neither read, multiplied nor stored.
 template <class CF, int C, int MODE, bool LAST, int RS = (C == 64 ? CF::RS2 : CF::RS1), int SW = (C == 32 ? SW_W : SW_3),
-          bool EDGE = (C != 32)>
+          bool EDGE = (C != 32), bool PARTIAL = false>
 __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float* __restrict__ out, f32x4 (&w)[2][5],
                                             const float* __restrict__ wl, const float* __restrict__ next_wl,
-                                            const float* __restrict__ bias, int wave, int lane) {
+                                            const float* __restrict__ bias, int wave, int lane, int live_tiles = 1 << 30) {
     static_assert(MODE == MODE_PLAIN || MODE == MODE_RESID_INPLACE, "block convolutions only (the strided block's second "
                   "conv finds its shortcut in the output image, like a residual)");
     static_assert(RS % 3 == 0 && (RS * CF::G) % 48 == 0, "image of whole tiles of 16 triples");
@@ -766,7 +768,9 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
     static_for<0, NU>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int m = u / NT, k = u % NT;
-        if constexpr (u + 1 < NU) issue(std::integral_constant<int, u + 1>{});
+        if constexpr (u + 1 < NU) {
+            if (!PARTIAL || (u + 1) % NT < live_tiles) issue(std::integral_constant<int, u + 1>{});
+        }
         if constexpr (k == 0) {                                              // the next group's weights, a group ahead
             const float* nw = (m + 1 < M) ? wl + (m + 1) * 5 * 256 : next_wl;
             if constexpr (m + 1 < M || !LAST) {
@@ -776,8 +780,10 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
         }
         __builtin_amdgcn_sched_barrier(0);
         // the previous tile's epilogue: one block of VALU work + three stores ahead of this step's MFMAs
-        if constexpr (m == M - 1 && k >= 1) epi_store(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
-        {
+        if constexpr (m == M - 1 && k >= 1) {
+            if (!PARTIAL || k - 1 < live_tiles) epi_store(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
+        }
+        if (!PARTIAL || k < live_tiles) {
             const f32x4(&d)[5] = ring[u & 1];
             // one block of packed VALU operations ahead of the step's MFMAs (VALU and MFMA share the issue port)
             const f32x4 s31 = pk_sub(d[3], d[1]);
@@ -805,7 +811,9 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
 #pragma unroll
             for (int r = 0; r < 3; ++r) res[r] = *(const f32x4*)(po[r] + k * TOFF);
         }
-        if constexpr (u == NU - 1) epi_store(std::integral_constant<int, NT - 1>{});
+        if constexpr (u == NU - 1) {
+            if (!PARTIAL || NT - 1 < live_tiles) epi_store(std::integral_constant<int, NT - 1>{});
+        }
     });
 }
 
@@ -1584,21 +1592,31 @@ __global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(Compres
         for (int t = 0; t < CF::NSREG; ++t)
             *(f32x4*)(bufB + img_off_triple<128, SW_3>(t / 3, j, (t % 3) + 1, 4 * wave + q)) = sreg[t];
     }
-    wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L1>(bufA, bufB, w3, slice(CF::off_conv(0)), slice(CF::off_conv(1)),
-                                                        W + CF::off_conv(0) + CF::WB, wave, lane);
-    __syncthreads();
-    static_for<0, NB>([&](auto bc) {
-        constexpr int blk = decltype(bc)::value;
-        constexpr int off_a = CF::off_conv(1 + 2 * blk), off_b = CF::off_conv(2 + 2 * blk);
-        wino3_layer<CF, 128, MODE_PLAIN, false, L1>(bufB, bufA, w3, slice(off_a), slice(off_b), W + off_a + CF::WB, wave, lane);
+    // a partly filled workgroup (the last one of a launch; the only one of a one-site call) skips the F(3,3) tiles that
+    // hold no items: 6 triples per item, 16 per tile
+    const int live_tiles = (6 * n_here + 15) / 16;
+    auto f33_layers = [&](auto partial) {
+        constexpr bool PARTIAL = decltype(partial)::value;
+        wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L1, SW_3, true, PARTIAL>(
+            bufA, bufB, w3, slice(CF::off_conv(0)), slice(CF::off_conv(1)), W + CF::off_conv(0) + CF::WB, wave, lane, live_tiles);
         __syncthreads();
-        if constexpr (blk < NB - 1)
-            wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L1>(bufA, bufB, w3, slice(off_b), slice(CF::off_conv(3 + 2 * blk)),
-                                                                W + off_b + CF::WB, wave, lane);
-        else
-            wino3_layer<CF, 128, MODE_RESID_INPLACE, true, L1>(bufA, bufB, w3, slice(off_b), nullptr, W + off_b + CF::WB, wave, lane);
-        __syncthreads();
-    });
+        static_for<0, NB>([&](auto bc) {
+            constexpr int blk = decltype(bc)::value;
+            constexpr int off_a = CF::off_conv(1 + 2 * blk), off_b = CF::off_conv(2 + 2 * blk);
+            wino3_layer<CF, 128, MODE_PLAIN, false, L1, SW_3, true, PARTIAL>(bufB, bufA, w3, slice(off_a), slice(off_b),
+                                                                            W + off_a + CF::WB, wave, lane, live_tiles);
+            __syncthreads();
+            if constexpr (blk < NB - 1)
+                wino3_layer<CF, 128, MODE_RESID_INPLACE, false, L1, SW_3, true, PARTIAL>(
+                    bufA, bufB, w3, slice(off_b), slice(CF::off_conv(3 + 2 * blk)), W + off_b + CF::WB, wave, lane, live_tiles);
+            else
+                wino3_layer<CF, 128, MODE_RESID_INPLACE, true, L1, SW_3, true, PARTIAL>(bufA, bufB, w3, slice(off_b), nullptr,
+                                                                                       W + off_b + CF::WB, wave, lane, live_tiles);
+            __syncthreads();
+        });
+    };
+    if (live_tiles == L1 * G / 48) f33_layers(std::false_type{});
+    else f33_layers(std::true_type{});
     f32x4* dst = (f32x4*)(a.dst + item0 * (L1 * 128));
     for (int f = tid; f < n_here * L1 * 32; f += CF::THREADS)
         dst[f] = *(const f32x4*)(bufB + img_off<128, SW_3>(1 + (f >> 5), f & 31));
