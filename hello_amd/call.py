@@ -98,62 +98,70 @@ def reference_segment(ref, start: int, stop: int, span: int = FEATURE_LENGTH) ->
 # ------------------------------------------------------------------------------------------------
 # one shard
 # ------------------------------------------------------------------------------------------------
-def score_shard(network, sites: Sequence[shard_io.CandidateSite], include_hp: bool = False,
-                genomes: Optional[Dict[str, str]] = None, feature_length: int = FEATURE_LENGTH):
+def score_shard(network, sites, include_hp: bool = False, genomes: Optional[Dict[str, str]] = None,
+                feature_length: int = FEATURE_LENGTH, keep=None):
     """Featurise and score every site of a shard in one launch each.  -> [(record line | None, .features entry |
-    None)] per site, in order -- what caller_calling.vcfRecords returns per site (:657-754)."""
+    None)] per site, in order -- what caller_calling.vcfRecords returns per site (:657-754).  ``sites``: a
+    ``shards.PackedShard`` (the flat arrays of a shard file: no Python object per read) or a list of
+    ``shards.CandidateSite``; ``keep``: optional per-site booleans, sites marked False are scored but emit nothing."""
     import torch
     from .featurizer import featurize
     eng = network.engine
     prog = eng.program
     hybrid = bool(prog.channels1)
-    if not sites:
+    packed = sites if isinstance(sites, shard_io.PackedShard) else shard_io.PackedShard.from_sites(sites)
+    if packed.n_sites == 0:
         return []
-    if hybrid and any(r1 is None for s in sites for _, _, r1 in s.alleles):
+    if hybrid and not packed.has_reads(1):
         raise ValueError("this model scores two read technologies: every allele of the shard needs both read sets")
     want0 = 7 if include_hp else 6
     if prog.channels0 != want0:
         raise ValueError(f"--include_hp {'set' if include_hp else 'not set'}: the featurizer would write {want0} channels, "
                          f"the model reads {prog.channels0}")
-    dev0, rpa0, aps = featurize(eng, [s.site_reads(0) for s in sites], feature_length, include_hp, device_output=True)
+    dev0, rpa0, aps = featurize(eng, packed.featurizer_arrays(0), feature_length, include_hp, device_output=True)
     dev1 = rpa1 = None
     if hybrid:
-        dev1, rpa1, _ = featurize(eng, [s.site_reads(1) for s in sites], feature_length, prog.channels1 == 7,
-                                  device_output=True)
-    refs = [genomes[s.chromosome] if genomes and s.chromosome in genomes else WindowReference(s.reference, s.window_start)
-            for s in sites]
+        dev1, rpa1, _ = featurize(eng, packed.featurizer_arrays(1), feature_length, prog.channels1 == 7, device_output=True)
+    n = packed.n_sites
+    starts, stops = packed.start.tolist(), packed.stop.tolist()
+    refs = [genomes[c] if genomes and c in genomes else WindowReference(packed.reference(s), int(packed.window_start[s]))
+            for s, c in enumerate(packed.chromosomes)]
     seg = None
     if prog.uses_ref:
-        seg = torch.from_numpy(np.stack([reference_segment(r, s.start, s.stop, feature_length)
-                                         for r, s in zip(refs, sites)])).to(dev0.device)
+        seg = torch.from_numpy(np.stack([reference_segment(refs[s], starts[s], stops[s], feature_length)
+                                         for s in range(n)])).to(dev0.device)
     logits, meta, post = eng.forward(dev0, rpa0, aps, dev1, rpa1, seg, posteriors=True)
-    post = post.cpu().numpy()
+    post = post.cpu().numpy().astype(np.float64).tolist()      # float(np.float32) == the same double
     meta = meta.cpu().numpy() if meta is not None else None
+    no_meta = np.array([1.0, 0.0, 0.0], np.float32)
     out, col = [], 0
-    for s, (site, ref) in enumerate(zip(sites, refs)):
-        keys = pair_keys([a for a, _, _ in site.alleles])
-        n = len(keys)
-        rows = [dict(zip(keys, (float(v) for v in post[r, col:col + n]))) for r in range(4)]
-        col += n
-        m = meta[s] if meta is not None else np.array([1.0, 0.0, 0.0], np.float32)
-        length = site.stop - site.start
-        call = vcf.call_site(rows[0], site.chromosome, site.start, length, ref, info="MixtureOfExpertPrediction")
+    for s in range(n):
+        keys = pair_keys(packed.names(s))
+        k = len(keys)
+        rows = [dict(zip(keys, post[r][col:col + k])) for r in range(4)]
+        col += k
+        if keep is not None and not keep[s]:
+            out.append((None, None))
+            continue
+        length = stops[s] - starts[s]
+        chromosome = packed.chromosomes[s]
+        call = vcf.call_site(rows[0], chromosome, starts[s], length, refs[s], info="MixtureOfExpertPrediction")
         if call is None:                               # no alternative allele at the site: nothing is written (:720-721)
             out.append((None, None))
             continue
-        out.append((call.line(), vcf.feature_record((rows[0], rows[1], rows[2], rows[3], m), site.chromosome,
-                                                    site.start, length)))
+        m = meta[s] if meta is not None else no_meta
+        out.append((call.line(), vcf.feature_record((rows[0], rows[1], rows[2], rows[3], m), chromosome, starts[s], length)))
     return out
 
 
-def run_shard(network, shard_path: str, output_prefix: str, include_hp: bool, genomes, loaded=None) -> Tuple[str, str]:
+def run_shard(network, shard_path: str, output_prefix: str, include_hp: bool, genomes, loaded=None, keep=None) -> Tuple[str, str]:
     """caller_calling.main for one shard (:757-904): -> (features file, log file)."""
     log_path = output_prefix + ".log"
     t0 = time.perf_counter()
     with open(log_path, "w") as log:
-        sites = loaded if loaded is not None else shard_io.read_shard(shard_path)
+        sites = loaded if loaded is not None else shard_io.PackedShard.from_file(shard_path)
         log.write(f"Shard {shard_path}: {len(sites)} candidate sites\n")
-        results = score_shard(network, sites, include_hp, genomes)
+        results = score_shard(network, sites, include_hp, genomes, keep=keep)
         features = []
         with open(output_prefix + ".vcf", "w") as fh:
             for i, (line, feats) in enumerate(results):
@@ -263,19 +271,17 @@ def main(args) -> str:
     network.eval()
     network.providePredictions = True                  # caller_calling.py:865-868
 
-    def load_shard(path):
-        sites = shard_io.read_shard(path)
-        return [s for s in sites if wanted is None or s.chromosome in wanted]
-
     feature_files, logs, windows = [], [], {}
-    # host threads read and unpack shards ahead of the GPU, which scores them one launch at a time, in order
+    # host threads read shards ahead of the GPU, which scores them one launch at a time, in order
     with ThreadPoolExecutor(max_workers=max(1, min(args.num_threads, 8))) as pool:
-        loaded = [pool.submit(load_shard, p) for p in shard_paths]
+        loaded = [pool.submit(shard_io.PackedShard.from_file, p) for p in shard_paths]
         for n, (path, fut) in enumerate(zip(shard_paths, loaded)):
             sites = fut.result()
-            for s in sites:
-                windows[(s.chromosome, s.start)] = (s.reference, s.window_start)
-            ff, lg = run_shard(network, path, os.path.join(features_dir, "features%d" % n), args.include_hp, genomes, sites)
+            keep = None if wanted is None else [c in wanted for c in sites.chromosomes]     # --chromosomes
+            for s in range(sites.n_sites):
+                if keep is None or keep[s]:
+                    windows[(sites.chromosomes[s], int(sites.start[s]))] = (sites.reference(s), int(sites.window_start[s]))
+            ff, lg = run_shard(network, path, os.path.join(features_dir, "features%d" % n), args.include_hp, genomes, sites, keep)
             feature_files.append(ff)
             logs.append(lg)
             logger.info("Completed shard %d of %d (%d sites)", n + 1, len(shard_paths), len(sites))

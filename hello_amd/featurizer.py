@@ -92,8 +92,9 @@ def featurize(engine: Engine, sites: Sequence[SiteReads], feature_length: int = 
               device_output: bool = False):
     """-> (pileups uint8 [sum R, L, C], reads_per_allele int32 [A], alleles_per_site int32 [S]).  With
     ``device_output`` the pileups are a torch CUDA tensor that can go straight into ``Engine.forward``."""
-    p = pack_sites(sites)
-    n_reads, n_sites = int(p["site_of_read"].shape[0]), len(sites)
+    # ``sites``: SiteReads objects, or the already flat arrays of ``pack_sites`` (shards.PackedShard.featurizer_arrays)
+    p = sites if isinstance(sites, dict) else pack_sites(sites)
+    n_reads, n_sites = int(p["site_of_read"].shape[0]), int(p["alleles_per_site"].shape[0])
     channels = 7 if include_hp else 6
     flags = 0
     if device_output:

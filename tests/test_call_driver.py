@@ -93,6 +93,30 @@ def test_shard_round_trip(tmp_path):
                 assert (r1 is None) == (q1 is None) and (r1 is None or len(r1) == len(q1))
 
 
+@pytest.mark.parametrize("hybrid,tagged", [(False, False), (True, True)])
+def test_packed_shard_arrays_equal_the_unpacked_sites(tmp_path, hybrid, tagged):
+    """The driver keeps a shard as the flat arrays of its file (shards.PackedShard): the featurizer arrays it derives by
+    index arithmetic -- dummy reads for unsupported alleles included -- are element for element what pack_sites builds
+    from the unpacked AlignedRead objects, and the per-site metadata is the sites'."""
+    from hello_amd import featurizer
+    rng = np.random.default_rng(31)
+    sites = random_sites(rng, 60, hybrid=hybrid, tagged=tagged)
+    assert any(len(r0) == 0 for s in sites for _, r0, _ in s.alleles)          # alleles without supporting reads
+    path = shards.write_shard(str(tmp_path / "s.npz"), sites)
+    for packed in (shards.PackedShard.from_file(path), shards.PackedShard.from_sites(sites)):
+        assert len(packed) == len(sites) and packed.hybrid == hybrid and packed.has_reads(1) == hybrid
+        for tech in ((0, 1) if hybrid else (0,)):
+            want = featurizer.pack_sites([s.site_reads(tech) for s in sites])
+            got = packed.featurizer_arrays(tech)
+            assert set(got) == set(want)
+            for k in want:
+                assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), k
+        for i, s in enumerate(sites):
+            assert (packed.chromosomes[i], int(packed.start[i]), int(packed.stop[i]), int(packed.window_start[i])) == \
+                   (s.chromosome, s.start, s.stop, s.window_start)
+            assert packed.names(i) == [a for a, _, _ in s.alleles] and packed.reference(i) == s.reference
+
+
 def test_fasta_and_window_reference(tmp_path):
     path = tmp_path / "g.fa"
     path.write_text(">chr1 first\nACGTAC\nGTTT\n>chr2\nGGGG\nCC\n>chrUn\nNNNN\n")
