@@ -96,6 +96,11 @@ def main():
     driver.score_shard(net, packed_shard)
     t9 = time.perf_counter()
     del arrays
+    repeats = []
+    for _ in range(4):
+        ta = time.perf_counter()
+        driver.score_shard(net, packed_shard)
+        repeats.append(time.perf_counter() - ta)
     us = lambda dt: 1e6 * dt / args.sites                                 # noqa: E731
     print(f"{args.sites} sites, {n_reads} reads ({n_reads / args.sites:.1f} per site); synthesis {t_synth:.2f} s (not a stage)")
     print(f"  site_reads() views            {us(t1 - t0):8.1f} us/site")
@@ -106,6 +111,8 @@ def main():
     print(f"  score_shard from site objects {us(t7 - t6):8.1f} us/site = {args.sites / (t7 - t6):,.0f} sites/s per host process")
     print(f"  PackedShard.featurizer_arrays {us(t8 - t7):8.1f} us/site")
     print(f"  score_shard from a PackedShard{us(t9 - t8):8.1f} us/site = {args.sites / (t9 - t8):,.0f} sites/s per host process")
+    print("  ... four more times            " + ", ".join(f"{us(r):.1f}" for r in repeats) +
+          f" us/site (best {args.sites / min(repeats):,.0f} sites/s)")
     net.close()
 
 
