@@ -19,7 +19,9 @@ sys.path.insert(0, ROOT)
 from hello_amd import call as driver, featurizer, netspec as ns, shards, vcf, weights  # noqa: E402
 from hello_amd.featurizer import AlignedRead  # noqa: E402
 from hello_amd.wrapper import ScoringNetwork, pair_keys  # noqa: E402
-from oracle import featurizer_oracle as fo  # noqa: E402  (the CIGAR op codes only)
+
+
+BAM_CMATCH = 0                                   # pysam / BAM CIGAR operation code of an alignment match
 
 
 def synth_sites(rng, n, coverage):
@@ -39,7 +41,7 @@ def synth_sites(rng, n, coverage):
                 n_bases = 150
                 st = start - int(rng.integers(20, 130))
                 reads.append(AlignedRead("".join(rng.choice(list("ACGT"), size=n_bases)), rng.integers(2, 60, size=n_bases).tolist(),
-                                         [(fo.BAM_CMATCH, n_bases)], st, mapq=int(rng.integers(0, 80)),
+                                         [(BAM_CMATCH, n_bases)], st, mapq=int(rng.integers(0, 80)),
                                          orientation=int(rng.choice([-1, 1])), hp=0))
             alleles.append((a, reads, None))
         sites.append(shards.CandidateSite("chr1", start, start + 1, reference, window_start, alleles))
