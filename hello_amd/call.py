@@ -10,14 +10,23 @@ script`` (:225-229) and lets ``prepareVcf.main`` build the final VCF from the ``
 
 This driver keeps that contract from the point where a shard's candidate sites exist (``hello_amd.shards``: BAM /
 FASTA ingestion, hotspot detection and allele assembly need pysam and the C++ searcher and stay upstream), and runs
-everything after it on the GPU, a whole shard per launch:
+everything after it at the engine's rate (``hello_amd.shard_pipeline``): reader threads load shards with bounded
+read-ahead; several shards are coalesced into one GPU launch
 
-    reads + CIGARs --hello_engine_featurize--> uint8 pileups (device) --Engine.forward--> logits, meta, pair
-    posteriors --> per site: record line (caller_calling.py:698-743) + ``.features`` entry (:743-754)
+    reads + CIGARs --hello_engine_featurize--> uint8 pileups (device) --hello_engine_forward--> logits, meta, pair
+    posteriors --hello_site_records (host threads)--> record lines (caller_calling.py:698-743), ``.features`` entries
+    (:743-754), final-VCF lines (prepareVcf.py:138-168)
 
-and writes, per shard N, ``<workdir>/<features dir>/features<N>.vcf``, ``features<N>.features`` (the pickle
-``prepareVcf`` reads) and ``features<N>.log`` ending in the sentinel; then ``<workdir>/results.output.vcf`` from the
+while the previous launch's records are written and the next one's bytes are staged.  Per shard N it writes
+``<workdir>/<features dir>/features<N>.vcf``, ``features<N>.features`` (the pickle ``prepareVcf`` reads),
+``features<N>.log`` ending in the sentinel and ``features<N>.mean.vcf``; then ``<workdir>/results.output.vcf`` from the
 meta-weighted mean of the experts (prepareVcf.py:126-176,199-260; sorted in process instead of by ``vcf-sort``).
+
+``--gpus N`` (or a launch under ``python -m torch.distributed.run``) runs one process per GPU: the shard files are dealt
+to the ranks as contiguous runs balanced by read count (``hello_amd.shard.partition_sites`` over per-shard read
+totals), every rank writes its shards' files, and after ONE barrier rank 0 merges the final VCF from the files and the
+ranks' key indexes -- the ranks exchange no pileup or posterior data (the reference's pool does not either,
+call.py:215-221).
 Flags of the reference that configure upstream stages (--hybrid_hotspot, --q_threshold, --mapq_threshold,
 --reconcilement_size, --chromosomes) are accepted so existing command lines keep working; --ibam / --pbam only name
 the features directory the way ``get_workdir`` does (call.py:40-48).
@@ -29,9 +38,10 @@ import glob
 import logging
 import os
 import pickle
+import re
+import subprocess
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -40,7 +50,7 @@ from . import shards as shard_io
 from . import vcf
 from .wrapper import pair_keys
 
-SENTINEL = "Completed running the script"            # caller_calling.py:902, checked by call.py:225-229
+from .shard_pipeline import SENTINEL                 # caller_calling.py:902, checked by call.py:225-229  # noqa: E402
 FEATURE_LENGTH = 150                                 # call.py:187
 
 
@@ -89,7 +99,9 @@ def reference_segment(ref, start: int, stop: int, span: int = FEATURE_LENGTH) ->
     """caller_calling.py:53-97 (get_reference_segment + one_hot_encode): uint8 [span, 5], ACGT + other."""
     mid = (start + stop) // 2
     left = mid - span // 2
-    seg = ref[left:left + span]
+    seg = ref[left:left + span] if left >= 0 else ""
+    if len(seg) != span:            # the reference's one_hot_encode yields a short tensor here and the network call fails
+        raise ValueError(f"the {span} bp reference segment around [{start}, {stop}) leaves the sequence (it starts at {left})")
     out = np.zeros((span, 5), np.uint8)
     out[np.arange(len(seg)), ["ACGT".find(b) if b in "ACGT" else 4 for b in seg]] = 1
     return out
@@ -98,82 +110,49 @@ def reference_segment(ref, start: int, stop: int, span: int = FEATURE_LENGTH) ->
 # ------------------------------------------------------------------------------------------------
 # one shard
 # ------------------------------------------------------------------------------------------------
+def _genome_bytes(genomes: Optional[Dict[str, str]]) -> Optional[Dict[str, bytes]]:
+    return {k: (v if isinstance(v, bytes) else v.encode("ascii")) for k, v in genomes.items()} if genomes else None
+
+
 def score_shard(network, sites, include_hp: bool = False, genomes: Optional[Dict[str, str]] = None,
                 feature_length: int = FEATURE_LENGTH, keep=None):
-    """Featurise and score every site of a shard in one launch each.  -> [(record line | None, .features entry |
-    None)] per site, in order -- what caller_calling.vcfRecords returns per site (:657-754).  ``sites``: a
-    ``shards.PackedShard`` (the flat arrays of a shard file: no Python object per read) or a list of
-    ``shards.CandidateSite``; ``keep``: optional per-site booleans, sites marked False are scored but emit nothing."""
-    import torch
-    from .featurizer import featurize
-    eng = network.engine
-    prog = eng.program
-    hybrid = bool(prog.channels1)
-    packed = sites if isinstance(sites, shard_io.PackedShard) else shard_io.PackedShard.from_sites(sites)
+    """Featurise and score every site of ONE shard in one launch, synchronously (the building block under test; the
+    driver itself streams shards through ``shard_pipeline.run``).  -> [(record line | None, .features entry | None)] per
+    site, in order -- what caller_calling.vcfRecords returns per site (:657-754).  ``sites``: a ``shards.PackedShard``
+    or a list of ``shards.CandidateSite``; ``keep``: optional per-site booleans, sites marked False are scored but emit
+    nothing."""
+    from . import records as rec
+    from .shard_pipeline import ShardScorer, prepare, site_table
+    packed = sites if isinstance(sites, shard_io.PackedShard) else shard_io.PackedShard.from_sites(sites, feature_length)
     if packed.n_sites == 0:
         return []
-    if hybrid and not packed.has_reads(1):
-        raise ValueError("this model scores two read technologies: every allele of the shard needs both read sets")
-    want0 = 7 if include_hp else 6
-    if prog.channels0 != want0:
-        raise ValueError(f"--include_hp {'set' if include_hp else 'not set'}: the featurizer would write {want0} channels, "
-                         f"the model reads {prog.channels0}")
-    dev0, rpa0, aps = featurize(eng, packed.featurizer_arrays(0), feature_length, include_hp, device_output=True)
-    dev1 = rpa1 = None
-    if hybrid:
-        dev1, rpa1, _ = featurize(eng, packed.featurizer_arrays(1), feature_length, prog.channels1 == 7, device_output=True)
-    n = packed.n_sites
-    starts, stops = packed.start.tolist(), packed.stop.tolist()
-    refs = [genomes[c] if genomes and c in genomes else WindowReference(packed.reference(s), int(packed.window_start[s]))
-            for s, c in enumerate(packed.chromosomes)]
-    seg = None
-    if prog.uses_ref:
-        seg = torch.from_numpy(np.stack([reference_segment(refs[s], starts[s], stops[s], feature_length)
-                                         for s in range(n)])).to(dev0.device)
-    logits, meta, post = eng.forward(dev0, rpa0, aps, dev1, rpa1, seg, posteriors=True)
-    post = post.cpu().numpy().astype(np.float64).tolist()      # float(np.float32) == the same double
-    meta = meta.cpu().numpy() if meta is not None else None
-    no_meta = np.array([1.0, 0.0, 0.0], np.float32)
-    out, col = [], 0
-    for s in range(n):
-        keys = pair_keys(packed.names(s))
-        k = len(keys)
-        rows = [dict(zip(keys, post[r][col:col + k])) for r in range(4)]
-        col += k
-        if keep is not None and not keep[s]:
-            out.append((None, None))
-            continue
-        length = stops[s] - starts[s]
-        chromosome = packed.chromosomes[s]
-        call = vcf.call_site(rows[0], chromosome, starts[s], length, refs[s], info="MixtureOfExpertPrediction")
-        if call is None:                               # no alternative allele at the site: nothing is written (:720-721)
-            out.append((None, None))
-            continue
-        m = meta[s] if meta is not None else no_meta
-        out.append((call.line(), vcf.feature_record((rows[0], rows[1], rows[2], rows[3], m), chromosome, starts[s], length)))
+    scorer = getattr(network, "_shard_scorer", None)
+    if scorer is None or scorer.L != feature_length:
+        scorer = network._shard_scorer = ShardScorer(network, include_hp, feature_length)
+    elif scorer.channels[0] != (7 if include_hp else 6):
+        raise ValueError(f"--include_hp {'set' if include_hp else 'not set'}: the featurizer would write {7 if include_hp else 6} "
+                         f"channels, the model reads {scorer.channels[0]}")
+    prepare(packed, scorer.hybrid, scorer.uses_ref)
+    done = scorer.submit([packed]) + scorer.flush()
+    scored = done[-1]
+    table = site_table([packed], _genome_bytes(genomes), keep=None if keep is None else np.asarray(keep, np.uint8))
+    with rec.site_records(table, scored.posteriors, scored.meta, None, features=True) as r:
+        entries = iter(pickle.loads(bytes(r.features)))
+        out = []
+        for s in range(packed.n_sites):
+            lo, hi = int(r.shard_vcf_off[s]), int(r.shard_vcf_off[s + 1])
+            out.append((bytes(r.shard_vcf[lo:hi - 1]).decode("ascii"), next(entries)) if hi > lo else (None, None))
     return out
 
 
-def run_shard(network, shard_path: str, output_prefix: str, include_hp: bool, genomes, loaded=None, keep=None) -> Tuple[str, str]:
-    """caller_calling.main for one shard (:757-904): -> (features file, log file)."""
-    log_path = output_prefix + ".log"
-    t0 = time.perf_counter()
-    with open(log_path, "w") as log:
-        sites = loaded if loaded is not None else shard_io.PackedShard.from_file(shard_path)
-        log.write(f"Shard {shard_path}: {len(sites)} candidate sites\n")
-        results = score_shard(network, sites, include_hp, genomes, keep=keep)
-        features = []
-        with open(output_prefix + ".vcf", "w") as fh:
-            for i, (line, feats) in enumerate(results):
-                if line is not None:
-                    fh.write(line + "\n")
-                    features.append(feats)
-                if (i + 1) % 100 == 0:
-                    log.write("Completed %d sites\n" % (i + 1))
-        vcf.write_features(output_prefix + ".features", features)
-        log.write(f"Scored {len(sites)} sites, {len(features)} records in {time.perf_counter() - t0:.3f} s\n")
-        log.write(SENTINEL + "\n")
-    return output_prefix + ".features", log_path
+def shard_number(path: str, fallback: int) -> int:
+    """The N of the reference's ``shard<N>.txt`` / ``features<N>`` (call.py:162-221): the digits that end the file's stem."""
+    m = re.search(r"(\d+)$", os.path.splitext(os.path.basename(path))[0])
+    return int(m.group(1)) if m else fallback
+
+
+def natural_key(path: str):
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -242,14 +221,57 @@ def parser() -> argparse.ArgumentParser:
     ap.add_argument("--hybrid_hotspot", default=False, action="store_true", help="(upstream stage; accepted)")
     ap.add_argument("--q_threshold", default=10, type=int, help="(upstream stage; accepted)")
     ap.add_argument("--mapq_threshold", default=10, type=int, help="(upstream stage; accepted)")
-    ap.add_argument("--num_threads", type=int, default=30, help="host threads reading shards ahead of the GPU")
+    ap.add_argument("--num_threads", type=int, default=30,
+                    help="host threads per GPU: shard readers and the record stage share them (the reference's pool size)")
     ap.add_argument("--reconcilement_size", default=10, type=int, help="(upstream stage; accepted)")
     ap.add_argument("--include_hp", default=False, action="store_true", help="Include HP tags in tensors")
     ap.add_argument("--shards", required=False,
                     help="glob (or directory) of pre-extracted candidate-site shards (hello_amd.shards), one per "
                          "reference shard<N>.txt")
-    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--device", type=int, default=0, help="GPU of a single-process run")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="processes / GPUs of this node: > 1 re-launches this command under torch.distributed.run "
+                         "(a launch that is already under it reads RANK / WORLD_SIZE instead)")
+    ap.add_argument("--sites_per_launch", type=int, default=8192, help="shards are coalesced into GPU launches of about this many sites")
     return ap
+
+
+def _argv_of(args) -> List[str]:
+    argv: List[str] = []
+    for action in parser()._actions:
+        if not action.option_strings or action.dest in ("help", "gpus"):
+            continue
+        value = getattr(args, action.dest, None)
+        if value is None or value is False:
+            continue
+        argv += [action.option_strings[0]] + ([] if value is True else [str(value)])
+    return argv
+
+
+def _launch_ranks(args) -> int:
+    """``--gpus N`` from a plain command line: one child process per GPU under torch.distributed.run, started BEFORE this
+    process touches the GPU; this process only waits for them."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "hello_amd.call"] + _argv_of(args) + ["--gpus", str(args.gpus)]
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode
+
+
+def shard_read_totals(paths: Sequence[str], threads: int = 4) -> np.ndarray:
+    """Reads the featurizer will write per shard (both technologies; dummy reads included): the weight shards are dealt
+    to ranks by.  Only the count arrays of each file are read."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def total(path):
+        if path.endswith(".npz"):
+            with np.load(path, allow_pickle=False) as z:
+                return sum(int(np.maximum(z[k], 1).sum()) for k in ("reads_per_allele0", "reads_per_allele1") if k in z.files)
+        return sum(int(np.maximum(a, 1).sum()) for k, a in shard_io.read_flat_arrays(path, ("reads_per_allele0", "reads_per_allele1")).items())
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        return np.array(list(pool.map(total, paths)), np.int64)
 
 
 def main(args) -> str:
@@ -258,46 +280,82 @@ def main(args) -> str:
         raise SystemExit("--shards is required: BAM / FASTA ingestion, hotspot detection and allele assembly are upstream of "
                          "this engine (SURVEY.md section 2, rows 9-13); extract candidate-site shards with the reference's "
                          "searcher and hello_amd.shards.write_shard")
-    shard_paths = sorted(glob.glob(os.path.join(args.shards, "*.npz")) if os.path.isdir(args.shards) else glob.glob(args.shards))
+    result_path = os.path.join(args.workdir, "results.output.vcf")
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if getattr(args, "gpus", 1) > 1 and not under_launcher:
+        rc = _launch_ranks(args)
+        if rc != 0:
+            raise SystemExit(rc)
+        return result_path
+    rank, world = (int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])) if under_launcher else (0, 1)
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+
+    shard_paths = sorted((glob.glob(os.path.join(args.shards, "*.hshard")) + glob.glob(os.path.join(args.shards, "*.npz")))
+                         if os.path.isdir(args.shards) else glob.glob(args.shards), key=natural_key)
     if not shard_paths:
         raise SystemExit(f"no shard matches {args.shards!r}")
+    numbers = [shard_number(p, i) for i, p in enumerate(shard_paths)]
+    if len(set(numbers)) != len(numbers):                # names that do not end in distinct numbers: number them in order
+        numbers = list(range(len(shard_paths)))
     features_dir = os.path.join(args.workdir, features_dir_name(args.ibam, args.pbam))
     os.makedirs(features_dir, exist_ok=True)
     wanted = set(args.chromosomes.split(",")) if args.chromosomes else None
     genomes = read_fasta(args.ref, wanted) if args.ref else {}
 
+    import torch
+    from . import shard as sharding, shard_pipeline as sp
+    lo, hi = 0, len(shard_paths)
+    device = args.device
+    threads = max(2, min(args.num_threads, len(os.sched_getaffinity(0))))
+    if world > 1:
+        import torch.distributed as dist
+        device = local_rank % max(torch.cuda.device_count(), 1)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        threads = max(2, min(args.num_threads, len(sharding.pin_rank(local_rank, local_world, device))))
+        # control plane only (shard totals, the end-of-run barrier): no tensor leaves a rank, so gloo serves every backend
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        mine = shard_read_totals(shard_paths[rank::world], threads)
+        gathered: List = [None] * world
+        dist.all_gather_object(gathered, mine)
+        totals = np.zeros(len(shard_paths), np.int64)
+        for r, part in enumerate(gathered):
+            totals[r::world] = part
+        lo, hi = sharding.partition_sites(totals, world)[rank]
+        logger.info("rank %d of %d: shards [%d, %d) of %d, %d reads of %d, GPU %d, %d host threads", rank, world, lo, hi,
+                    len(shard_paths), int(totals[lo:hi].sum()), int(totals.sum()), device, threads)
+
     from .loader import load
-    network = load(args.network, device=args.device)
+    network = load(args.network, device=device)
     network.eval()
     network.providePredictions = True                  # caller_calling.py:865-868
-
-    feature_files, logs, windows = [], [], {}
-    # host threads read shards ahead of the GPU, which scores them one launch at a time, in order
-    with ThreadPoolExecutor(max_workers=max(1, min(args.num_threads, 8))) as pool:
-        loaded = [pool.submit(shard_io.PackedShard.from_file, p) for p in shard_paths]
-        for n, (path, fut) in enumerate(zip(shard_paths, loaded)):
-            sites = fut.result()
-            keep = None if wanted is None else [c in wanted for c in sites.chromosomes]     # --chromosomes
-            for s in range(sites.n_sites):
-                if keep is None or keep[s]:
-                    windows[(sites.chromosomes[s], int(sites.start[s]))] = (sites.reference(s), int(sites.window_start[s]))
-            ff, lg = run_shard(network, path, os.path.join(features_dir, "features%d" % n), args.include_hp, genomes, sites, keep)
-            feature_files.append(ff)
-            logs.append(lg)
-            logger.info("Completed shard %d of %d (%d sites)", n + 1, len(shard_paths), len(sites))
+    readers = max(1, min(threads // 2, 8))
+    t0 = time.perf_counter()
+    stats = sp.run(network, shard_paths[lo:hi], lambda n: os.path.join(features_dir, "features%d" % n), args.include_hp,
+                   _genome_bytes(genomes), wanted, reader_threads=readers, record_threads=max(1, threads - readers),
+                   sites_per_launch=getattr(args, "sites_per_launch", 8192), tags=numbers[lo:hi])
     network.close()
-    for lg in logs:                                     # call.py:225-229
-        if SENTINEL not in open(lg).read():
-            raise ValueError("Did not run: log file %s doesn't have termination string" % lg)
-
-    def genome_of(rec):
-        if rec["chromosome"] in genomes:
-            return genomes[rec["chromosome"]]
-        return WindowReference(*windows[(rec["chromosome"], rec["position"])])
-    result = prepare_vcf(feature_files, os.path.join(args.workdir, "results.output.vcf"), genome_of,
-                         {c: len(g) for c, g in genomes.items()})
-    logger.info("Completed runs. Results in %s", result)
-    return result
+    logger.info("rank %d: %d shards, %d sites, %d reads in %d launches, %.2f s (%.0f sites/s; waiting for readers %.2f s, "
+                "staging %.2f s, record stage %.2f s on its thread)", rank, hi - lo, stats.sites, stats.reads, stats.launches,
+                stats.seconds, stats.sites / max(stats.seconds, 1e-9), stats.wait_read, stats.stage_seconds, stats.record_seconds)
+    for out in stats.outputs:                           # call.py:225-229
+        if SENTINEL not in open(out.prefix + ".log").read():
+            raise ValueError("Did not run: log file %s doesn't have termination string" % (out.prefix + ".log"))
+    outputs = stats.outputs
+    if world > 1:
+        import torch.distributed as dist
+        sp.save_index(os.path.join(features_dir, "mean_index.rank%d.npz" % rank), outputs)
+        dist.barrier()                                  # THE synchronisation of the run: every rank's files are complete
+        if rank == 0:
+            outputs = [o for r in range(world) for o in sp.load_index(os.path.join(features_dir, "mean_index.rank%d.npz" % r))]
+    if rank == 0:
+        lengths = {c: len(g) for c, g in genomes.items()}
+        n = sp.merge_final_vcf(outputs, lambda names: header(names, lengths), result_path)
+        logger.info("Completed runs in %.2f s. %d records in %s", time.perf_counter() - t0, n, result_path)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return result_path
 
 
 if __name__ == "__main__":

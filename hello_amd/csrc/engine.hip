@@ -25,6 +25,23 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+namespace hello {
+// the same thread-local message, for the other translation units of the library (records.hip)
+int set_last_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+}  // namespace hello
+
+namespace {
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \

@@ -48,11 +48,16 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeaturizeArgs a) {
         const int C = a.channels;
         const int s = a.site_of_read[r];
         const long long wstart = a.window_start[s];
-        const unsigned char* ref = a.ref + a.ref_off[s];
+        const unsigned char* ref_text = a.ref + a.ref_off[s];
+        const long long ref_len = a.ref_off[s + 1] - a.ref_off[s];
+        // device-side guard (host callers are validated, hello_amd/shards.py): a position outside the site's reference
+        // window reads as "no base", a CIGAR that runs past its read stops painting
+        auto ref_at = [&](long long i) -> unsigned char { return (i >= 0 && i < ref_len) ? ref_text[i] : (unsigned char)0; };
         const long long as0 = a.asm_start[s], as1 = a.asm_stop[s];
         const long long start = (as0 + as1) / 2 - a.length / 2, end = start + a.length;
         const unsigned char* bases = a.bases + a.read_off[r];
         const unsigned char* quals = a.quals + a.read_off[r];
+        const long long read_len = a.read_off[r + 1] - a.read_off[r];
         const int mapq_c = quality_color(a.mapq[r], 60);
         const int strand_c = a.orientation[r] > 0 ? 70 : 240;                   // :1002-1005
         const int hp = a.hp[r];
@@ -68,10 +73,10 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeaturizeArgs a) {
             if (op == BAM_CMATCH || op == BAM_CEQUAL || op == BAM_CDIFF) {     // :1074-1096
                 for (long long j = lane; j < len; j += 64) {
                     const long long pos = rf + j;
-                    if (start <= pos && pos < end) {
+                    if (start <= pos && pos < end && rp + j < read_len) {
                         volatile unsigned char* px = row + (pos - start) * C;
                         px[0] = (unsigned char)base_color(bases[rp + j]);
-                        px[1] = (unsigned char)base_color(ref[pos - wstart]);
+                        px[1] = (unsigned char)base_color(ref_at(pos - wstart));
                         px[2] = (unsigned char)quality_color(quals[rp + j], 40);
                         px[3] = (unsigned char)mapq_c;
                         px[4] = (unsigned char)strand_c;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeaturizeArgs a) {
                     for (long long i = rf - 1 + lane; i < rf + len; i += 64) {
                         if (start <= i && i < end) {
                             volatile unsigned char* px = row + (i - start) * C;
-                            px[1] = (unsigned char)base_color(ref[i - wstart]);
+                            px[1] = (unsigned char)base_color(ref_at(i - wstart));
                             px[3] = (unsigned char)mapq_c;
                             px[4] = (unsigned char)strand_c;
                             px[5] = (unsigned char)position_color(i - wstart);
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeaturizeArgs a) {
                     if (lane == 0) {
                         volatile unsigned char* px = row + (rf - 1 - start) * C;
                         px[0] = 0;                                               // gap colour
-                        px[2] = (unsigned char)(rp > 0 ? quality_color(quals[rp - 1], 40) : 0);
+                        px[2] = (unsigned char)((rp > 0 && rp <= read_len) ? quality_color(quals[rp - 1], 40) : 0);
                     }
                 }
                 rf += len;
@@ -105,10 +110,10 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeaturizeArgs a) {
             } else if (op == BAM_CINS) {                                        // :1131-1160 (+ fall-through :1161)
                 if (start <= rf - 1 && rf - 1 < end && lane == 0) {
                     int qmin = 255;
-                    for (long long k = (rp > 0 ? rp - 1 : rp); k < rp + len; ++k) qmin = quals[k] < qmin ? quals[k] : qmin;
+                    for (long long k = (rp > 0 ? rp - 1 : rp); k < rp + len && k < read_len; ++k) qmin = quals[k] < qmin ? quals[k] : qmin;
                     volatile unsigned char* px = row + (rf - 1 - start) * C;
                     px[0] = 0;
-                    px[1] = (unsigned char)base_color(ref[rf - 1 - wstart]);
+                    px[1] = (unsigned char)base_color(ref_at(rf - 1 - wstart));
                     px[2] = (unsigned char)quality_color(qmin, 40);
                     px[3] = (unsigned char)mapq_c;
                     px[4] = (unsigned char)strand_c;

@@ -121,3 +121,20 @@ def featurize(engine: Engine, sites: Sequence[SiteReads], feature_length: int = 
     else:
         launch(None)
     return out, p["reads_per_allele"], p["alleles_per_site"]
+
+
+FEATURIZE_ARRAYS = ("bases", "quals", "read_off", "cigars", "cigar_off", "ref_start", "mapq", "orientation", "hp", "site_of_read",
+                    "ref", "ref_off", "window_start", "asm_start", "asm_stop")          # hello_engine_featurize's order
+
+
+def featurize_device(engine: Engine, pointers: dict, n_reads: int, n_sites: int, feature_length: int, channels: int,
+                     out_pointer: int, stream: int):
+    """``hello_engine_featurize`` on arrays ALREADY in device memory (``pointers``: name of FEATURIZE_ARRAYS -> device
+    address), asynchronous on ``stream`` -- the staged form the shard pipeline uses (one H2D copy per launch carries all
+    fifteen arrays)."""
+    fn = engine.lib.hello_engine_featurize
+    fn.restype = C.c_int
+    vp = C.c_void_p
+    fn.argtypes = [vp] * 16 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, vp]
+    _check(fn(engine.handle, *[pointers[k] for k in FEATURIZE_ARRAYS], n_reads, n_sites, feature_length, channels,
+              out_pointer, HELLO_IN_DEVICE | HELLO_OUT_DEVICE, stream))

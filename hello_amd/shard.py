@@ -140,28 +140,45 @@ def _parse_cpulist(text: str) -> List[int]:
     return cpus
 
 
-def rank_cpus(local_rank: int, local_world: int, device_index: Optional[int] = None) -> List[int]:
-    """CPUs one rank's host threads (pinned staging copies, CSR building) should run on: an equal share of
-    the CPUs this process may use, taken from the NUMA node of the rank's GPU when sysfs tells it (the ranks
-    on the same node split that node's CPUs), else a plain equal split of the affinity mask."""
+def _gpu_numa_node(device_index: int) -> int:
+    """NUMA node of a GPU from sysfs, -1 when unknown."""
+    try:
+        import torch
+        prop = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
+        return int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+    except Exception:
+        return -1
+
+
+def rank_cpus(local_rank: int, local_world: int, device_index: Optional[int] = None,
+              node_of_device=None, cpus_of_node=None, n_devices: Optional[int] = None) -> List[int]:
+    """CPUs one rank's host threads (pinned staging copies, CSR building, shard readers, the record stage) should run
+    on.  Local rank r drives GPU r modulo the number of GPUs; when sysfs names the NUMA node of those GPUs, the ranks
+    whose GPUs sit on the same node split THAT node's CPUs evenly, by the rank's index among them -- every CPU of a
+    node with GPUs goes to exactly one rank.  Otherwise a plain equal split of the affinity mask.  ``node_of_device`` /
+    ``cpus_of_node`` / ``n_devices`` replace the sysfs and device queries (tests)."""
     allowed = sorted(os.sched_getaffinity(0))
-    node_cpus = None
+    pool, index, sharers = allowed, local_rank, max(local_world, 1)
     if device_index is not None:
         try:
-            import torch
-            prop = torch.cuda.get_device_properties(device_index)
-            bdf = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
-            node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
-            if node >= 0:
-                node_cpus = [c for c in _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
-                             if c in set(allowed)]
+            if n_devices is None:
+                import torch
+                n_devices = max(torch.cuda.device_count(), 1)
+            node_of_device = node_of_device or _gpu_numa_node
+            if cpus_of_node is None:
+                def cpus_of_node(node):
+                    return _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+            nodes = [node_of_device(r % n_devices) for r in range(local_world)]
+            node = nodes[local_rank]
+            cpus = [c for c in cpus_of_node(node) if c in set(allowed)] if node >= 0 else []
+            if cpus:
+                same = [r for r in range(local_world) if nodes[r] == node]
+                pool, index, sharers = cpus, same.index(local_rank), len(same)
         except Exception:
-            node_cpus = None
-    pool = node_cpus if node_cpus else allowed
-    share = max(1, len(pool) // max(local_world, 1))
-    start = (local_rank % max(1, len(pool) // share)) * share
-    mine = pool[start:start + share]
-    return mine or allowed
+            pool, index, sharers = allowed, local_rank, max(local_world, 1)
+    lo, hi = len(pool) * index // sharers, len(pool) * (index + 1) // sharers
+    return pool[lo:hi] or pool or allowed
 
 
 def pin_rank(local_rank: int, local_world: int, device_index: Optional[int] = None) -> List[int]:

@@ -235,6 +235,69 @@ int hello_engine_debug_read(hello_engine* engine, float* out, int64_t capacity, 
 
 void hello_engine_destroy(hello_engine* engine);
 
+/* ---- record stage (host only: no engine, no GPU) ---------------------------------------------------------------------
+ * Stands in for, per site of a whole launch and on `n_threads` host threads:
+ *   - caller_calling.vcfRecords' decision and record (python/caller_calling.py:698-743: best pair of the mixture row,
+ *     QUAL = -10 log10(1 - min(p, 1 - 1e-8)), ALT list, genotype, createVcfRecord normalisation
+ *     python/vcfFromContigs.py:139-227) with INFO "MixtureOfExpertPrediction" -> the shard's `.vcf` lines;
+ *   - its `.features` entry (:743-754) as one pickle stream per shard (the list prepareVcf.py:138 loads);
+ *   - prepareVcf.vcfRecords' call on the meta-weighted mean of the experts in float64 (python/prepareVcf.py:154-168) with
+ *     INFO "HELLO" -> the lines of the final VCF, with their normalised positions for the final sort;
+ *   - the best pair / probability / QUAL of all five rows (mixture, expert 0..2, mean).
+ * ALT alleles are written in sorted order; equal pair probabilities are ordered by the pair's allele strings, as Python's
+ * sort of (value, key) tuples orders them.  A site whose `keep` byte is 0 is decided but emits nothing. */
+typedef struct hello_site_table {
+    int32_t n_sites;
+    const int32_t* alleles_per_site;         /* [S] */
+    const uint8_t* allele_text;              /* every allele string of every site, concatenated (ASCII) */
+    const int64_t* allele_text_off;          /* [A + 1] */
+    int32_t n_chromosomes;
+    const uint8_t* chromosome_text;          /* chromosome names, concatenated */
+    const int64_t* chromosome_text_off;      /* [n_chromosomes + 1] */
+    const int32_t* chromosome_of_site;       /* [S] index into the names */
+    const int64_t* start;                    /* [S] allele span [start, stop) in genome coordinates (0-based) */
+    const int64_t* stop;
+    const uint8_t* ref_windows;              /* per-site reference windows, concatenated (or NULL with `genome`) */
+    const int64_t* ref_window_off;           /* [S + 1] */
+    const int64_t* window_start;             /* [S] genome position of each window's first byte */
+    const uint8_t* const* genome;            /* [n_chromosomes] whole sequences (entries may be NULL) or NULL */
+    const int64_t* genome_len;               /* [n_chromosomes] */
+    const uint8_t* keep;                     /* [S] or NULL (= all) */
+} hello_site_table;
+
+typedef struct hello_features_format {       /* how `meta` (float32 [3]) is written inside a `.features` entry:     */
+    const uint8_t* meta_prefix;              /* pickle opcodes before and after the 12 payload bytes -- the binding  */
+    int32_t meta_prefix_len;                 /* takes them from its own NumPy's pickle of such an array, so the file */
+    const uint8_t* meta_suffix;              /* loads wherever that NumPy's pickles load                             */
+    int32_t meta_suffix_len;
+} hello_features_format;
+
+typedef struct hello_records hello_records;
+
+typedef struct hello_records_view {          /* pointers into a hello_records object; valid until it is destroyed */
+    int32_t n_sites, n_shards;
+    const uint8_t* shard_vcf;                /* record lines ('\n'-terminated) in site order */
+    const int64_t* shard_vcf_off;            /* [S + 1]: site s owns bytes [off[s], off[s+1]) (empty: no record) */
+    const uint8_t* mean_vcf;                 /* the final VCF's lines for the same sites */
+    const int64_t* mean_vcf_off;             /* [S + 1] */
+    const int64_t* mean_position;            /* [S] 0-based position of the mean call after normalisation, -1: no record */
+    const uint8_t* features;                 /* n_shards pickle streams, concatenated */
+    const int64_t* features_off;             /* [n_shards + 1] */
+    const int32_t* n_records;                /* [n_shards] */
+    const int32_t* best_pair;                /* [5][S] pair index within the site: rows mixture, expert 0..2, mean */
+    const double* best_p;                    /* [5][S] */
+    const double* qual;                      /* [5][S] */
+} hello_records_view;
+
+/*   posteriors [4][n_pairs_total] and meta [S][3] (NULL = [1, 0, 0]) as written by hello_engine_forward, HOST memory;
+ *   shard_site_off [n_shards + 1] site offsets of the shards the launch coalesced (NULL = one shard);
+ *   fmt NULL = no `.features` streams; n_threads <= 0 = one per hardware thread. */
+int hello_site_records(const hello_site_table* sites, const float* posteriors, int64_t n_pairs_total, const float* meta,
+                       const int32_t* shard_site_off, int32_t n_shards, const hello_features_format* fmt,
+                       int32_t n_threads, hello_records** out);
+int hello_records_get(const hello_records* records, hello_records_view* view);
+void hello_records_destroy(hello_records* records);
+
 const char* hello_last_error(void);
 int hello_abi_version(void);
 

@@ -82,7 +82,7 @@ def test_shard_round_trip(tmp_path):
     rng = np.random.default_rng(5)
     for hybrid in (False, True):
         sites = random_sites(rng, 7, hybrid=hybrid, tagged=True)
-        back = shards.read_shard(shards.write_shard(str(tmp_path / f"s{int(hybrid)}.npz"), sites))
+        back = shards.read_shard(shards.write_shard(str(tmp_path / (f"s{int(hybrid)}.npz" if hybrid else "s.hshard")), sites))
         assert len(back) == len(sites)
         for a, b in zip(sites, back):
             assert (a.chromosome, a.start, a.stop, a.reference, a.window_start) == (b.chromosome, b.start, b.stop, b.reference, b.window_start)
@@ -102,7 +102,7 @@ def test_packed_shard_arrays_equal_the_unpacked_sites(tmp_path, hybrid, tagged):
     rng = np.random.default_rng(31)
     sites = random_sites(rng, 60, hybrid=hybrid, tagged=tagged)
     assert any(len(r0) == 0 for s in sites for _, r0, _ in s.alleles)          # alleles without supporting reads
-    path = shards.write_shard(str(tmp_path / "s.npz"), sites)
+    path = shards.write_shard(str(tmp_path / "s.hshard"), sites)
     for packed in (shards.PackedShard.from_file(path), shards.PackedShard.from_sites(sites)):
         assert len(packed) == len(sites) and packed.hybrid == hybrid and packed.has_reads(1) == hybrid
         for tech in ((0, 1) if hybrid else (0,)):
@@ -168,7 +168,7 @@ def test_driver_end_to_end_matches_the_oracle_chain(tmp_path, cfg, hybrid, tagge
     shard_sites = [random_sites(rng, 30, hybrid, tagged), random_sites(rng, 17, hybrid, tagged)]
     os.makedirs(tmp_path / "shards")
     for k, sites in enumerate(shard_sites):
-        shards.write_shard(str(tmp_path / "shards" / f"shard{k}.npz"), sites)
+        shards.write_shard(str(tmp_path / "shards" / (f"shard{k}.npz" if k else f"shard{k}.hshard")), sites)
     argv = ["--network", model, "--workdir", str(tmp_path / "work"), "--shards", str(tmp_path / "shards"), "--num_threads", "2"]
     if tagged:
         argv.append("--include_hp")
@@ -215,3 +215,67 @@ def test_driver_end_to_end_matches_the_oracle_chain(tmp_path, cfg, hybrid, tagge
     assert n_records >= 30
     body = [ln for ln in open(result).read().split("\n")[:-1] if not ln.startswith("#")]
     assert len(body) >= 30 and all(ln.split("\t")[7] == "HELLO" for ln in body)
+
+
+def _write_model_and_shards(tmp_path, cfg, n_shards, sites_per_shard, hybrid=False, tagged=False, seed=5):
+    from hello_amd import loader, netspec as ns, weights
+    spec = ns.build(cfg)
+    model = str(tmp_path / "model.hello.npz")
+    loader.save_native(model, cfg, weights.synth_state(spec, seed=17))
+    rng = np.random.default_rng(seed)
+    os.makedirs(tmp_path / "shards", exist_ok=True)
+    for k in range(n_shards):
+        n = sites_per_shard if isinstance(sites_per_shard, int) else sites_per_shard[k]
+        sites = random_sites(rng, n, hybrid, tagged, chromosomes=("chr%d" % (1 + k % 3), "chr2"))
+        for s in sites:                                     # spread the shards' positions so the final sort interleaves them
+            s.start += 50_000 * (k % 4); s.stop += 50_000 * (k % 4); s.window_start += 50_000 * (k % 4)       # noqa: E702
+            for _, r0, r1 in s.alleles:
+                for rd in r0 + (r1 or []):
+                    rd.ref_start += 50_000 * (k % 4)
+        shards.write_shard(str(tmp_path / "shards" / (f"shard{k}.npz" if k == 2 else f"shard{k}.hshard")), sites)   # one NumPy archive among them
+    return model
+
+
+def _files(directory):
+    return {name: open(os.path.join(directory, name), "rb").read() for name in sorted(os.listdir(directory))
+            if not name.endswith(".log") and not name.startswith("mean_index")}
+
+
+@pytest.mark.gpu
+def test_launch_coalescing_and_pipeline_depth_are_invisible(tmp_path):
+    """The same shards as one launch each, coalesced three at a time and all in one launch: byte-identical per-shard files
+    and final VCF (the launch is not the file: offsets, site indices and CSR counts are renumbered per launch); an empty
+    shard still completes with its sentinel."""
+    model = _write_model_and_shards(tmp_path, "hybrid_ensemble2", 7, [9, 0, 14, 5, 11, 1, 8], hybrid=True)
+    outs = []
+    for label, per_launch in (("one", 1), ("three", 30), ("all", 100000)):
+        work = tmp_path / label
+        result = call.main(call.parser().parse_args(["--network", model, "--workdir", str(work), "--shards", str(tmp_path / "shards"),
+                                                     "--num_threads", "4", "--sites_per_launch", str(per_launch)]))
+        outs.append((_files(work / "features"), open(result, "rb").read()))
+        assert call.SENTINEL in open(work / "features" / "features1.log").read()
+        assert pickle.load(open(work / "features" / "features1.features", "rb")) == []
+    assert outs[0] == outs[1] == outs[2]
+    assert len(outs[0][0]) == 7 * 3 and outs[0][1].count(b"\n") > 20
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_write_the_single_process_result(tmp_path):
+    """``--gpus 2`` re-launches the command under torch.distributed.run: two ranks (sharing this box's one GPU) are dealt
+    the shards by read count, write their shards' files, meet at one barrier, and rank 0 merges the final VCF -- byte for
+    byte what a single process writes."""
+    import subprocess
+    import sys
+    model = _write_model_and_shards(tmp_path, "single_tech", 9, [12, 30, 7, 22, 3, 16, 25, 9, 14])
+    single = call.main(call.parser().parse_args(["--network", model, "--workdir", str(tmp_path / "single"),
+                                                 "--shards", str(tmp_path / "shards"), "--num_threads", "4"]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    run = subprocess.run([sys.executable, "-m", "hello_amd.call", "--network", model, "--workdir", str(tmp_path / "two"),
+                          "--shards", str(tmp_path / "shards"), "--num_threads", "4", "--gpus", "2"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert "rank 1 of 2" in run.stderr and "rank 0 of 2" in run.stderr
+    assert open(tmp_path / "two" / "results.output.vcf", "rb").read() == open(single, "rb").read()
+    assert _files(tmp_path / "two" / "features") == _files(tmp_path / "single" / "features")
+    assert len(open(single).read().split("\n")) > 40

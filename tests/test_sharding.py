@@ -87,6 +87,17 @@ def test_shard_sizes_and_rank_cpus():
         seen += cpus
     if len(allowed) >= 4:
         assert len(set(seen)) == len(seen)          # ranks do not share CPUs when there are enough
+    # 8 ranks, GPUs 0-3 on NUMA node 0 and 4-7 on node 1: the four ranks of a node split ALL of that node's CPUs
+    half = len(allowed) // 2
+    topo = dict(node_of_device=lambda d: d // 4, cpus_of_node=lambda n: allowed[:half] if n == 0 else allowed[half:], n_devices=8)
+    per_rank = [shard.rank_cpus(r, 8, r, **topo) for r in range(8)]
+    if half >= 4:
+        assert sorted(c for cpus in per_rank[:4] for c in cpus) == allowed[:half]
+        assert sorted(c for cpus in per_rank[4:] for c in cpus) == allowed[half:]
+    # two ranks rehearsing on ONE card share its node and split it
+    one = dict(node_of_device=lambda d: 0, cpus_of_node=lambda n: allowed, n_devices=1)
+    a, b = shard.rank_cpus(0, 2, 0, **one), shard.rank_cpus(1, 2, 0, **one)
+    assert sorted(a + b) == allowed and (len(allowed) < 2 or not set(a) & set(b))
 
 
 def test_bench_rank_pieces_cover_the_global_stream_exactly():

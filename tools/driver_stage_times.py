@@ -1,14 +1,23 @@
-"""Where the time of the scoring-stage driver (hello_amd.call.score_shard) goes on a synthetic shard: packing the
-aligned reads, the featurizer launch, the forward, and the per-site genotype / VCF / .features records.
+"""Throughput of the scoring-stage driver (python -m hello_amd.call = hello_amd.shard_pipeline) from shard FILES to the
+final VCF, from ONE host process on one GPU, and where its host time goes.
 
-    python tools/driver_stage_times.py [--sites 4000] [--coverage 30]
+    python tools/driver_stage_times.py [--sites 262144] [--shard_sites 400,4000] [--coverage 30] [--threads 16]
 
-The engine's batched rate (bench.py) is set by the GPU; this shows what the Python host side around it costs per site,
-i.e. how many host processes the driver needs in front of one GPU (the reference runs one per core, call.py:26-30,111).
+A synthetic shard (30 reads per site, 150-base reads, two alleles per site) is replicated with shifted coordinates into
+enough ``.hshard`` files (tmpfs: the page cache stands in for the upstream stage handing shards over) for ``--sites``
+sites, once as reference-sized shards (~400 sites: call.py:162, maxShards 500 per chromosome) and once as large ones, and
+``call.main`` runs end to end: per-shard .vcf / .features / .mean.vcf / .log files + results.output.vcf.  Printed: sites/s
+of the whole run and of the scoring loop, the loop's stage clocks (feeder waiting for readers, staging, record stage on
+its thread), the process's peak RSS -- at a quarter of the shards and at all of them, which is how "memory is flat in the
+number of shards" is checked -- and the record stage alone on 1 / 4 / N threads.
 """
 import argparse
+import logging
 import os
+import resource
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -16,106 +25,110 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from hello_amd import call as driver, featurizer, netspec as ns, shards, vcf, weights  # noqa: E402
-from hello_amd.featurizer import AlignedRead  # noqa: E402
-from hello_amd.wrapper import ScoringNetwork, pair_keys  # noqa: E402
+from hello_amd import call as driver, loader, netspec as ns, records, shard_pipeline as sp, shards, weights  # noqa: E402
+
+BAM_CMATCH = 0
 
 
-BAM_CMATCH = 0                                   # pysam / BAM CIGAR operation code of an alignment match
+def template_payload(rng, n_sites, coverage):
+    """One synthetic shard as flat arrays, built vectorised (no Python object per read)."""
+    ref_len, spacing = 520, 700
+    window_start = 1000 + spacing * np.arange(n_sites, dtype=np.int64)
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n_sites * ref_len)
+    start = window_start + 240 + rng.integers(0, 20, size=n_sites)
+    ref_base = ref[np.arange(n_sites) * ref_len + (start - window_start)]
+    alt = np.frombuffer(b"ACGT", np.uint8)[(np.searchsorted(np.frombuffer(b"ACGT", np.uint8), ref_base) + rng.integers(1, 4, size=n_sites)) % 4]
+    allele_text = np.stack([ref_base, alt], axis=1).reshape(-1)
+    per_site = np.maximum(2, rng.poisson(coverage, size=n_sites))
+    first = np.clip(rng.binomial(per_site, 0.5), 1, per_site - 1)
+    rpa = np.stack([first, per_site - first], axis=1).reshape(-1).astype(np.int32)
+    R = int(rpa.sum())
+    site_of_read = np.repeat(np.arange(n_sites), per_site)
+    payload = dict(
+        chromosome_text=np.frombuffer(b"chr1", np.uint8), chromosome_text_off=np.array([0, 4], np.int64),
+        chromosome_of_site=np.zeros(n_sites, np.int32), start=start, stop=start + 1, window_start=window_start,
+        ref=ref, ref_off=ref_len * np.arange(n_sites + 1, dtype=np.int64), alleles_per_site=np.full(n_sites, 2, np.int32),
+        allele_text=allele_text, allele_text_off=np.arange(2 * n_sites + 1, dtype=np.int64), has_second=np.array(0),
+        reads_per_allele0=rpa, bases0=rng.choice(np.frombuffer(b"ACGT", np.uint8), size=R * 150),
+        quals0=rng.integers(2, 60, size=R * 150).astype(np.uint8), read_off0=150 * np.arange(R + 1, dtype=np.int64),
+        cigars0=np.full(R, (150 << 4) | BAM_CMATCH, np.uint32), cigar_off0=np.arange(R + 1, dtype=np.int64),
+        ref_start0=start[site_of_read] - rng.integers(20, 130, size=R), mapq0=rng.integers(0, 80, size=R).astype(np.uint8),
+        orientation0=rng.choice(np.array([-1, 1], np.int8), size=R), hp0=np.zeros(R, np.uint8))
+    return payload, R
 
 
-def synth_sites(rng, n, coverage):
-    sites = []
-    for s in range(n):
-        window_start = 1000 + 700 * s
-        ref_len = 520
-        reference = "".join(rng.choice(list("ACGT"), size=ref_len))
-        start = window_start + 240 + int(rng.integers(0, 20))
-        ref_allele = reference[start - window_start]
-        alt = "ACGT"[("ACGT".index(ref_allele) + 1 + int(rng.integers(0, 3))) % 4]
-        per_allele = np.maximum(1, rng.multinomial(max(2, rng.poisson(coverage)), [0.5, 0.5]))
-        alleles = []
-        for a, count in zip((ref_allele, alt), per_allele):
-            reads = []
-            for _ in range(int(count)):
-                n_bases = 150
-                st = start - int(rng.integers(20, 130))
-                reads.append(AlignedRead("".join(rng.choice(list("ACGT"), size=n_bases)), rng.integers(2, 60, size=n_bases).tolist(),
-                                         [(BAM_CMATCH, n_bases)], st, mapq=int(rng.integers(0, 80)),
-                                         orientation=int(rng.choice([-1, 1])), hp=0))
-            alleles.append((a, reads, None))
-        sites.append(shards.CandidateSite("chr1", start, start + 1, reference, window_start, alleles))
-    return sites
+def write_shards(directory, payload, n_files, span):
+    shards.PackedShard(dict(payload))                         # the template validates
+    for k in range(n_files):
+        moved = dict(payload)
+        for name in ("start", "stop", "window_start", "ref_start0"):
+            moved[name] = payload[name] + k * span
+        shards.write_flat(os.path.join(directory, f"shard{k}.hshard"), moved)
+
+
+def rss_mb():
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sites", type=int, default=4000)
+    ap.add_argument("--sites", type=int, default=262144)
+    ap.add_argument("--shard_sites", default="400,4000")
     ap.add_argument("--coverage", type=int, default=30)
+    ap.add_argument("--threads", type=int, default=min(16, len(os.sched_getaffinity(0))))
+    ap.add_argument("--config", default="single_tech")
     args = ap.parse_args()
-    import torch
+    logging.basicConfig(level=logging.WARNING)
     rng = np.random.default_rng(7)
-    spec = ns.build("single_tech")
-    state = weights.synth_state(spec, seed=1)
-    net = ScoringNetwork(spec, state, device=0, providePredictions=True)
-    eng = net.engine
-    t = time.perf_counter()
-    sites = synth_sites(rng, args.sites, args.coverage)
-    t_synth = time.perf_counter() - t
-    n_reads = sum(len(r0) for s in sites for _, r0, _ in s.alleles)
-    driver.score_shard(net, sites[:64])                                   # warm-up (allocations, first launches)
-    packed_shard = shards.PackedShard.from_sites(sites)                    # what PackedShard.from_file yields for a shard file
-
-    t0 = time.perf_counter()
-    site_reads = [s.site_reads(0) for s in sites]
-    t1 = time.perf_counter()
-    packed = featurizer.pack_sites(site_reads)
-    t2 = time.perf_counter()
-    dev0, rpa0, aps = featurizer.featurize(eng, site_reads, 150, False, device_output=True)     # packs again inside
-    torch.cuda.synchronize()
-    t3 = time.perf_counter()
-    logits, meta, post = eng.forward(dev0, rpa0, aps, None, None, None, posteriors=True)
-    post = post.cpu().numpy()
-    t4 = time.perf_counter()
-    out, col = [], 0
-    for site in sites:
-        keys = pair_keys([a for a, _, _ in site.alleles])
-        n = len(keys)
-        rows = [dict(zip(keys, (float(v) for v in post[r, col:col + n]))) for r in range(4)]
-        col += n
-        ref = driver.WindowReference(site.reference, site.window_start)
-        c = vcf.call_site(rows[0], site.chromosome, site.start, site.stop - site.start, ref, info="MixtureOfExpertPrediction")
-        if c is not None:
-            out.append((c.line(), vcf.feature_record((rows[0], rows[1], rows[2], rows[3], np.array([1.0, 0.0, 0.0], np.float32)),
-                                                     site.chromosome, site.start, site.stop - site.start)))
-    t5 = time.perf_counter()
-    del packed
-    t6 = time.perf_counter()
-    driver.score_shard(net, sites)
-    t7 = time.perf_counter()
-    arrays = packed_shard.featurizer_arrays(0)
-    t8 = time.perf_counter()
-    driver.score_shard(net, packed_shard)
-    t9 = time.perf_counter()
-    del arrays
-    repeats = []
-    for _ in range(4):
-        ta = time.perf_counter()
-        driver.score_shard(net, packed_shard)
-        repeats.append(time.perf_counter() - ta)
-    us = lambda dt: 1e6 * dt / args.sites                                 # noqa: E731
-    print(f"{args.sites} sites, {n_reads} reads ({n_reads / args.sites:.1f} per site); synthesis {t_synth:.2f} s (not a stage)")
-    print(f"  site_reads() views            {us(t1 - t0):8.1f} us/site")
-    print(f"  pack_sites (host arrays)      {us(t2 - t1):8.1f} us/site")
-    print(f"  featurize (pack + launch)     {us(t3 - t2):8.1f} us/site")
-    print(f"  forward + posteriors to host  {us(t4 - t3):8.1f} us/site")
-    print(f"  genotype / VCF / .features    {us(t5 - t4):8.1f} us/site   ({len(out)} records)")
-    print(f"  score_shard from site objects {us(t7 - t6):8.1f} us/site = {args.sites / (t7 - t6):,.0f} sites/s per host process")
-    print(f"  PackedShard.featurizer_arrays {us(t8 - t7):8.1f} us/site")
-    print(f"  score_shard from a PackedShard{us(t9 - t8):8.1f} us/site = {args.sites / (t9 - t8):,.0f} sites/s per host process")
-    print("  ... four more times            " + ", ".join(f"{us(r):.1f}" for r in repeats) +
-          f" us/site (best {args.sites / min(repeats):,.0f} sites/s)")
-    net.close()
+    base = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None, prefix="hello_driver_")
+    try:
+        spec = ns.build(args.config)
+        model = os.path.join(base, "model.hello.npz")
+        loader.save_native(model, args.config, weights.synth_state(spec, seed=1))
+        print(f"# python tools/driver_stage_times.py --sites {args.sites} --shard_sites {args.shard_sites} --threads {args.threads}   "
+              f"({args.config}, {args.coverage} reads per site, {len(os.sched_getaffinity(0))} CPUs visible)")
+        for shard_sites in [int(x) for x in args.shard_sites.split(",")]:
+            payload, n_reads = template_payload(rng, shard_sites, args.coverage)
+            n_files = max(4, args.sites // shard_sites)
+            for label, count in (("quarter", max(1, n_files // 4)), ("all", n_files)):
+                sdir, work = os.path.join(base, f"shards_{shard_sites}_{label}"), os.path.join(base, f"work_{shard_sites}_{label}")
+                os.makedirs(sdir)
+                write_shards(sdir, payload, count, 700 * shard_sites + 10_000)
+                argv = ["--network", model, "--workdir", work, "--shards", sdir, "--num_threads", str(args.threads)]
+                captured = []
+                handler = logging.Handler()
+                handler.emit = lambda record, captured=captured: captured.append(record.getMessage())
+                log = logging.getLogger("hello_amd.call")
+                log.setLevel(logging.INFO)
+                log.addHandler(handler)
+                t0 = time.perf_counter()
+                driver.main(driver.parser().parse_args(argv))
+                dt = time.perf_counter() - t0
+                log.removeHandler(handler)
+                sites = count * shard_sites
+                lines = sum(1 for _ in open(os.path.join(work, "results.output.vcf")))
+                print(f"{shard_sites:5d} sites/shard x {count:5d} shards = {sites:8d} sites ({n_reads / shard_sites:.1f} reads/site): "
+                      f"{dt:6.2f} s end to end incl. model load + final VCF = {sites / dt:9,.0f} sites/s; {lines} lines in the final VCF; "
+                      f"peak RSS {rss_mb():,.0f} MB")
+                for m in captured:
+                    if "sites/s" in m or "Completed runs" in m:
+                        print("      " + m)
+                shutil.rmtree(sdir)
+                shutil.rmtree(work)
+        # the record stage alone (host only): one launch of 8 192 sites
+        payload, _ = template_payload(rng, 8192, args.coverage)
+        shard = shards.PackedShard(dict(payload))
+        table = sp.site_table([shard])
+        post = rng.random((4, 3 * 8192)).astype(np.float32)
+        for threads in sorted({1, 4, args.threads}):
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                records.site_records(table, post, None, threads=threads).close()
+                best = min(best, time.perf_counter() - t0)
+            print(f"record stage alone, 8 192 sites, {threads:2d} threads: {best * 1e3:6.2f} ms = {8192 / best:11,.0f} sites/s")
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
 
 
 if __name__ == "__main__":
