@@ -71,7 +71,8 @@ struct Failure {
     }
 };
 
-// ---- pickle stream (protocol 4 opcodes, no framing, memo written only in the per-shard preamble) -----------------------
+// ---- pickle stream (protocol 4 opcodes, no framing; the memo holds the five field names, written in the preamble: a
+// shard's stream depends on nothing but its own records) ---------------------------------------------------------------
 struct Pickle {
     std::string& o;
     explicit Pickle(std::string& out) : o(out) {}
@@ -103,7 +104,7 @@ struct Pickle {
     }
 };
 
-enum { MEMO_CHROMOSOME = 0, MEMO_POSITION, MEMO_LENGTH, MEMO_META, MEMO_EXPERTS, MEMO_FIRST_NAME };
+enum { MEMO_CHROMOSOME = 0, MEMO_POSITION, MEMO_LENGTH, MEMO_META, MEMO_EXPERTS };
 
 // ---- one site --------------------------------------------------------------------------------------------------------
 struct SiteCtx {
@@ -387,7 +388,7 @@ int hello_site_records(const hello_site_table* t, const float* posteriors, int64
                 piece.records += 1;
                 Pickle pk(piece.bytes);
                 pk.op('}'); pk.op('(');                        // EMPTY_DICT MARK
-                pk.get(MEMO_CHROMOSOME); pk.get(MEMO_FIRST_NAME + (uint32_t)c);
+                pk.get(MEMO_CHROMOSOME); pk.text(cx.chromosome.p, cx.chromosome.n);
                 pk.get(MEMO_POSITION); pk.integer(cx.start);
                 pk.get(MEMO_LENGTH); pk.integer(cx.length);
                 pk.get(MEMO_META);
@@ -450,12 +451,6 @@ int hello_site_records(const hello_site_table* t, const float* posteriors, int64
         pk.op('\x80'); pk.op(4);                               // PROTO 4 (no FRAME: framing is optional for readers)
         const char* fields[5] = {"chromosome", "position", "length", "meta", "expertPredictions"};
         for (uint32_t i = 0; i < 5; ++i) { pk.text(fields[i], strlen(fields[i])); pk.put(i); pk.op('0'); }   // memoise, POP
-        for (int32_t c = 0; c < t->n_chromosomes; ++c) {
-            pk.text((const char*)t->chromosome_text + t->chromosome_text_off[c],
-                    (size_t)(t->chromosome_text_off[c + 1] - t->chromosome_text_off[c]));
-            pk.put(MEMO_FIRST_NAME + (uint32_t)c);
-            pk.op('0');
-        }
         pk.op(']');                                            // EMPTY_LIST
         std::vector<std::vector<const Chunk::Piece*>> per_shard(n_shards);
         for (auto& ch : chunks)

@@ -41,6 +41,8 @@ DTYPES = dict(bases=np.uint8, quals=np.uint8, read_off=np.int64, cigars=np.uint3
 
 def prepare(shard: PackedShard, hybrid: bool, uses_ref: bool) -> PackedShard:
     """Reader-thread work on a loaded shard: everything that does not need the GPU."""
+    if shard.n_sites == 0:
+        return shard
     if hybrid and not shard.has_reads(1):
         raise ValueError("this model scores two read technologies: every allele of the shard needs both read sets")
     shard.featurizer_core(0)

@@ -299,6 +299,8 @@ class PackedShard:
 
     def n_reads(self, tech: int = 0) -> int:
         """Reads the featurizer will write for technology ``tech`` (dummy reads of unsupported alleles included)."""
+        if not self.has_reads(tech):
+            return 0
         return int(np.maximum(np.asarray(self.z[f"reads_per_allele{tech}"], np.int64), 1).sum())
 
     # -- validation --------------------------------------------------------------------------------------------

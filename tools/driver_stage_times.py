@@ -1,11 +1,11 @@
 """Throughput of the scoring-stage driver (python -m hello_amd.call = hello_amd.shard_pipeline) from shard FILES to the
 final VCF, from ONE host process on one GPU, and where its host time goes.
 
-    python tools/driver_stage_times.py [--sites 262144] [--shard_sites 400,4000] [--coverage 30] [--threads 16]
+    python tools/driver_stage_times.py [--sites 1048576] [--shard_sites 400,4000] [--coverage 30] [--threads 16]
 
-A synthetic shard (30 reads per site, 150-base reads, two alleles per site) is replicated with shifted coordinates into
-enough ``.hshard`` files (tmpfs: the page cache stands in for the upstream stage handing shards over) for ``--sites``
-sites, once as reference-sized shards (~400 sites: call.py:162, maxShards 500 per chromosome) and once as large ones, and
+A synthetic shard (30 reads per site, 150-base reads, two alleles per site) is replicated into enough ``.hshard`` files
+(16 distinct ones with shifted coordinates, the rest links to them; tmpfs: the page cache stands in for the upstream stage
+handing shards over) for ``--sites`` sites, once as reference-sized shards (~400 sites: call.py:162, maxShards 500 per chromosome) and once as large ones, and
 ``call.main`` runs end to end: per-shard .vcf / .features / .mean.vcf / .log files + results.output.vcf.  Printed: sites/s
 of the whole run and of the scoring loop, the loop's stage clocks (feeder waiting for readers, staging, record stage on
 its thread), the process's peak RSS -- at a quarter of the shards and at all of them, which is how "memory is flat in the
@@ -57,13 +57,19 @@ def template_payload(rng, n_sites, coverage):
     return payload, R
 
 
-def write_shards(directory, payload, n_files, span):
+def write_shards(directory, payload, n_files, span, distinct=16):
+    """``n_files`` shard files: ``distinct`` real ones (coordinates shifted per file), the rest symbolic links to them in
+    rotation -- the page cache then holds ``distinct`` shards however many the run reads."""
     shards.PackedShard(dict(payload))                         # the template validates
     for k in range(n_files):
+        path = os.path.join(directory, f"shard{k}.hshard")
+        if k >= distinct:
+            os.symlink(os.path.join(directory, f"shard{k % distinct}.hshard"), path)
+            continue
         moved = dict(payload)
         for name in ("start", "stop", "window_start", "ref_start0"):
             moved[name] = payload[name] + k * span
-        shards.write_flat(os.path.join(directory, f"shard{k}.hshard"), moved)
+        shards.write_flat(path, moved)
 
 
 def rss_mb():
@@ -72,7 +78,7 @@ def rss_mb():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sites", type=int, default=262144)
+    ap.add_argument("--sites", type=int, default=1048576)
     ap.add_argument("--shard_sites", default="400,4000")
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--threads", type=int, default=min(16, len(os.sched_getaffinity(0))))
