@@ -16,12 +16,13 @@ HBM, outputs left there) is reported beside it as ``device_resident``: the pipel
 the kernels, so the two agree within a few percent.
 
 With N > 1 (one process per GPU under torch.distributed.run) the global step batch is N times as large
-(weak scaling); every rank computes the same read-balanced site partition from the shared counts, feeds ITS
-range through its own pipeline (pinned pool and host threads on CPUs near its GPU) and keeps its logits
-resident; ONE RCCL gather at the end of the run brings every rank's logits to rank 0, inside the timed
-region.
+(``--scaling weak``, the default) or the same ``--launches-per-step`` launches cut N ways (``--scaling strong``:
+the fixed 1.64 M-site stream of the N = 1 run); every rank computes the same read-balanced site partition from
+the shared counts, pins and feeds ONLY its range through its own pipeline (host threads on CPUs near its GPU) and
+keeps its logits resident; ONE RCCL gather at the end of the run brings every rank's logits to rank 0, inside the
+timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S] [--launches-per-step B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S] [--launches-per-step B] [--scaling weak|strong]
 """
 import argparse
 import json
@@ -175,6 +176,9 @@ def main():
     ap.add_argument("--fused", choices=["full", "trunk", "none"], default="full",
                     help="read convolver: one fused kernel from the bytes / layer-by-layer stem + fused trunk / "
                          "layer by layer")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every GPU gets --launches-per-step launches per step (global batch N times as "
+                         "large); strong = the N = 1 stream (--launches-per-step launches per step in total) cut N ways")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--op-times", action="store_true", help="print per-op device times to stderr")
     args = ap.parse_args()
@@ -237,10 +241,14 @@ def main():
 
     # ---- the pinned host pool (the same seeded batches on every rank: one global site stream) ---------------
     pool = [synth.make_sites(args.sites, seed=1000 + i + args.seed, coverage=30) for i in range(args.pool)]
-    pinned = [pin_batch(b) for b in pool]
     counts = [dict(reads_per_site=shard.reads_per_site(b), alleles_per_site=b.alleles_per_site) for b in pool]
-    pieces, sizes = rank_pieces(counts, args.launches_per_step * world, rank, world)
-    piece_batches = [pinned[k] if (lo, hi) == (0, pool[k].n_sites) else pinned[k].site_slice(lo, hi) for k, lo, hi in pieces]
+    global_launches = args.launches_per_step * (world if args.scaling == "weak" else 1)
+    pieces, sizes = rank_pieces(counts, global_launches, rank, world)
+    # a rank pins what it feeds and nothing else: whole pool batches once each, a cut batch only as its slice
+    whole = {k: pin_batch(pool[k]) for k in sorted({k for k, lo, hi in pieces if (lo, hi) == (0, pool[k].n_sites)})}
+    cut = {(k, lo, hi): pin_batch(pool[k].site_slice(lo, hi)) for k, lo, hi in pieces if (lo, hi) != (0, pool[k].n_sites)}
+    piece_batches = [whole[k] if (lo, hi) == (0, pool[k].n_sites) else cut[(k, lo, hi)] for k, lo, hi in pieces]
+    pinned_bytes = sum(int(b.reads0.numel()) for b in list(whole.values()) + list(cut.values()))
     step_sites = sum(hi - lo for _, lo, hi in pieces)
     step_alleles = sizes[rank][1]
     assert step_sites == sizes[rank][0] and step_alleles == sum(int(b.n_alleles) for b in piece_batches)
@@ -392,6 +400,20 @@ def main():
                 for i, (k, n, ms) in enumerate(rows):
                     print(f"  op {i:3d} {k:15s} {ms:9.4f} ms  {n}", file=sys.stderr)
                 print(f"  sum of ops {sum(r[2] for r in rows):.3f} ms over {n_prof} forwards", file=sys.stderr)
+            # everything behind the read convolver, priced like the dominant kernel (executed / algorithmic MFMA work)
+            r0 = res[0]["batch"]
+            stage = [(op, ms) for op, (k, n, ms) in zip(eng.program.ops, rows) if op.kind != 8]
+            stage_ms = sum(ms for _, ms in stage)
+            rows_of = {0: r0.reads0.shape[0], 2: r0.n_alleles, 3: r0.n_sites}
+            stage_exec = sum(2.0 * (op.exec_macs_per_row or op.macs_per_row) * rows_of.get(op.domain, 0) for op, _ in stage)
+            stage_alg = sum(2.0 * op.macs_per_row * rows_of.get(op.domain, 0) for op, _ in stage)
+            roofline["allele_stage"] = {
+                "ms_per_launch": round(stage_ms, 4), "kernel_launches": len(stage),
+                "executed_tflops": round(stage_exec / (stage_ms * 1e-3) / 1e12, 2) if stage_ms > 0 else None,
+                "executed_frac": round(stage_exec / (stage_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if stage_ms > 0 else None,
+                "algorithmic_frac": round(stage_alg / (stage_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if stage_ms > 0 else None,
+                "note": "every op after the fused read convolver (compressor, expert, head, glue), per 8 192-site launch, "
+                        "from the per-op HIP events of a separate profiled pass"}
             kernels = {}
             for op, (k, n, ms) in zip(eng.program.ops, rows):
                 kname = {"conv1d": "conv1d_mfma_kernel", "readconv_fused": "readconv_kernel"}.get(k, k + "_kernel")
@@ -416,6 +438,7 @@ def main():
         # which would blur the per-kernel roofline above.
         two_engines = None
         try:
+            pinned = [whole[k] if k in whole else pin_batch(pool[k]) for k in range(len(pool))]
             eng2 = Engine(spec, state, device=dev_index)
             pipe2 = HostPipeline(engines=[eng, eng2], posteriors=True)
             done = 0
@@ -527,7 +550,7 @@ def main():
         line = {
             "metric": "candidate sites/sec (whole node)", "value": round(value, 1), "unit": "sites/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / max(args.steps, 1), 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / max(args.steps, 1), 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Illumina 30x single-tech model (moe_attention single_tech weight_norm), synthetic "
                                    f"pileups cov 30, seeded synthetic weights; host-resident uint8 pileups + counts -> "
@@ -542,10 +565,13 @@ def main():
                        "alleles_per_site": round(b0.n_alleles / b0.n_sites, 3),
                        "window": 150, "channels": 6, "parallelism": f"site-sharded dp{world}, one gather at the end",
                        "fused_read_convolver": bool(fused), "outputs": "logits + genotype-pair posteriors (host)",
-                       "host_cpus_of_rank0": len(cpus),
+                       "host_cpus_of_rank0": len(cpus), "pinned_input_bytes_of_rank0": pinned_bytes,
                        "repeat_passes_bit_identical": drift == 0, "outputs_finite": bool(finite)},
             "roofline": roofline,
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu if (cpu is not None or world == 1) else {
+                "value": None, "unit": "sites/s", "cores": 0, "kind": "port",
+                "sample": "not run at N > 1: the CPU baseline is timed on rank 0 of the N = 1 run only (it forks one worker per "
+                          "host core, which would compete with the other ranks' feeder threads)"},
             "device_resident": device_resident,
             "two_engines": two_engines,
             "latency": latency,

@@ -330,6 +330,26 @@ def hybrid_full(norm="wn", prefix="moeMerged") -> ModelSpec:
     return ModelSpec(nets, name="hybrid_full", prefix=prefix)
 
 
+def hybrid_compressor2(norm="wn", prefix="moeMerged") -> ModelSpec:
+    """The third way MoEAttention.forward makes hybrid features (MixtureOfExpertsAdvanced.py:181-192): a hybrid
+    COMPRESSOR on the summed read frames of both technologies instead of the combiners -- ``compressor2`` + ``xattn2``;
+    the meta-expert then reads that compressor's SITE-level output f2[0] (:192), the one place where the site-level
+    compressor call of :136 is live.  No shipped configuration file selects it; the architecture modules are the
+    shipped ones (the dict of ..._weight_norm.py with combiner0/1 replaced by compressor2)."""
+    nets = _nets(prefix, {
+        "read_convolver0": (read_convolver, dict(norm=norm)),
+        "read_convolver1": (read_convolver, dict(norm=norm)),
+        "compressor0": (compressor, dict(norm=norm)),
+        "compressor1": (compressor, dict(norm=norm)),
+        "compressor2": (compressor, dict(norm=norm)),
+        "xattn0": (xattn_subtract, dict(norm=norm)),
+        "xattn1": (xattn_subtract, dict(norm=norm)),
+        "xattn2": (xattn_subtract, dict(norm=norm)),
+        "meta": (meta_convolver, dict(norm=norm)),
+    })
+    return ModelSpec(nets, name="hybrid_compressor2", prefix=prefix)
+
+
 def hybrid_ensemble2(norm="wn", prefix="moeMerged") -> ModelSpec:
     """moe_attention_config_full_hybrid_old_equivalent_weight_norm_ensemble2.py: two experts mixed
     by a meta-expert that reads the one-hot reference segment; third expert is all-zero logits."""
@@ -500,6 +520,7 @@ CONFIGS = {
     "hybrid_no_ensemble_wide": lambda **kw: hybrid_no_ensemble(w=2, **kw),
     "hybrid_full": lambda **kw: hybrid_full(**kw),
     "hybrid_ensemble2": lambda **kw: hybrid_ensemble2(**kw),
+    "hybrid_compressor2": lambda **kw: hybrid_compressor2(**kw),
     # moe_attention_config_single_tech_old_equivalent_layer_norm.py: plain convs, no normalisation, Softplus
     "single_tech_softplus": lambda **kw: single_tech(norm="none", act="softplus", **kw),
     # the same file with its commented-out line 14 active: norm_type = "LayerNormModule" (terminus stays BatchNorm)

@@ -133,6 +133,16 @@ def reference_model(config_name, norm):
                 m.gen_config()
         wrapper.eval()
         return wrapper
+    if config_name == "hybrid_compressor2":
+        # no configuration file ships this branch (MixtureOfExpertsAdvanced.py:181-192): the full hybrid dict with the
+        # combiners replaced by a third compressor, through the reference's own factory
+        module = importlib.reload(importlib.import_module(ns.REFERENCE_CONFIG_MODULE["hybrid_full"]))
+        cfg = dict(module.configDict)
+        del cfg["combiner0"], cfg["combiner1"]
+        cfg["compressor2"] = cfg["compressor0"]
+        wrapper = REF.createMoEFullMergedAdvancedModelWrapper(REF.create_moe_attention_model(cfg))
+        wrapper.eval()
+        return wrapper
     if config_name == "single_tech_softplus":
         # the config module rewrites globals of the shared architecture modules: restore them afterwards
         import architectures.read_convolver as rc
@@ -256,6 +266,8 @@ CASES = [
     ("hybrid_full", "hybrid_full", "wn", 3, 16, dict(coverage=25, hybrid_coverage=12), True, False, ("multi",)),
     ("hybrid_ensemble2", "hybrid_ensemble2", "wn", 3, 17, dict(coverage=25, hybrid_coverage=12),
      True, False, ("one", "multi")),
+    ("hybrid_compressor2", "hybrid_compressor2", "wn", 4, 26, dict(coverage=20, hybrid_coverage=10), True, False,
+     ("one", "multi", "dummy")),
     ("merged_single", "merged_single", "wn", 4, 18, dict(coverage=25), True, False, ("one", "multi", "dummy")),
     ("merged_hybrid", "merged_hybrid", "wn", 3, 19, dict(coverage=20, hybrid_coverage=10), True, False,
      ("one", "multi")),
@@ -328,6 +340,60 @@ def make_pickle_fixture():
     np.savez_compressed(os.path.join(HERE, "mini_reference.npz"), **payload)
     print(f"mini_reference: pickle {os.path.getsize(path) / 1024:.0f} KB, logits "
           f"[{res['logits'].min():.3f},{res['logits'].max():.3f}]")
+
+
+def make_compressor2_pickle_fixture():
+    """A real reference pickle of a small hybrid MoEAttention that takes the ``compressor2`` branch of its forward
+    (MixtureOfExpertsAdvanced.py:181-192: hybrid compressor on the summed read frames, xattn2 on its output, the
+    meta-expert on its SITE-level output f2[0]) -- the branch no shipped configuration selects.  Layer lists from the
+    reference's own generators, model from its own factory, torch.save'd whole."""
+    wn = dict(use_weight_norm=True)
+    rb = dict(kernelSizes=[3, 3], paddings=[1, 1], dilations=[1, 1])
+
+    def read_conv():
+        cfg = NNTools.SingleConvLayer(6, 8, 3, 0, 1, 1, **wn)
+        cfg.append({"type": "MaxPool1d", "kwargs": {"kernel_size": 3, "stride": 2, "padding": 0}})
+        return cfg + [NNTools.ResidualBlockFTShortcut(8, 8, strides=[1, 1], **rb, **wn),
+                      NNTools.ResidualBlockConvShortcut(8, 16, strides=[2, 1, 2], **rb, **wn)]
+
+    def comp():
+        return NNTools.SingleConvLayer(16, 16, 1, 0, 1, 1, **wn) + [NNTools.ResidualBlockConvShortcut(16, 32, strides=[2, 1, 2], **rb, **wn)]
+
+    def xattn():
+        cfg = [{"type": "Fork", "kwargs": {"net_args": [[{"type": "Noop", "kwargs": {}}],
+                                                         [{"type": "SelectArgument", "kwargs": {"select": 1}}]]}},
+               {"type": "LinearCombination", "kwargs": {"coefficients": [2, -1]}}]
+        cfg += NNTools.SingleConvLayer(32, 32, 1, 0, 1, 1, **wn)
+        cfg += [NNTools.ResidualBlockConvShortcut(32, 64, strides=[2, 1, 2], **rb, **wn)]
+        return cfg + NNTools.terminus(64, 1, use_weight_norm=True)
+
+    meta = [{"type": "SelectArgument", "kwargs": {"select": 0}}] + NNTools.SingleConvLayer(32, 32, 1, 0, 1, 1, **wn)
+    meta += [NNTools.ResidualBlockConvShortcut(32, 64, strides=[2, 1, 2], **rb, **wn)] + NNTools.terminus(64, 3, use_weight_norm=True)
+    torch.manual_seed(8642)
+    moe = REF.create_moe_attention_model({"read_conv0": read_conv(), "read_conv1": read_conv(), "compressor0": comp(),
+                                          "compressor1": comp(), "compressor2": comp(), "xattn0": xattn(), "xattn1": xattn(),
+                                          "xattn2": xattn(), "meta": meta})
+    wrapper = REF.createMoEFullMergedAdvancedModelWrapper(moe)
+    wrapper.eval()
+    with torch.no_grad():
+        for name, p in wrapper.named_parameters():
+            if name.endswith("weight_g"):
+                p.mul_(1.0 + 0.25 * torch.rand_like(p))
+            if name in ("moeMerged.read_convolver0.network.0.conv1d.weight_g", "moeMerged.read_convolver1.network.0.conv1d.weight_g"):
+                p.div_(128.0)
+    path = os.path.join(HERE, "mini_compressor2.wrapper.dnn")
+    torch.save(wrapper, path)
+    batch = synth.make_sites(5, seed=654, coverage=12, hybrid_coverage=7)
+    res = run_batched(wrapper, batch)
+    res.pop("frames0")
+    res.update(run_wrapper(wrapper, batch, synth.allele_names(batch)))
+    wrapper.providePredictions = False
+    payload = dict(reads0=batch.reads0, reads_per_allele0=batch.reads_per_allele0, reads1=batch.reads1,
+                   reads_per_allele1=batch.reads_per_allele1, alleles_per_site=batch.alleles_per_site, ref_onehot=batch.ref_onehot)
+    payload.update({"exp_" + k: v for k, v in res.items()})
+    np.savez_compressed(os.path.join(HERE, "mini_compressor2.npz"), **payload)
+    print(f"mini_compressor2: pickle {os.path.getsize(path) / 1024:.0f} KB, logits [{res['logits'].min():.3f},{res['logits'].max():.3f}], "
+          f"meta rows {res['meta'][:2].round(3).tolist()}")
 
 
 def make_merged_pickle_fixture():
@@ -904,6 +970,8 @@ def main():
             return
     if not only or "mini_reference" in only:
         make_pickle_fixture()
+    if not only or "mini_compressor2" in only:
+        make_compressor2_pickle_fixture()
     if not only or "mini_merged" in only:
         make_merged_pickle_fixture()
     if not only or "mini_addendum" in only:

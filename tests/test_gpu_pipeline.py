@@ -100,3 +100,32 @@ def test_bench_under_torchrun_initialises_rccl_and_reports_one_gpu(tmp_path):
     assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["scaling"] == "weak"
     assert rec["config"]["sites_total"] == 2 * 3 * 512 and rec["config"]["repeat_passes_bit_identical"]
     assert rec["value"] > 0 and 0 < rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["kernel"] == "readconv_kernel"
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_mode_at_world_one_equals_the_plain_run(tmp_path):
+    """``--scaling strong`` (the N = 1 stream cut N ways) under torch.distributed.run at world size 1
+    is the plain run's workload -- the same number of sites, and its value within 3 % of the plain run's on the same box
+    (so the N = 1 point of a scaling curve agrees with the headline bench)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, cwd=root, env=env, capture_output=True,
+                           text=True, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    strong = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                             "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), os.path.join(root, "bench.py")] + common +
+                            ["--scaling", "strong"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert strong.returncode == 0, strong.stderr[-2000:]
+    a = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in strong.stdout.splitlines() if ln.startswith("{")][-1])
+    assert a["scaling"] == "weak" and b["scaling"] == "strong" and b["n_gpus"] == 1
+    assert a["config"]["sites_total"] == b["config"]["sites_total"] == 6 * 10 * 8192
+    assert abs(b["value"] / a["value"] - 1.0) < 0.03, (a["value"], b["value"])
+    assert b["cpu_baseline"] is None and a["cpu_baseline"] is None          # switched off here; at N > 1 it carries a reason

@@ -118,6 +118,25 @@ def test_loader_runs_a_merged_family_pickle():
     net.close()
 
 
+def test_loader_runs_the_hybrid_compressor_branch_pickle():
+    """MixtureOfExpertsAdvanced.py:181-192 (``compressor2`` + ``xattn2``, meta on the hybrid compressor's site-level
+    output) from a reference pickle: logits, meta and the wrapper's five outputs against what the reference returned."""
+    net = loader.load(os.path.join(GOLDEN, "mini_compressor2.wrapper.dnn"))
+    net.providePredictions = True
+    z = np.load(os.path.join(GOLDEN, "mini_compressor2.npz"))
+    batch = synth.SiteBatch(z["reads0"], z["reads_per_allele0"], z["alleles_per_site"], z["ref_onehot"], z["reads1"],
+                            z["reads_per_allele1"])
+    logits, meta = net.engine.forward_batch(batch)
+    np.testing.assert_allclose(logits, z["exp_logits"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(meta, z["exp_meta"], rtol=1e-5, atol=2e-6)
+    for s, (fd, seg) in enumerate(site_dicts(batch)):
+        mix, e0, e1, e2, m = net(fd, seg)
+        for got, key in ((mix, "mix"), (e0, "e0"), (e1, "e1"), (e2, "e2")):
+            np.testing.assert_allclose(np.array([float(v) for v in got.values()]), z[f"exp_site{s}_{key}"], **PROB)
+        np.testing.assert_allclose(m.numpy(), z[f"exp_site{s}_meta"], **PROB)
+    net.close()
+
+
 @pytest.mark.parametrize("name", ["mini_merged_concat", "mini_merged_sepmeta"])
 def test_loader_runs_the_other_merged_family_variants(name):
     """mini_merged_concat: the class default useAdditive=False (expert input cat(allele, rest of site));

@@ -97,6 +97,23 @@ def test_merged_family_separate_meta_convolvers_bn_eps_affine_and_missing_bias()
     assert prog.n_experts == 3 and prog.has_meta
 
 
+def test_hybrid_compressor_branch_pickle_loads_and_matches_reference():
+    """MoEAttention.forward's ``compressor2`` branch (MixtureOfExpertsAdvanced.py:181-192): the hybrid compressor on the
+    summed read frames, xattn2 on it, and the meta-expert on its SITE-level output -- a reference pickle of exactly that
+    model through the loader, the oracle and the lowering (the branch had never run)."""
+    spec, state, batch, z = _pickle_case("mini_compressor2")
+    assert set(spec.nets) == {"read_convolver0", "read_convolver1", "compressor0", "compressor1", "compressor2", "xattn0", "xattn1",
+                              "xattn2", "meta"}
+    logits, meta = mo.forward_batch(mo.Oracle(spec, state), batch)
+    np.testing.assert_allclose(logits, z["exp_logits"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(meta, z["exp_meta"], rtol=1e-5, atol=1e-6)
+    assert 0.15 < z["exp_meta"].min() and z["exp_meta"].max() < 0.6                  # the softmax is not saturated
+    prog = compiler.compile_model(spec, state)
+    assert prog.n_experts == 3 and prog.has_meta and not prog.uses_ref
+    # the site-level compressor call is live in this branch: compressor2 runs on alleles AND on sites
+    assert {o.domain for o in prog.ops if o.name.startswith("moeMerged.compressor2")} == {compiler.ROWS_ALLELES, compiler.ROWS_SITES}
+
+
 def test_hybrid_concatenating_model_is_rejected_like_the_reference_rejects_it():
     """The reference's forward raises on a hybrid MoEMergedAdvanced without useAdditive (:436, `if perSiteFrame1` on
     a tensor): there is nothing to match, so lowering refuses it with the citation."""

@@ -9,7 +9,7 @@ from hello_amd import synth, weights
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FIXTURES = ["single_tech_batched", "single_tech_bn", "single_tech_hp", "single_tech_deep",
-            "hybrid_no_ensemble", "hybrid_full", "hybrid_ensemble2", "merged_single", "merged_hybrid", "single_tech_addendum", "hybrid_no_ensemble_addendum", "single_tech_softplus", "hybrid_no_ensemble_wide",
+            "hybrid_no_ensemble", "hybrid_full", "hybrid_ensemble2", "hybrid_compressor2", "merged_single", "merged_hybrid", "single_tech_addendum", "hybrid_no_ensemble_addendum", "single_tech_softplus", "hybrid_no_ensemble_wide",
             "merged_hybrid_250", "single_tech_layernorm"]
 
 

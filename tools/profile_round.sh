@@ -2,10 +2,10 @@
 # Profiles of one round on the GPU box: rocprofv3 kernel statistics of the driver's bench command, then PMC passes
 # (one counter group per pass: FETCH_SIZE and WRITE_SIZE do not fit together, MI355X_MICROARCH.md "rocprofv3 PMC slots";
 # --pmc only with --kernel-trace, never with system / runtime tracing).  Run from the repository root:
-#     bash tools/profile_round.sh r02
+#     bash tools/profile_round.sh r03
 # Writes raw output under gpurun_out/prof_<tag>/ and the summaries to copy into profiles/ under gpurun_out/profiles_<tag>/.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
@@ -29,4 +29,20 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   echo "pmc $name done"
 done
 python3 tools/summarize_pmc.py --traffic $SUM > $SUM/hbm_traffic.json || true
+# 3. one row per kernel of the forward: (5 + 20) steps x 10 launches = 250 forwards in the statistics run
+python3 tools/summarize_pmc.py --table $SUM $SUM/${TAG}_rocprofv3_kernel_stats_bench.csv 250 > $SUM/${TAG}_kernel_table.md || true
+# 4. the 2x-channel ("wide") hybrid model: readconv_wide_kernel and its layer-by-layer allele stage (statistics + SQ pass)
+WIDE="tools/config_sweep.py --only wide --sites 1024 --steps 6"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_wide -- python3 $WIDE > $OUT/wide_stats.txt 2> $OUT/wide_stats.err || echo "wide stats failed"
+f=$(find $OUT/stats_wide -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $SUM/${TAG}_rocprofv3_kernel_stats_wide.csv
+mkdir -p $SUM/wide
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  name=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_wide_$name -- python3 $WIDE > $OUT/pmc_wide_$name.txt 2> $OUT/pmc_wide_$name.err || echo "wide pass $name failed"
+  f=$(find $OUT/pmc_wide_$name -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 tools/summarize_pmc.py $f > $SUM/wide/${TAG}_wide_pmc_$name.txt
+  echo "wide pmc $name done"
+done
+# config_sweep runs 2 warm-up + 6 timed forwards of the configuration
+python3 tools/summarize_pmc.py --table $SUM/wide $SUM/${TAG}_rocprofv3_kernel_stats_wide.csv 8 > $SUM/${TAG}_kernel_table_wide.md || true
 ls -la $SUM
