@@ -78,6 +78,9 @@ def test_million_site_stream_is_reproducible_and_matches_oracle_on_samples():
     ("C5 haplotagged (7 channels), cov U{20..80}", "single_tech_hp", dict(coverage=(20, 80), channels=7, tech="pacbio")),
     ("hybrid no-ensemble wide (2x channels: readconv_wide_kernel), 30x + 15x", "hybrid_no_ensemble_wide",
      dict(coverage=30, hybrid_coverage=15)),
+    ("MoEMergedAdvanced 250 bp feature map (250 bp geometry of the fused kernel, BatchNorm, grouped combiner), 30x + 15x",
+     "merged_hybrid_250", dict(coverage=30, hybrid_coverage=15, window=250)),
+    ("single-tech Softplus / no normalisation (..._layer_norm.py as shipped)", "single_tech_softplus", dict(coverage=30)),
 ])
 def test_full_size_batches_of_the_other_baseline_configs(label, cfg, kw):
     """BASELINE.json's other configurations at a full 8 192-site launch (alleles straddling the fused kernel's read

@@ -32,7 +32,7 @@ python3 tools/summarize_pmc.py --traffic $SUM > $SUM/hbm_traffic.json || true
 # 3. one row per kernel of the forward: (5 + 20) steps x 10 launches = 250 forwards in the statistics run
 python3 tools/summarize_pmc.py --table $SUM $SUM/${TAG}_rocprofv3_kernel_stats_bench.csv 250 > $SUM/${TAG}_kernel_table.md || true
 # 4. the 2x-channel ("wide") hybrid model: readconv_wide_kernel and its layer-by-layer allele stage (statistics + SQ pass)
-WIDE="tools/config_sweep.py --only wide --sites 1024 --steps 6"
+WIDE="tools/config_sweep.py --only wide --sites 4096 --steps 6"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_wide -- python3 $WIDE > $OUT/wide_stats.txt 2> $OUT/wide_stats.err || echo "wide stats failed"
 f=$(find $OUT/stats_wide -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $SUM/${TAG}_rocprofv3_kernel_stats_wide.csv
 mkdir -p $SUM/wide
