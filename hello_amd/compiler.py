@@ -32,7 +32,7 @@ SEG_R0A, SEG_R1A, SEG_AS = 0, 1, 2
 BUF_NONE, BUF_READS0, BUF_READS1, BUF_REF, BUF_FIRST_SCRATCH = -1, 0, 1, 2, 3
 (OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED, OP_LAYERNORM,
  OP_COMPRESSOR_FUSED) = range(1, 11)
-FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS, FLAG_WINOGRAD = 1, 2, 4, 8, 16, 32
+FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS, FLAG_WINOGRAD, FLAG_BF16X3 = 1, 2, 4, 8, 16, 32, 64
 OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
             8: "readconv_fused", 9: "layernorm", 10: "compressor_fused"}
 
@@ -93,6 +93,7 @@ class Program:
     fused_read_convolver: bool = False
     fused_compressor: bool = False
     winograd: bool = False           # k3/s1/p1 convolutions run in Winograd form (F(2,3) / F(3,3)) where a kernel offers it
+    arithmetic: str = "fp32"         # "bf16x3": the read convolver's 64-channel trunk as 3-term bf16 splits (selectable mode)
 
     def describe(self) -> str:
         lines = [f"program {self.spec_name}: {len(self.ops)} ops, {len(self.buffers)} buffers, "
@@ -198,7 +199,11 @@ def _is_canonical_read_convolver(nodes, cin) -> bool:
 
 
 class _Lowering:
-    def __init__(self, spec: ns.ModelSpec, state, fused: bool, winograd: bool = True):
+    def __init__(self, spec: ns.ModelSpec, state, fused: bool, winograd: bool = True, arithmetic: str = "fp32"):
+        if arithmetic not in ("fp32", "bf16x3"):
+            raise ValueError(f"arithmetic must be 'fp32' or 'bf16x3', not {arithmetic!r}")
+        self.arithmetic = arithmetic
+        self.used_bf16x3 = False
         self.spec = spec
         self.state = state
         self.folded = wts.fold(spec, state)
@@ -387,8 +392,16 @@ class _Lowering:
         if fusable:
             _, l1, _, l2, _, _ = readconv_pack.geometry(spec.window)
             y = self.new(ROWS_ALLELES, l2, 64)
-            w_off = self.blob.add(readconv_pack.pack(nodes, self.folded, cin, winograd=self.winograd, window=spec.window))
+            packed = readconv_pack.pack(nodes, self.folded, cin, winograd=self.winograd, window=spec.window)
             wflag = FLAG_WINOGRAD if self.winograd else 0
+            # arithmetic mode bf16x3 (never the default): the 64 -> 64 trunk convolutions of the whole-kernel form on the
+            # bf16 matrix cores as 3-term splits; their split weights ride behind the fp32 blob
+            if (self.arithmetic == "bf16x3" and self.fused is True and self.winograd and spec.window == 150 and extras == 0
+                    and not softplus):
+                packed = np.concatenate([packed, readconv_pack.pack_bf16x3(nodes, self.folded)])
+                wflag |= FLAG_BF16X3
+                self.used_bf16x3 = True
+            w_off = self.blob.add(packed)
             if self.fused == "trunk":
                 # stem layer by layer (3 valid convs + max pool), fused residual trunk + segment sum
                 pooled = self.net(nodes[:readconv_pack.TRUNK_FIRST_NODE], x)
@@ -574,16 +587,19 @@ def _allocate(ops: List[Op], values: Dict[int, Value]):
     return phys
 
 
-def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool = True) -> Program:
+def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool = True, arithmetic: str = "fp32") -> Program:
     """``winograd``: k3/s1/p1 convolutions are evaluated in Winograd form -- F(3,3) (5 instead of 9 contractions per
     3 positions) where the row length / the fused kernel's geometry is whole triples, else F(2,3) (4 instead of 6
     per pair) -- same fp32 arithmetic, results differ from the direct form by float re-association only."""
-    low = _Lowering(spec, state, fused, winograd)
+    low = _Lowering(spec, state, fused, winograd, arithmetic)
     n_experts, has_meta = low.lower()
+    if arithmetic == "bf16x3" and not low.used_bf16x3:
+        raise ValueError("arithmetic='bf16x3' exists for the canonical 150 bp ReLU read convolver in the whole-kernel "
+                         "Winograd form (fused=True, winograd=True): this model / these options do not run it")
     buffers = _allocate(low.ops, low.values)
     return Program(
         spec_name=spec.name, window=spec.window, channels0=spec.channels[0],
         channels1=spec.channels[1] if spec.hybrid_inputs else 0,
         n_experts=n_experts, has_meta=has_meta, uses_ref=low.uses_ref, ops=low.ops,
         buffers=buffers, weights=low.blob.finish(), fused_read_convolver=low.used_fused,
-        fused_compressor=low.used_fused_compressor, winograd=low.winograd)
+        fused_compressor=low.used_fused_compressor, winograd=low.winograd, arithmetic=arithmetic)

@@ -214,6 +214,11 @@ int validate_model(const hello_model_desc* d) {
                 !(d->window == 150 && (o.flags & HELLO_FLAG_WINOGRAD) && (o.flags & HELLO_FLAG_SRC_U8) && o.k == 0))
                 return fail(HELLO_ERR_MODEL, "op %d: the Softplus read convolver runs whole (from the bytes), in Winograd "
                                              "form, on 150 bp windows, without extra blocks", i);
+            if ((o.flags & HELLO_FLAG_BF16X3) &&
+                !(d->window == 150 && !wide && (o.flags & HELLO_FLAG_WINOGRAD) && (o.flags & HELLO_FLAG_SRC_U8) && o.k == 0 &&
+                  !(o.flags & HELLO_FLAG_SOFTPLUS)))
+                return fail(HELLO_ERR_MODEL, "op %d: the bf16x3 arithmetic mode exists for the canonical read convolver run whole "
+                                             "(from the bytes) in Winograd form on 150 bp windows, ReLU, without extra blocks", i);
             if (d->window == 250 && !((o.flags & HELLO_FLAG_WINOGRAD) && (o.flags & HELLO_FLAG_SRC_U8) && o.k == 0))
                 return fail(HELLO_ERR_MODEL, "op %d: 250 bp windows run whole (from the bytes), in Winograd form, "
                                              "without extra blocks", i);
@@ -803,9 +808,10 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.softplus = (o.flags & HELLO_FLAG_SOFTPLUS) ? 1 : 0;
                 a.extra_blocks = o.k;
                 a.winograd = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
+                a.bf16x3 = (o.flags & HELLO_FLAG_BF16X3) ? 1 : 0;
                 const bool wide = o.cout == 128;
-                if ((size_t)o.w_off + (wide ? hello::readconv_wide_weight_floats() : hello::readconv_weight_floats(o.k, a.winograd, d.window)) >
-                    e->n_weight_floats)
+                if ((size_t)o.w_off + (wide ? hello::readconv_wide_weight_floats() : hello::readconv_weight_floats(o.k, a.winograd, d.window)) +
+                        (a.bf16x3 ? hello::readconv_bf16x3_extra_floats(o.k) : 0) > e->n_weight_floats)
                     return fail(HELLO_ERR_MODEL, "op %d: fused read-convolver weight block truncated", op_index);
                 {
                     // the plan of stage_batch_indices: the bulk in whole rounds of n-group workgroups, then the rest as

@@ -77,6 +77,8 @@ struct ReadConvArgs {
     int winograd;              // k3/s1 convolutions in Winograd form: F(3,3) trunk at 150 bp, else F(2,3) (weights packed accordingly)
     int window;                // pileup window: 150 | 250 (250: `reads` + Winograd form only)
     int softplus;              // Softplus instead of ReLU (`reads` + Winograd form, 150 bp only)
+    int bf16x3;                // arithmetic mode bf16x3 (`reads` + Winograd form, 150 bp, ReLU, no extra blocks): the 64-channel
+                               // trunk on the bf16 matrix cores as 3-term splits; its split weights follow the fp32 blob
 };
 bool readconv_supports_window(int window);
 int readconv_reads_per_group(int window);
@@ -92,7 +94,8 @@ struct ReadConvPlan {
 };
 ReadConvPlan readconv_plan(long long n_reads, int window);
 ReadConvPlan readconv_wide_plan(long long n_reads);   // every workgroup one group, one launch
-int readconv_weight_floats(int extra_blocks, bool winograd, int window);   // 150 bp + Winograd: residual trunk in F(3,3) form
+int readconv_weight_floats(int extra_blocks, bool winograd, int window);
+int readconv_bf16x3_extra_floats(int extra_blocks);     // floats the bf16x3 mode's split weights add behind that blob   // 150 bp + Winograd: residual trunk in F(3,3) form
 bool readconv_supports_extra_blocks(int extra_blocks);
 hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream);
 // frames[a] = sum of the partial slots of allele a, in slot order

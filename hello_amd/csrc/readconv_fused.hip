@@ -138,6 +138,8 @@ using Geometry250 = rc::Cfg<2, 4, 250>;   // 250 bp windows: 2 reads per workgro
 using GeometrySoftplus = rc::Cfg<4, 4, 150, rc::ACT_SOFTPLUS>;
 static_assert(Geometry::F33 && GeometrySoftplus::F33 && !Geometry250::F33, "weight packing rule of readconv_pack.py");
 static_assert(Geometry::F33_32 && GeometrySoftplus::F33_32, "weight packing rule of readconv_pack.py");
+// bf16x3: [1 + 2 (3 + extra) layers][4 blocks][6 steps][hi | lo][64 lanes][8 bf16] = 12 288 floats per layer behind the blob
+int readconv_bf16x3_extra_floats(int extra_blocks) { return (1 + 2 * (3 + extra_blocks)) * 12288; }
 int readconv_weight_floats(int extra_blocks, bool winograd, int window) {
     if (!winograd) return rc::Offs<false>::off_d(3 + extra_blocks);
     return window == 150 ? rc::Offs<true, true>::off_d(3 + extra_blocks) : rc::Offs<true>::off_d(3 + extra_blocks);
@@ -221,7 +223,33 @@ __device__ __forceinline__ int swz(int row) {
 // trade places and the chunk is XORed with 2*((row>>2)&3).
 // SW_3 (64 channels): images walked THREE rows per lane (F(3,3) layers): chunk ^ 2*((row/3)&7); rows 3j..3j+2 share
 // their swizzle, and 16 lanes' rows 3j+i hit 16 distinct bank groups.
-enum { SW_OLD = 0, SW_W = 1, SW_3 = 2 };
+enum { SW_OLD = 0, SW_W = 1, SW_3 = 2, SW_SPLIT = 3 };
+
+// ---- split images (arithmetic mode bf16x3: the 64-channel trunk on the bf16 matrix cores) ------------------------------
+// A value x is kept as two bf16: hi = bf16(x), lo = bf16(x - hi): 16 of its 24 mantissa bits.  A 64-channel row is 256
+// bytes -- the size of its fp32 row -- cut into sixteen 16-byte chunks: chunk g + 8 * part holds the 8 channels 8g .. 8g+7
+// of part 0 (hi) or 1 (lo), so ONE ds_read_b128 is the 8-deep B operand of a v_mfma_f32_16x16x32_bf16 lane.  Chunks are
+// XOR-swizzled with 2 * (row & 7): the 16 lanes of a ds_read_b128 group (rows j = 0-3, 12-15 of one lane quarter and
+// 4-11 of the next, whose chunks differ in bit 0) then hit 16 distinct bank groups for any first row.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int split_off(int row, int g, int part) { return row * 256 + 16 * ((g + 8 * part) ^ (2 * (row & 7))); }
+__device__ __forceinline__ unsigned short to_bf16(float x) {            // v_cvt_pk_bf16_f32: round to nearest even
+    const __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, h);
+}
+// channels 4 c4 .. 4 c4 + 3 of `row` <- v, as hi and lo parts (two 8-byte stores)
+__device__ __forceinline__ void store_split(unsigned char* __restrict__ img, int row, int c4, f32x4 v) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned short hi = to_bf16(v[e]);
+        h[e] = (short)hi;
+        l[e] = (short)to_bf16(v[e] - __uint_as_float((unsigned)hi << 16));
+    }
+    *(bf16x4*)(img + split_off(row, c4 >> 1, 0) + 8 * (c4 & 1)) = h;
+    *(bf16x4*)(img + split_off(row, c4 >> 1, 1) + 8 * (c4 & 1)) = l;
+}
 template <int C, int SW>
 __device__ __forceinline__ int img_off(int row, int chunk) {     // float offset of 16-byte chunk `chunk` of `row`
     if constexpr (SW == SW_OLD) {
@@ -376,7 +404,8 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
         return *(const f32x4*)(in + img_off<CIN, SIN>(row, 4 * (s % M) + q));
     };
     // output pointer of the k-th tile: base + constant; rows past the group go to the dump slot
-    float* const outbase = out + 16 * pg * COUT + img_off<COUT, SOUT>(j + LEAD, 4 * cb + q);
+    static_assert(SOUT != SW_SPLIT || (COUT == 64 && MODE == MODE_PLAIN), "split images: the 64-channel trunk's input");
+    float* const outbase = out + 16 * pg * COUT + img_off<COUT, SOUT == SW_SPLIT ? SW_OLD : SOUT>(j + LEAD, 4 * cb + q);
     auto out_ptr = [&](int k) -> float* {
         float* ptr = outbase + k * NPG * 16 * COUT;
         if constexpr (SOUT == SW_3)                                     // a swizzle without the tiles' 16-row period
@@ -404,7 +433,11 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
             for (int e = 0; e < 4; ++e) v[e] += sreg[k < CF::NSREG ? k : 0][e];
         }
         if ((padmask >> k) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};      // the shared zero row between reads
-        *(f32x4*)out_ptr(k) = v;
+        if constexpr (SOUT == SW_SPLIT) {                              // hi / lo bf16 parts for the bf16x3 trunk
+            if ((pg + NPG * k) * 16 + j < VROWS) store_split((unsigned char*)out, 16 * (pg + NPG * k) + j + LEAD, 4 * cb + q, v);
+        } else {
+            *(f32x4*)out_ptr(k) = v;
+        }
     };
     auto residual = [&](int k) -> f32x4 {
         if (MODE == MODE_RESID_INPLACE) return *(const f32x4*)out_ptr(k);
@@ -817,6 +850,89 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
     });
 }
 
+// ---- bf16x3: a k = 3, stride 1, pad 1 convolution 64 -> 64 over a split image, on the bf16 matrix cores --------------
+// x w ~= xh wh + (xh wl + xl wh): three v_mfma_f32_16x16x32_bf16 (K = 32 in 16 cycles) per 32-deep chunk of the direct
+// form's K = 3 taps x 64 channels, against v_mfma_f32_16x16x4_f32's K = 4 in 32 cycles; the dropped xl wl and the split
+// residues are ~2^-17 of a product.  The hh terms and the cross terms accumulate in separate registers (bias in the first).
+// A wave owns one of the four 16-channel blocks and walks the compact image's 9 tiles of 16 rows; lane (j, q) supplies
+// channels 32 h + 8 q .. + 7 of row 16 t + j + tap at step s = 2 tap + h (one ds_read_b128 per part) and ends with
+// channels 16 cb + 4 q .. + 3 of row 16 t + j, as in the fp32 layers.  Rows of different reads touch (compact image):
+// the lanes whose tap would cross a read boundary feed zeros, like conv_layer's BMASK.
+// The RESIDUAL STREAM STAYS IN REGISTERS in fp32 (`xres`, one float4 per tile: every layer maps the same lane to the same
+// outputs): a block's output is relu(conv) + xres exactly, and only the convolutions' INPUTS are rounded to 16 bits, so
+// the rounding does not compound through the blocks.
+//   BF_PLAIN   out = relu(conv(in))                      (a block's first convolution)
+//   BF_RESID   xres = relu(conv(in)) + xres; out = xres  (its second one; the strided block's second conv with xres =
+//              the 1x1 shortcut).  OUT_F32: the last layer writes fp32 (the SW_3 image the segment sum reads).
+// `wh` / `wl`: this wave's weights, [6 steps] x 8 bf16 per lane; unless LAST they are refilled in place with the next
+// layer's (`next_w`: this wave's block and lane, [6 steps][hi | lo][64 lanes][8]) after their last use.
+enum { BF_PLAIN = 0, BF_RESID = 1 };
+template <class CF, int MODE, bool LAST, bool OUT_F32>
+__device__ __forceinline__ void bf16x3_layer(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                             bf16x8 (&wh)[6], bf16x8 (&wl)[6], const unsigned short* __restrict__ next_w,
+                                             const float* __restrict__ bias, f32x4 (&xres)[CF::NSREG], int wave, int lane) {
+    constexpr int RS = CF::RS2, NT = RS * CF::G / 16, NU = NT * 6;
+    static_assert(CF::COMPACT && (RS * CF::G) % 16 == 0 && CF::NW == 4 && NT <= CF::NSREG, "the compact 150 bp geometry");
+    const int cb = wave, j = lane & 15, q = lane >> 4;
+    const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // image row of (tile k, lane row j, tap) = 16 k + j + tap (flat row + 1 leading zero row - 1 pad): the swizzle term
+    // depends on (j + tap) & 7 only, so a tile adds a constant
+    const unsigned char* ph[6];
+    const unsigned char* pl[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        ph[s] = in + split_off(j + s / 2, 4 * (s & 1) + q, 0);
+        pl[s] = in + split_off(j + s / 2, 4 * (s & 1) + q, 1);
+    }
+    bf16x8 rh[2], rl[2];
+    auto issue = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int k = u / 6, s = u % 6;
+        rh[u & 1] = *(const bf16x8*)(ph[s] + k * 16 * 256);
+        rl[u & 1] = *(const bf16x8*)(pl[s] + k * 16 * 256);
+    };
+    f32x4 acc_a = b4, acc_b = zero4;
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int k = u / 6, s = u % 6, tap = s / 2;
+        if constexpr (u + 1 < NU) issue(std::integral_constant<int, u + 1>{});
+        bf16x8 xh = rh[u & 1], xl = rl[u & 1];
+        // read boundaries inside the tile: flat row 16 k + jj opens a read -> its tap 0 is padding; closes one -> tap 2 is
+        constexpr int first = ((16 * k + RS - 1) / RS) * RS - 16 * k, last = ((16 * k + RS) / RS) * RS - 1 - 16 * k;
+        if constexpr (tap == 0 && 16 * k + first > 0 && first >= 0 && first < 16) {
+            xh = (j == first) ? zero8 : xh;
+            xl = (j == first) ? zero8 : xl;
+        }
+        if constexpr (tap == 2 && last < 16 && 16 * k + last < RS * CF::G - 1) {
+            xh = (j == last) ? zero8 : xh;
+            xl = (j == last) ? zero8 : xl;
+        }
+        acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh, acc_a, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xl, acc_b, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xh, acc_b, 0, 0, 0);
+        if constexpr (!LAST && k == NT - 1) {                 // the next layer's weights roll in after their last use
+            wh[s] = *(const bf16x8*)(next_w + (s * 2) * 512);
+            wl[s] = *(const bf16x8*)(next_w + (s * 2 + 1) * 512);
+        }
+        if constexpr (s == 5) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = CF::act(acc_a[e] + acc_b[e]);
+            if constexpr (MODE == BF_RESID) {
+                y = y + xres[k];
+                xres[k] = y;
+            }
+            if constexpr (OUT_F32) *(f32x4*)((float*)out + img_off<64, SW_3>(16 * k + j + 1, 4 * cb + q)) = y;
+            else store_split(out, 16 * k + j + 1, 4 * cb + q, y);
+            acc_a = b4;
+            acc_b = zero4;
+        }
+    });
+}
+
 // ---- stem conv1: pileup bytes -> 16 channels (valid convolution over the stacked reads) ---------------
 // The bytes are read as they are (no float copy): lane (j, q) of a tile needs k = 4*step + q of row j, and
 // k = tap*C + c is the byte offset from the row start.  Tiles of a wave: t = wave + 4*i; pairs of tiles in
@@ -1113,10 +1229,14 @@ __device__ __forceinline__ void stem_conv3_pool_wino(const float* __restrict__ i
     });
 }
 
-template <class CF, bool STEM, int NB64, bool WINO>
+template <class CF, bool STEM, int NB64, bool WINO, bool BF16 = false>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
     constexpr bool F33 = WINO && CF::F33;                     // 64-channel residual blocks in F(3,3) form
+    // BF16 (arithmetic mode "bf16x3", never the default): the seven (eleven) 64 -> 64 convolutions run on the bf16 matrix
+    // cores as 3-term splits (bf16x3_layer); everything before them -- stem, 32-channel blocks, the strided convolution
+    // and its shortcut -- and the per-allele sums stay exact fp32
+    static_assert(!BF16 || (F33 && CF::ACT == ACT_RELU), "bf16x3: the 150 bp ReLU geometry of the Winograd kernel");
     using O = Offs<WINO, F33>;
     constexpr int L1 = CF::L1, RS1 = CF::RS1, L2 = CF::L2, RS2 = CF::RS2;
     static_assert(CF::COMPACT || WINO, "the zero-row 64-channel geometry is implemented for the Winograd form only");
@@ -1320,8 +1440,21 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     load_weights<2>(w2, W + OFF_SC, cb4, lane);
     if (tid < 32) ((f32x4*)H)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};   // rows 0 and 36G+1
     conv_layer<CF, 32, 64, 3, 2, 1, RS1, RS2, L2, T2, MODE_PLAIN, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX,
-               F33 ? SW_3 : SWX>(X, H, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
-    if constexpr (F33) {
+               BF16 ? SW_SPLIT : (F33 ? SW_3 : SWX)>(X, H, w6, nullptr, W + OFF_C1 + W3264, sreg, pad2, dump, wave, lane);
+    // bf16x3: this wave's split weights of trunk layer l (0 = the strided block's second conv, then the blocks' convs):
+    // [layer][4 blocks][6 steps][hi | lo][64 lanes][8 bf16] behind the fp32 blob
+    const unsigned short* const WS16 = (const unsigned short*)(W + O::off_d(NB64)) + cb4 * 6144 + lane * 8;
+    bf16x8 bwh[6], bwl[6];
+    if constexpr (BF16) {
+        // the shortcut per 16-row tile, in registers: it becomes the fp32 residual stream of the whole 64-channel trunk
+        conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX, SWX>(
+            X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            bwh[st] = *(const bf16x8*)(WS16 + (st * 2) * 512);
+            bwl[st] = *(const bf16x8*)(WS16 + (st * 2 + 1) * 512);
+        }
+    } else if constexpr (F33) {
         // the shortcut in the row order the F(3,3) epilogue of the block's second conv holds its outputs in
         static_assert(!F33 || CF::NSREG >= 3 * (RS2 * CF::G / 48), "shortcut tiles kept in registers");
         conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, 3 * (RS2 * CF::G / 48), MODE_TO_REGS, false, GEOM_WTRIPLE, 16, RS2 * CF::G,
@@ -1341,7 +1474,10 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     if (tid < 32) ((f32x4*)X)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this wave's block of an F(3,3) layer, this lane: [4 input groups][5 components][64 lanes][4]
     auto slice3 = [&](int off) { return W + off + cb4 * (20 * 256) + lane * 4; };
-    if constexpr (F33) {
+    if constexpr (BF16) {
+        bf16x3_layer<CF, BF_RESID, false, false>((const unsigned char*)H, (unsigned char*)X, bwh, bwl, WS16 + 24576,
+                                                 W + OFF_C2 + O::W6464D, sreg, wave, lane);
+    } else if constexpr (F33) {
         // the shortcut moves from registers into the output image (each lane stores what it will read back as the
         // residual of its own outputs): holding it across the layer would not fit beside 15 accumulators
         {
@@ -1365,7 +1501,17 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
 #pragma unroll
     for (int blk = 0; blk < NB64; ++blk) {
         const int off_a = O::off_d(blk), off_b = off_a + (O::W6464D + 64);
-        if constexpr (F33) {
+        if constexpr (BF16) {
+            bf16x3_layer<CF, BF_PLAIN, false, false>((const unsigned char*)X, (unsigned char*)H, bwh, bwl,
+                                                     WS16 + (2 + 2 * blk) * 24576, W + off_a + O::W6464D, sreg, wave, lane);
+            __syncthreads();
+            if (blk < NB64 - 1)
+                bf16x3_layer<CF, BF_RESID, false, false>((const unsigned char*)H, (unsigned char*)X, bwh, bwl,
+                                                         WS16 + (3 + 2 * blk) * 24576, W + off_b + O::W6464D, sreg, wave, lane);
+            else
+                bf16x3_layer<CF, BF_RESID, true, true>((const unsigned char*)H, (unsigned char*)X, bwh, bwl, nullptr,
+                                                       W + off_b + O::W6464D, sreg, wave, lane);
+        } else if constexpr (F33) {
             wino3_layer<CF, 64, MODE_PLAIN, false>(X, H, w3, slice3(off_a), slice3(off_b), W + off_a + O::W6464D, wave, lane);
             __syncthreads();
             if (blk < NB64 - 1)
@@ -1417,7 +1563,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     flush();
 }
 
-template <class CF, int NB64, bool WINO, bool STEM_ONLY = false>
+template <class CF, int NB64, bool WINO, bool STEM_ONLY = false, bool BF16 = false>
 static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     // the LDS opt-in is a per-device attribute of the function: once per device this process launches on
     // (threads that share a device race benignly: the call is idempotent)
@@ -1428,10 +1574,10 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     if (!configured) {
         hipError_t e = hipSuccess;
         if constexpr (!STEM_ONLY)
-            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false, NB64, WINO>,
+            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false, NB64, WINO, BF16>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64, WINO>,
+            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64, WINO, BF16>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e != hipSuccess) return e;
         configured = true;
@@ -1441,9 +1587,9 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     const unsigned groups = (unsigned)((a.n_reads + per_wg - 1) / per_wg);       // workgroups
     if (a.reads) {
         if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO, BF16>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     } else if constexpr (!STEM_ONLY) {
-        hipLaunchKernelGGL((readconv_kernel<CF, false, NB64, WINO>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, false, NB64, WINO, BF16>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     } else {
         return hipErrorInvalidValue;
     }
@@ -1457,6 +1603,10 @@ hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
         return launch_cfg<Geometry250, 3, true, true>(a, stream);
     }
     if (a.window != 150) return hipErrorInvalidValue;
+    if (a.bf16x3) {                // arithmetic mode bf16x3: canonical architecture, whole kernel from the bytes, Winograd form
+        if (!a.reads || !a.winograd || a.extra_blocks != 0 || a.softplus) return hipErrorInvalidValue;
+        return launch_cfg<Geometry, 3, true, true, true>(a, stream);
+    }
     if (a.softplus) {              // the Softplus configuration: whole kernel, Winograd form
         if (!a.reads || !a.winograd || a.extra_blocks != 0) return hipErrorInvalidValue;
         return launch_cfg<GeometrySoftplus, 3, true, true>(a, stream);

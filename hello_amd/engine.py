@@ -107,12 +107,25 @@ class Engine:
     """One compiled model resident on one GPU (one instance per process and device)."""
 
     def __init__(self, spec: ns.ModelSpec, state, device: int = 0, fused: bool = True, winograd: bool = True,
-                 program: Optional["compiler.Program"] = None):
-        """``program``: an already compiled (or deliberately edited) program to load instead of compiling."""
+                 program: Optional["compiler.Program"] = None, arithmetic: Optional[str] = None):
+        """``program``: an already compiled (or deliberately edited) program to load instead of compiling.
+        ``arithmetic``: "fp32" (exact fp32 everywhere, the default) or "bf16x3" -- the read convolver's 64 -> 64 trunk
+        convolutions on the bf16 matrix cores as 3-term splits (x w ~= xh wh + xh wl + xl wh; ~2^-17 per product, the
+        residual stream kept in fp32); DESIGN.md section 3.1d gives its measured accuracy and speed.  An explicit "bf16x3"
+        raises where the mode does not exist (other read-convolver geometries, layer-by-layer paths); the environment
+        variable HELLO_ARITHMETIC=bf16x3 only changes the default of callers that pass nothing, and only where the mode
+        exists (it is how the whole parity suite is run in this mode)."""
         self.lib = load_library()
         self.spec = spec
-        self.program = program if program is not None else compiler.compile_model(spec, state, fused=fused,
-                                                                                  winograd=winograd)
+        if program is None:
+            if arithmetic is None and os.environ.get("HELLO_ARITHMETIC", "fp32") == "bf16x3":
+                try:
+                    program = compiler.compile_model(spec, state, fused=fused, winograd=winograd, arithmetic="bf16x3")
+                except ValueError:
+                    program = None
+            if program is None:
+                program = compiler.compile_model(spec, state, fused=fused, winograd=winograd, arithmetic=arithmetic or "fp32")
+        self.program = program
         p = self.program
         self._ops = (HelloOp * len(p.ops))()
         for dst, o in zip(self._ops, p.ops):

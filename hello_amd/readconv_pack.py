@@ -165,6 +165,41 @@ def pack(nodes, folded, cin=None, winograd: bool = False, window: int = 150) -> 
     return blob
 
 
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit patterns (uint16), round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def pack_bf16x3(nodes, folded) -> np.ndarray:
+    """Arithmetic mode "bf16x3": the split weights of the 64 -> 64 trunk convolutions (the strided block's second conv,
+    then the residual blocks' convs, in kernel order) for bf16x3_layer in readconv_fused.hip, appended behind the fp32 blob
+    (whose biases these layers keep using): w = hi + lo with hi = bf16(w), lo = bf16(w - hi);
+        [layer][4 channel blocks][6 steps s = 2 tap + h][hi | lo][64 lanes][8]
+        lane l, element i  =  W[out = 16 block + (l & 15)][in = 32 h + 8 (l >> 4) + i][tap]
+    returned as float32 words holding the uint16 pairs."""
+    convs = trunk_convs(nodes)
+    layers = [convs[8]] + convs[9:] + [c for blk in nodes[TRUNK_FIRST_NODE + 7:] for c in (blk.body[0], blk.body[1])]
+    lanes = np.arange(64)
+    out_idx = np.arange(4)[:, None] * 16 + (lanes & 15)[None, :]                                    # [cb, lane]
+    in_idx = 32 * np.arange(2)[:, None, None] + 8 * (lanes >> 4)[None, :, None] + np.arange(8)[None, None, :]   # [h, lane, i]
+    parts = []
+    for c in layers:
+        w, _ = folded[c.key]
+        assert w.shape == (64, 64, 3), w.shape
+        w = w.astype(np.float32)
+        hi = to_bf16_bits(w)
+        lo = to_bf16_bits(w - (hi.astype(np.uint32) << np.uint32(16)).view(np.float32))
+        for cb in range(4):
+            for tap in range(3):
+                for h in range(2):
+                    for part in (hi, lo):
+                        parts.append(part[out_idx[cb][:, None], in_idx[h], tap].ravel())            # [lane][i]
+    bits = np.concatenate(parts).astype(np.uint16)
+    assert bits.size == len(layers) * 24576
+    return bits.view(np.float32).copy()
+
+
 # ------------------------------------------------------------------------------------------------
 # fused allele-level compressor (compressor_kernel in readconv_fused.hip)
 # ------------------------------------------------------------------------------------------------

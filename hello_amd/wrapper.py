@@ -74,9 +74,9 @@ class ScoringNetwork:
     """Counterpart of ``MoEMergedWrapperAdvanced`` backed by the HIP engine."""
 
     def __init__(self, spec: ns.ModelSpec, state, device: int = 0, providePredictions: bool = False, fused: bool = True,
-                 winograd: bool = True):
+                 winograd: bool = True, arithmetic=None):
         self.spec = spec
-        self.engine = Engine(spec, state, device=device, fused=fused, winograd=winograd)
+        self.engine = Engine(spec, state, device=device, fused=fused, winograd=winograd, arithmetic=arithmetic)
         self.moeMerged = _BatchedOperator(self.engine, spec)
         self.providePredictions = providePredictions
         self.training = False

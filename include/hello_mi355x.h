@@ -101,6 +101,11 @@ typedef enum hello_op_kind {
                                         packs them for that form and window;
                                         CONV1D (k 3, stride 1, pad 1): weights are the T Winograd taps, packed
                                         [cout][cin/8][T][8]; T = 5 (F(3,3)) when lin % 3 == 0, else 4 (F(2,3)) */
+#define HELLO_FLAG_BF16X3   64       /* READCONV_FUSED (whole kernel from the bytes, 150 bp, ReLU, Winograd form, k = 0): arithmetic mode
+                                        "bf16x3" -- the seven 64 -> 64 trunk convolutions on the bf16 matrix cores as 3-term
+                                        splits x w ~= xh wh + xh wl + xl wh of pre-split operands; their split weights
+                                        (hello_amd/readconv_pack.py pack_bf16x3) follow the op's fp32 weight block.  Never
+                                        the default: results differ from exact fp32 at the 1e-6 level of the activations */
 #define HELLO_FLAG_MIX_REST 8        /* MIX: dst[a] = src0[a] - (src1[site(a)] - src0[a])  (:372-383)  */
 
 typedef struct hello_op {

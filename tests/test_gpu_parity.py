@@ -513,3 +513,56 @@ def test_stress_against_oracle(label, cfg, kw, gain):
     assert col == post.shape[1] and worst < PROB_ATOL, (label, gain, worst)
     print(f"stress {label} gain {gain}: |dlogit|/scale {np.abs(logits - want).max() / scale:.2e}, posteriors {worst:.2e}")
     eng.close()
+
+
+# ---- arithmetic mode bf16x3 (selectable, never the default) ------------------------------------------------------------
+def test_bf16x3_mode_is_refused_where_it_does_not_exist():
+    from hello_amd.engine import Engine
+    for cfg, kw in (("merged_hybrid_250", {}), ("single_tech", dict(winograd=False)), ("single_tech", dict(fused="trunk")),
+                    ("single_tech_softplus", {}), ("hybrid_no_ensemble_wide", {})):
+        spec = ns.build(cfg)
+        with pytest.raises(ValueError, match="bf16x3"):
+            Engine(spec, weights.synth_state(spec, seed=1), device=0, arithmetic="bf16x3", **kw)
+    with pytest.raises(ValueError, match="arithmetic"):
+        Engine(ns.build("single_tech"), weights.synth_state(ns.build("single_tech"), seed=1), device=0, arithmetic="fp16")
+
+
+@pytest.mark.parametrize("cfg,kw", [("single_tech", dict(coverage=30)), ("hybrid_full", dict(coverage=20, hybrid_coverage=10)),
+                                    ("single_tech_hp", dict(coverage=(20, 80), channels=7, tech="pacbio"))])
+def test_bf16x3_mode_frames_and_posteriors(cfg, kw):
+    """The read convolver's 64-channel trunk on the bf16 matrix cores (3-term splits, fp32 residual stream): its
+    per-allele frames against the exact-fp32 engine's (the same kernel up to the strided block) -- a relative deviation at
+    the 1e-5 level of the frames' scale, never more than 1e-4 --, bit-reproducible, and the model's posteriors against
+    the oracle inside the north star's 1e-4 at the fixtures' weight scale."""
+    from hello_amd.engine import Engine
+    from oracle import moe_oracle as mo
+    spec = ns.build(cfg)
+    state = weights.synth_state(spec, seed=21)
+    hybrid = "hybrid_coverage" in kw
+    batch = _with_extremes(synth.make_sites(150, seed=5 + len(cfg), **kw), 77, hybrid, kw.get("channels", 6))
+    exact, split = Engine(spec, state, device=0), Engine(spec, state, device=0, arithmetic="bf16x3")
+    assert split.program.arithmetic == "bf16x3" and exact.program.arithmetic == "fp32"
+    fused = [i for i, o in enumerate(split.program.ops) if o.kind == 8]
+    assert len(fused) == (2 if hybrid else 1)
+    for i in fused:
+        frames = []
+        for eng in (exact, split):
+            eng.capture_op_output(i)
+            eng.forward_batch(batch)
+            frames.append(eng.read_op_output().copy())
+            eng.capture_op_output(None)
+        scale = float(np.abs(frames[0]).max())
+        dev = float(np.abs(frames[1] - frames[0]).max()) / scale
+        print(f"bf16x3 {cfg} op {i}: frames max |d| / scale = {dev:.2e} (scale {scale:.3g})")
+        assert 0 < dev < 1e-4
+    logits, meta, post = split.forward_batch(batch, posteriors=True)
+    again, _, post2 = split.forward_batch(batch, posteriors=True)
+    assert np.array_equal(logits, again) and np.array_equal(post, post2)
+    exact_logits, _, exact_post = exact.forward_batch(batch, posteriors=True)
+    want, _ = mo.forward_batch(mo.Oracle(spec, state, backend="torch"), batch, chunk_sites=1)
+    d_oracle = float(np.abs(sigmoid(logits) - sigmoid(want)).max())
+    d_exact = float(np.abs(post - exact_post).max())
+    print(f"bf16x3 {cfg}: allele probabilities vs oracle {d_oracle:.2e}, posteriors vs the fp32 engine {d_exact:.2e}")
+    assert d_oracle < PROB_ATOL and d_exact < PROB_ATOL
+    exact.close()
+    split.close()

@@ -36,8 +36,7 @@ def main():
             hybrid = "hybrid_coverage" in kw
             batch = _with_extremes(synth.make_sites(36, seed=int(1000 * gain) + len(cfg), **kw), 4000 + int(10 * gain), hybrid,
                                    kw.get("channels", 6))
-            extra = {} if args.arithmetic == "fp32" else dict(arithmetic=args.arithmetic)
-            eng = Engine(spec, state, device=0, **extra)
+            eng = Engine(spec, state, device=0, arithmetic=args.arithmetic)
             logits, meta, post = eng.forward_batch(batch, posteriors=True)
             eng.close()
             want, want_meta = mo.forward_batch(mo.Oracle(spec, state, backend="torch"), batch, chunk_sites=1)
