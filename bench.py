@@ -364,7 +364,7 @@ def main():
         "pcie_h2d_gbs": round(float(np.mean([b.reads0.numel() for b in piece_batches])) / launch_s / 1e9, 3),
     }
 
-    device_resident = latency = small = parity = two_engines = None
+    device_resident = latency = small = parity = two_engines = bf16x3 = None
     if world == 1 and not args.no_secondary:
         stream = torch.cuda.current_stream(dev).cuda_stream
         # ---- device-resident rate: pileups already in HBM, outputs left there (no PCIe in the loop) --------------
@@ -460,6 +460,62 @@ def main():
             eng2.close()
         except Exception as exc:
             print(f"two-engine leg failed: {exc!r}", file=sys.stderr)
+
+        # ---- the selectable arithmetic mode bf16x3 (read convolver's residual trunk on the bf16 matrix cores as 3-term
+        # splits, fp32 residual stream): NOT the headline -- `value` is exact fp32 -- reported beside it with its own parity
+        try:
+            engb = Engine(spec, state, device=dev_index, arithmetic="bf16x3")
+            resb = []
+            for b in pool[:2]:
+                a, p = b.n_alleles, n_pairs(b.alleles_per_site)
+                resb.append(dict(batch=b, reads=torch.from_numpy(b.reads0).to(dev),
+                                 out=(torch.empty((1, a), dtype=torch.float32, device=dev), None,
+                                      torch.empty((4, p), dtype=torch.float32, device=dev))))
+
+            def bstep(i):
+                r = resb[i % len(resb)]
+                engb.forward(r["reads"], r["batch"].reads_per_allele0, r["batch"].alleles_per_site, stream=stream,
+                             out=r["out"], posteriors=True)
+            for i in range(3):
+                bstep(i)
+            torch.cuda.synchronize(dev)
+            engb.set_profiling(40, only="readconv_fused")
+            t1 = time.perf_counter()
+            for i in range(40):
+                bstep(i)
+            torch.cuda.synchronize(dev)
+            dt_b = time.perf_counter() - t1
+            rows_b, _ = engb.op_times_ms()
+            engb.set_profiling(0)
+            kernel_ms = max(r[2] for r in rows_b)
+            pipe_b = HostPipeline(engb, depth=2, posteriors=True)
+            for i in range(4):
+                pipe_b.submit(piece_batches[i % len(piece_batches)], tag=i)
+            pipe_b.flush()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            got = 0
+            for i in range(60):
+                got += len(pipe_b.submit(piece_batches[i % len(piece_batches)], tag=i))
+            got += len(pipe_b.flush())
+            torch.cuda.synchronize(dev)
+            dt_h = time.perf_counter() - t1
+            bf16x3 = {"device_resident": round(args.sites * 40 / dt_b, 1), "host_to_host": round(args.sites * got / dt_h, 1),
+                      "unit": "sites/s", "ms_per_launch": round(1e3 * dt_b / 40, 4), "readconv_launch_ms": round(kernel_ms, 4),
+                      "arithmetic": "read convolver: stem, strided convolution + shortcut and per-allele sums exact fp32; the six "
+                                    "32 -> 32 and seven 64 -> 64 residual-trunk convolutions as x w ~= xh wh + xh wl + xl wh on "
+                                    "v_mfma_f32_16x16x32_bf16 with the residual stream kept in fp32 registers; allele stage exact fp32",
+                      "note": "Engine(..., arithmetic='bf16x3'): selectable, never the default; `value` above is exact fp32"}
+            if cpu is not None and getattr(cpu_baseline, "reference_answers", None) is not None:
+                check, want_probs, want_post = cpu_baseline.reference_answers
+                gl, _, gp = engb.forward_batch(check, posteriors=True)
+                bf16x3["parity"] = {"max_abs_delta_allele_probability": float(np.abs(1.0 / (1.0 + np.exp(-gl[0].astype(np.float64))) - want_probs).max()),
+                                    "max_abs_delta_pair_posterior": float(np.abs(gp[0] - want_post).max()), "tolerance": 1e-4,
+                                    "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
+            del resb
+            engb.close()
+        except Exception as exc:
+            print(f"bf16x3 leg failed: {exc!r}", file=sys.stderr)
 
         # ---- latency: the reference's deployment form is ONE site per call (caller_calling.py:872-891) ------------
         try:
@@ -574,6 +630,7 @@ def main():
                           "host core, which would compete with the other ranks' feeder threads)"},
             "device_resident": device_resident,
             "two_engines": two_engines,
+            "bf16x3": bf16x3,
             "latency": latency,
             "parity": parity,
             "small_batch": small,

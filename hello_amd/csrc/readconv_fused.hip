@@ -139,7 +139,8 @@ using GeometrySoftplus = rc::Cfg<4, 4, 150, rc::ACT_SOFTPLUS>;
 static_assert(Geometry::F33 && GeometrySoftplus::F33 && !Geometry250::F33, "weight packing rule of readconv_pack.py");
 static_assert(Geometry::F33_32 && GeometrySoftplus::F33_32, "weight packing rule of readconv_pack.py");
 // bf16x3: [1 + 2 (3 + extra) layers][4 blocks][6 steps][hi | lo][64 lanes][8 bf16] = 12 288 floats per layer behind the blob
-int readconv_bf16x3_extra_floats(int extra_blocks) { return (1 + 2 * (3 + extra_blocks)) * 12288; }
+// and [6 layers 32 -> 32][2 blocks][3 taps][hi | lo][64 lanes][8] = 3 072 floats per layer behind those
+int readconv_bf16x3_extra_floats(int extra_blocks) { return (1 + 2 * (3 + extra_blocks)) * 12288 + 6 * 3072; }
 int readconv_weight_floats(int extra_blocks, bool winograd, int window) {
     if (!winograd) return rc::Offs<false>::off_d(3 + extra_blocks);
     return window == 150 ? rc::Offs<true, true>::off_d(3 + extra_blocks) : rc::Offs<true>::off_d(3 + extra_blocks);
@@ -237,6 +238,23 @@ __device__ __forceinline__ int split_off(int row, int g, int part) { return row 
 __device__ __forceinline__ unsigned short to_bf16(float x) {            // v_cvt_pk_bf16_f32: round to nearest even
     const __bf16 h = (__bf16)x;
     return __builtin_bit_cast(unsigned short, h);
+}
+// 32 channels: a row is 128 bytes = eight 16-byte chunks, chunk g + 4 * part (g = 8-channel group 0..3), XOR-swizzled with
+// 2 * ((row >> 1) & 3): two rows share a 256-byte bank span, and the chunks of neighbouring lane quarters differ in bit 0.
+__device__ __forceinline__ int split_off32(int row, int g, int part) { return row * 128 + 16 * ((g + 4 * part) ^ (2 * ((row >> 1) & 3))); }
+__device__ __forceinline__ void split4(f32x4 v, bf16x4& h, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned short hi = to_bf16(v[e]);
+        h[e] = (short)hi;
+        l[e] = (short)to_bf16(v[e] - __uint_as_float((unsigned)hi << 16));
+    }
+}
+__device__ __forceinline__ void store_split32(unsigned char* __restrict__ img, int row, int c4, f32x4 v) {
+    bf16x4 h, l;
+    split4(v, h, l);
+    *(bf16x4*)(img + split_off32(row, c4 >> 1, 0) + 8 * (c4 & 1)) = h;
+    *(bf16x4*)(img + split_off32(row, c4 >> 1, 1) + 8 * (c4 & 1)) = l;
 }
 // channels 4 c4 .. 4 c4 + 3 of `row` <- v, as hi and lo parts (two 8-byte stores)
 __device__ __forceinline__ void store_split(unsigned char* __restrict__ img, int row, int c4, f32x4 v) {
@@ -933,6 +951,68 @@ __device__ __forceinline__ void bf16x3_layer(const unsigned char* __restrict__ i
     });
 }
 
+// The same at 32 channels (the three ResidualBlock(32) ahead of the strided block): the image keeps its shared zero rows
+// (row stride 72 = 71 + 1), which are the padding -- no boundary masks --, a tap is exactly one 32-deep chunk (3 steps of
+// 3 MFMAs per tile), and the 18 tiles are split over 2 channel blocks x 2 position groups of waves (9 tiles each, tile
+// pg + 2 k).  An output row that is a shared zero row is stored as zero and stays zero in the residual stream.
+// OUT_F32: the last layer writes the fp32 SW_W image the strided convolution and its shortcut read.
+template <class CF, int MODE, bool LAST, bool OUT_F32>
+__device__ __forceinline__ void bf16x3_layer32(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                               bf16x8 (&wh)[3], bf16x8 (&wl)[3], const unsigned short* __restrict__ next_w,
+                                               const float* __restrict__ bias, f32x4 (&xres)[CF::NSREG], int wave, int lane) {
+    constexpr int RS = CF::RS1, NT = RS * CF::G / 32, NU = NT * 3;
+    static_assert((RS * CF::G) % 32 == 0 && CF::NW == 4 && NT <= CF::NSREG, "18 tiles over 2 position groups");
+    const int cb = wave % 2, pg = wave / 2, j = lane & 15, q = lane >> 4;
+    const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // image row of (tile pg + 2 k, lane row j, tap) = 16 (pg + 2 k) + j + tap; the swizzle has a period of 8 rows
+    const unsigned char* ph[3];
+    const unsigned char* pl[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        ph[s] = in + 16 * pg * 128 + split_off32(j + s, q, 0);
+        pl[s] = in + 16 * pg * 128 + split_off32(j + s, q, 1);
+    }
+    unsigned zmask = 0;                          // bit k: this lane's row of the wave's k-th tile is a shared zero row
+#pragma unroll
+    for (int k = 0; k < NT; ++k) zmask |= ((((pg + 2 * k) * 16 + j) % RS) == RS - 1 ? 1u : 0u) << k;
+    bf16x8 rh[2], rl[2];
+    auto issue = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int k = u / 3, s = u % 3;
+        rh[u & 1] = *(const bf16x8*)(ph[s] + k * 32 * 128);
+        rl[u & 1] = *(const bf16x8*)(pl[s] + k * 32 * 128);
+    };
+    f32x4 acc_a = b4, acc_b = zero4;
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int k = u / 3, s = u % 3;
+        if constexpr (u + 1 < NU) issue(std::integral_constant<int, u + 1>{});
+        const bf16x8 xh = rh[u & 1], xl = rl[u & 1];
+        acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh, acc_a, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xl, acc_b, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xh, acc_b, 0, 0, 0);
+        if constexpr (!LAST && k == NT - 1) {
+            wh[s] = *(const bf16x8*)(next_w + (s * 2) * 512);
+            wl[s] = *(const bf16x8*)(next_w + (s * 2 + 1) * 512);
+        }
+        if constexpr (s == 2) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = CF::act(acc_a[e] + acc_b[e]);
+            if constexpr (MODE == BF_RESID) y = y + xres[k];
+            if ((zmask >> k) & 1u) y = zero4;
+            if constexpr (MODE == BF_RESID) xres[k] = y;
+            const int row = 16 * (pg + 2 * k) + j + 1;
+            if constexpr (OUT_F32) *(f32x4*)((float*)out + img_off<32, SW_W>(row, 4 * cb + q)) = y;
+            else store_split32(out, row, 4 * cb + q, y);
+            acc_a = b4;
+            acc_b = zero4;
+        }
+    });
+}
+
 // ---- stem conv1: pileup bytes -> 16 channels (valid convolution over the stacked reads) ---------------
 // The bytes are read as they are (no float copy): lane (j, q) of a tile needs k = 4*step + q of row j, and
 // k = tap*C + c is the byte offset from the row start.  Tiles of a wave: t = wave + 4*i; pairs of tiles in
@@ -1401,9 +1481,43 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
 
     // ---- 3 x ResidualBlock(32): x -> relu(conv) -> relu(conv) + x --------------------------------
     __syncthreads();
+    // bf16x3: this wave's split weights of the 32-channel layers, [6 layers][2 blocks][3 taps][hi | lo][64 lanes][8] behind
+    // the 64-channel layers' block
+    const unsigned short* const WS32 = (const unsigned short*)(W + O::off_d(NB64)) + (1 + 2 * NB64) * 24576 + cb2 * 3072 + lane * 8;
+    bf16x8 cwh[3], cwl[3];
+    if constexpr (BF16) {
+        // the stem's fp32 output becomes the residual stream (registers) and, in place, the split image the first
+        // convolution reads: every lane picks up the float4s it will own in every 32-channel layer
+        const int j = lane & 15, q = lane >> 4, pg = wave / 2;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            cwh[st] = *(const bf16x8*)(WS32 + (st * 2) * 512);
+            cwl[st] = *(const bf16x8*)(WS32 + (st * 2 + 1) * 512);
+        }
+#pragma unroll
+        for (int k = 0; k < RS1 * G / 32; ++k)
+            sreg[k] = *(const f32x4*)(X + img_off<32, SWX>(16 * (pg + 2 * k) + j + 1, 4 * cb2 + q));
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RS1 * G / 32; ++k) store_split32((unsigned char*)X, 16 * (pg + 2 * k) + j + 1, 4 * cb2 + q, sreg[k]);
+        __syncthreads();
+    }
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
         const int off_a = OFF_B + (2 * blk) * (O::W3232D + 32), off_b = off_a + (O::W3232D + 32);
+        if constexpr (BF16) {
+            bf16x3_layer32<CF, BF_PLAIN, false, false>((const unsigned char*)X, (unsigned char*)H, cwh, cwl,
+                                                       WS32 + (2 * blk + 1) * 6144, W + off_a + O::W3232D, sreg, wave, lane);
+            __syncthreads();
+            if (blk < 2)
+                bf16x3_layer32<CF, BF_RESID, false, false>((const unsigned char*)H, (unsigned char*)X, cwh, cwl,
+                                                           WS32 + (2 * blk + 2) * 6144, W + off_b + O::W3232D, sreg, wave, lane);
+            else
+                bf16x3_layer32<CF, BF_RESID, true, true>((const unsigned char*)H, (unsigned char*)X, cwh, cwl, nullptr,
+                                                         W + off_b + O::W3232D, sreg, wave, lane);
+            __syncthreads();
+            continue;
+        }
         // the block's second conv rolls in the next block's first conv, or the strided conv (4 channel blocks;
         // its 6 registers are the first 6 of the 8 a Winograd layer refills)
         const float* nxt = (blk < 2) ? slice(off_b + (W3232 + 32), cb2, NVA) : slice(OFF_C1, cb4, 6);

@@ -173,7 +173,8 @@ def to_bf16_bits(x: np.ndarray) -> np.ndarray:
 
 def pack_bf16x3(nodes, folded) -> np.ndarray:
     """Arithmetic mode "bf16x3": the split weights of the 64 -> 64 trunk convolutions (the strided block's second conv,
-    then the residual blocks' convs, in kernel order) for bf16x3_layer in readconv_fused.hip, appended behind the fp32 blob
+    then the residual blocks' convs, in kernel order) and of the six 32 -> 32 ones for bf16x3_layer / bf16x3_layer32 in
+    readconv_fused.hip, appended behind the fp32 blob
     (whose biases these layers keep using): w = hi + lo with hi = bf16(w), lo = bf16(w - hi);
         [layer][4 channel blocks][6 steps s = 2 tap + h][hi | lo][64 lanes][8]
         lane l, element i  =  W[out = 16 block + (l & 15)][in = 32 h + 8 (l >> 4) + i][tap]
@@ -195,8 +196,22 @@ def pack_bf16x3(nodes, folded) -> np.ndarray:
                 for h in range(2):
                     for part in (hi, lo):
                         parts.append(part[out_idx[cb][:, None], in_idx[h], tap].ravel())            # [lane][i]
+    # the six 32 -> 32 convolutions of the ResidualBlock(32)s: one 32-deep chunk per tap
+    #     [layer][2 channel blocks][3 taps][hi | lo][64 lanes][8],  lane l, element i = W[16 block + (l & 15)][8 (l >> 4) + i][tap]
+    out32 = np.arange(2)[:, None] * 16 + (lanes & 15)[None, :]
+    in32 = 8 * (lanes >> 4)[:, None] + np.arange(8)[None, :]                                         # [lane, i]
+    for c in convs[:6]:
+        w, _ = folded[c.key]
+        assert w.shape == (32, 32, 3), w.shape
+        w = w.astype(np.float32)
+        hi = to_bf16_bits(w)
+        lo = to_bf16_bits(w - (hi.astype(np.uint32) << np.uint32(16)).view(np.float32))
+        for cb in range(2):
+            for tap in range(3):
+                for part in (hi, lo):
+                    parts.append(part[out32[cb][:, None], in32, tap].ravel())
     bits = np.concatenate(parts).astype(np.uint16)
-    assert bits.size == len(layers) * 24576
+    assert bits.size == len(layers) * 24576 + 6 * 6144
     return bits.view(np.float32).copy()
 
 

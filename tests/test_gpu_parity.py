@@ -540,7 +540,7 @@ def test_bf16x3_mode_frames_and_posteriors(cfg, kw):
     state = weights.synth_state(spec, seed=21)
     hybrid = "hybrid_coverage" in kw
     batch = _with_extremes(synth.make_sites(150, seed=5 + len(cfg), **kw), 77, hybrid, kw.get("channels", 6))
-    exact, split = Engine(spec, state, device=0), Engine(spec, state, device=0, arithmetic="bf16x3")
+    exact, split = Engine(spec, state, device=0, arithmetic="fp32"), Engine(spec, state, device=0, arithmetic="bf16x3")
     assert split.program.arithmetic == "bf16x3" and exact.program.arithmetic == "fp32"
     fused = [i for i, o in enumerate(split.program.ops) if o.kind == 8]
     assert len(fused) == (2 if hybrid else 1)
