@@ -885,6 +885,12 @@ __device__ __forceinline__ void wino3_layer(const float* __restrict__ in, float*
 // `wh` / `wl`: this wave's weights, [6 steps] x 8 bf16 per lane; unless LAST they are refilled in place with the next
 // layer's (`next_w`: this wave's block and lane, [6 steps][hi | lo][64 lanes][8]) after their last use.
 enum { BF_PLAIN = 0, BF_RESID = 1 };
+// Operand requests run BF16_DEPTH steps ahead of the MFMAs that consume them (measured 1 / 2 / 3 / 4: 8.15 / 7.91 / 7.95 /
+// 7.93 ms for the kernel), and a tile's epilogue is deferred behind the first MFMAs of the next tile (7.75 -> 7.68 ms);
+// profiles/r03_bf16x3_experiments.txt has the ablations (without its MFMAs the kernel is no faster: the layers are bound by
+// their LDS operand stream and VALU epilogues, not by the matrix pipe)
+constexpr int BF16_DEPTH = 2;
+constexpr bool BF16_DEFER = true;
 template <class CF, int MODE, bool LAST, bool OUT_F32>
 __device__ __forceinline__ void bf16x3_layer(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
                                              bf16x8 (&wh)[6], bf16x8 (&wl)[6], const unsigned short* __restrict__ next_w,
@@ -894,7 +900,6 @@ __device__ __forceinline__ void bf16x3_layer(const unsigned char* __restrict__ i
     const int cb = wave, j = lane & 15, q = lane >> 4;
     const f32x4 b4 = *(const f32x4*)(bias + cb * 16 + 4 * q);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     // image row of (tile k, lane row j, tap) = 16 k + j + tap (flat row + 1 leading zero row - 1 pad): the swizzle term
     // depends on (j + tap) & 7 only, so a tile adds a constant
     const unsigned char* ph[6];
@@ -904,49 +909,64 @@ __device__ __forceinline__ void bf16x3_layer(const unsigned char* __restrict__ i
         ph[s] = in + split_off(j + s / 2, 4 * (s & 1) + q, 0);
         pl[s] = in + split_off(j + s / 2, 4 * (s & 1) + q, 1);
     }
-    bf16x8 rh[2], rl[2];
+    const unsigned char* const zrow = in + 16 * q;          // the image's leading zero row (both parts of it are zeros)
+    constexpr int DEPTH = BF16_DEPTH;            // operand requests in flight ahead of the MFMAs that consume them
+    bf16x8 rh[DEPTH + 1], rl[DEPTH + 1];
     auto issue = [&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        constexpr int k = u / 6, s = u % 6;
-        rh[u & 1] = *(const bf16x8*)(ph[s] + k * 16 * 256);
-        rl[u & 1] = *(const bf16x8*)(pl[s] + k * 16 * 256);
-    };
-    f32x4 acc_a = b4, acc_b = zero4;
-    issue(std::integral_constant<int, 0>{});
-    static_for<0, NU>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
         constexpr int k = u / 6, s = u % 6, tap = s / 2;
-        if constexpr (u + 1 < NU) issue(std::integral_constant<int, u + 1>{});
-        bf16x8 xh = rh[u & 1], xl = rl[u & 1];
-        // read boundaries inside the tile: flat row 16 k + jj opens a read -> its tap 0 is padding; closes one -> tap 2 is
+        const unsigned char* a_h = ph[s] + k * 16 * 256;
+        const unsigned char* a_l = pl[s] + k * 16 * 256;
+        // read boundaries inside the tile: flat row 16 k + jj opens a read -> its tap 0 is padding; closes one -> its tap 2
+        // is.  Those lanes fetch the zero row instead (one select per address, not eight per operand).
         constexpr int first = ((16 * k + RS - 1) / RS) * RS - 16 * k, last = ((16 * k + RS) / RS) * RS - 1 - 16 * k;
         if constexpr (tap == 0 && 16 * k + first > 0 && first >= 0 && first < 16) {
-            xh = (j == first) ? zero8 : xh;
-            xl = (j == first) ? zero8 : xl;
+            a_h = (j == first) ? zrow : a_h;
+            a_l = (j == first) ? zrow : a_l;
         }
         if constexpr (tap == 2 && last < 16 && 16 * k + last < RS * CF::G - 1) {
-            xh = (j == last) ? zero8 : xh;
-            xl = (j == last) ? zero8 : xl;
+            a_h = (j == last) ? zrow : a_h;
+            a_l = (j == last) ? zrow : a_l;
         }
-        acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh, acc_a, 0, 0, 0);
-        acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xl, acc_b, 0, 0, 0);
-        acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xh, acc_b, 0, 0, 0);
+        rh[u % (DEPTH + 1)] = *(const bf16x8*)a_h;
+        rl[u % (DEPTH + 1)] = *(const bf16x8*)a_l;
+    };
+    // tile k accumulates in acc[k & 1]; its epilogue (sum, ReLU, residual, split, stores) runs behind the first MFMAs of
+    // tile k + 1, whose accumulators are the other pair: no wait for the matrix pipe between tiles
+    f32x4 acc_a[2] = {b4, b4}, acc_b[2] = {zero4, zero4};
+    auto epilogue = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = CF::act(acc_a[k & 1][e] + acc_b[k & 1][e]);
+        if constexpr (MODE == BF_RESID) {
+            y = y + xres[k];
+            xres[k] = y;
+        }
+        if constexpr (OUT_F32) *(f32x4*)((float*)out + img_off<64, SW_3>(16 * k + j + 1, 4 * cb + q)) = y;
+        else store_split(out, 16 * k + j + 1, 4 * cb + q, y);
+        acc_a[k & 1] = b4;
+        acc_b[k & 1] = zero4;
+    };
+    static_for<0, DEPTH>(issue);
+    static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int k = u / 6, s = u % 6;
+        if constexpr (u + DEPTH < NU) issue(std::integral_constant<int, u + DEPTH>{});
+        __builtin_amdgcn_sched_barrier(0);                    // requests stay ahead of the MFMAs, step by step
+        const bf16x8 xh = rh[u % (DEPTH + 1)], xl = rl[u % (DEPTH + 1)];
+        acc_a[k & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh, acc_a[k & 1], 0, 0, 0);
+        acc_b[k & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xl, acc_b[k & 1], 0, 0, 0);
+        acc_b[k & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xh, acc_b[k & 1], 0, 0, 0);
         if constexpr (!LAST && k == NT - 1) {                 // the next layer's weights roll in after their last use
             wh[s] = *(const bf16x8*)(next_w + (s * 2) * 512);
             wl[s] = *(const bf16x8*)(next_w + (s * 2 + 1) * 512);
         }
-        if constexpr (s == 5) {
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = CF::act(acc_a[e] + acc_b[e]);
-            if constexpr (MODE == BF_RESID) {
-                y = y + xres[k];
-                xres[k] = y;
-            }
-            if constexpr (OUT_F32) *(f32x4*)((float*)out + img_off<64, SW_3>(16 * k + j + 1, 4 * cb + q)) = y;
-            else store_split(out, 16 * k + j + 1, 4 * cb + q, y);
-            acc_a = b4;
-            acc_b = zero4;
+        if constexpr (BF16_DEFER) {
+            if constexpr (s == 1 && k >= 1) epilogue(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
+            if constexpr (u == NU - 1) epilogue(std::integral_constant<int, NT - 1>{});
+        } else if constexpr (u % (NU / NT) == NU / NT - 1) {
+            epilogue(std::integral_constant<int, k>{});
         }
     });
 }
@@ -976,39 +996,48 @@ __device__ __forceinline__ void bf16x3_layer32(const unsigned char* __restrict__
     unsigned zmask = 0;                          // bit k: this lane's row of the wave's k-th tile is a shared zero row
 #pragma unroll
     for (int k = 0; k < NT; ++k) zmask |= ((((pg + 2 * k) * 16 + j) % RS) == RS - 1 ? 1u : 0u) << k;
-    bf16x8 rh[2], rl[2];
+    constexpr int DEPTH = BF16_DEPTH;
+    bf16x8 rh[DEPTH + 1], rl[DEPTH + 1];
     auto issue = [&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int k = u / 3, s = u % 3;
-        rh[u & 1] = *(const bf16x8*)(ph[s] + k * 32 * 128);
-        rl[u & 1] = *(const bf16x8*)(pl[s] + k * 32 * 128);
+        rh[u % (DEPTH + 1)] = *(const bf16x8*)(ph[s] + k * 32 * 128);
+        rl[u % (DEPTH + 1)] = *(const bf16x8*)(pl[s] + k * 32 * 128);
     };
-    f32x4 acc_a = b4, acc_b = zero4;
-    issue(std::integral_constant<int, 0>{});
+    f32x4 acc_a[2] = {b4, b4}, acc_b[2] = {zero4, zero4};
+    auto epilogue = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = CF::act(acc_a[k & 1][e] + acc_b[k & 1][e]);
+        if constexpr (MODE == BF_RESID) y = y + xres[k];
+        if ((zmask >> k) & 1u) y = zero4;
+        if constexpr (MODE == BF_RESID) xres[k] = y;
+        const int row = 16 * (pg + 2 * k) + j + 1;
+        if constexpr (OUT_F32) *(f32x4*)((float*)out + img_off<32, SW_W>(row, 4 * cb + q)) = y;
+        else store_split32(out, row, 4 * cb + q, y);
+        acc_a[k & 1] = b4;
+        acc_b[k & 1] = zero4;
+    };
+    static_for<0, DEPTH>(issue);
     static_for<0, NU>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int k = u / 3, s = u % 3;
-        if constexpr (u + 1 < NU) issue(std::integral_constant<int, u + 1>{});
-        const bf16x8 xh = rh[u & 1], xl = rl[u & 1];
-        acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh, acc_a, 0, 0, 0);
-        acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xl, acc_b, 0, 0, 0);
-        acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xh, acc_b, 0, 0, 0);
+        if constexpr (u + DEPTH < NU) issue(std::integral_constant<int, u + DEPTH>{});
+        __builtin_amdgcn_sched_barrier(0);                    // requests stay ahead of the MFMAs, step by step
+        const bf16x8 xh = rh[u % (DEPTH + 1)], xl = rl[u % (DEPTH + 1)];
+        acc_a[k & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh, acc_a[k & 1], 0, 0, 0);
+        acc_b[k & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xl, acc_b[k & 1], 0, 0, 0);
+        acc_b[k & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xh, acc_b[k & 1], 0, 0, 0);
         if constexpr (!LAST && k == NT - 1) {
             wh[s] = *(const bf16x8*)(next_w + (s * 2) * 512);
             wl[s] = *(const bf16x8*)(next_w + (s * 2 + 1) * 512);
         }
-        if constexpr (s == 2) {
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = CF::act(acc_a[e] + acc_b[e]);
-            if constexpr (MODE == BF_RESID) y = y + xres[k];
-            if ((zmask >> k) & 1u) y = zero4;
-            if constexpr (MODE == BF_RESID) xres[k] = y;
-            const int row = 16 * (pg + 2 * k) + j + 1;
-            if constexpr (OUT_F32) *(f32x4*)((float*)out + img_off<32, SW_W>(row, 4 * cb + q)) = y;
-            else store_split32(out, row, 4 * cb + q, y);
-            acc_a = b4;
-            acc_b = zero4;
+        if constexpr (BF16_DEFER) {
+            if constexpr (s == 1 && k >= 1) epilogue(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{});
+            if constexpr (u == NU - 1) epilogue(std::integral_constant<int, NT - 1>{});
+        } else if constexpr (u % (NU / NT) == NU / NT - 1) {
+            epilogue(std::integral_constant<int, k>{});
         }
     });
 }
