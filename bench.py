@@ -461,61 +461,66 @@ def main():
         except Exception as exc:
             print(f"two-engine leg failed: {exc!r}", file=sys.stderr)
 
-        # ---- the selectable arithmetic mode bf16x3 (read convolver's residual trunk on the bf16 matrix cores as 3-term
-        # splits, fp32 residual stream): NOT the headline -- `value` is exact fp32 -- reported beside it with its own parity
-        try:
-            engb = Engine(spec, state, device=dev_index, arithmetic="bf16x3")
-            resb = []
-            for b in pool[:2]:
-                a, p = b.n_alleles, n_pairs(b.alleles_per_site)
-                resb.append(dict(batch=b, reads=torch.from_numpy(b.reads0).to(dev),
-                                 out=(torch.empty((1, a), dtype=torch.float32, device=dev), None,
-                                      torch.empty((4, p), dtype=torch.float32, device=dev))))
+        # ---- the selectable arithmetic modes (read convolver's residual trunk on the bf16 matrix cores as 3-term splits,
+        # fp32 residual stream): NOT the headline -- `value` is exact fp32 -- reported beside it with their own parity
+        bf16x3 = {}
+        for mode in ("bf16x3", "bf16x3+32"):
+            try:
+                engb = Engine(spec, state, device=dev_index, arithmetic=mode)
+                resb = []
+                for b in pool[:2]:
+                    a, p = b.n_alleles, n_pairs(b.alleles_per_site)
+                    resb.append(dict(batch=b, reads=torch.from_numpy(b.reads0).to(dev),
+                                     out=(torch.empty((1, a), dtype=torch.float32, device=dev), None,
+                                          torch.empty((4, p), dtype=torch.float32, device=dev))))
 
-            def bstep(i):
-                r = resb[i % len(resb)]
-                engb.forward(r["reads"], r["batch"].reads_per_allele0, r["batch"].alleles_per_site, stream=stream,
-                             out=r["out"], posteriors=True)
-            for i in range(3):
-                bstep(i)
-            torch.cuda.synchronize(dev)
-            engb.set_profiling(40, only="readconv_fused")
-            t1 = time.perf_counter()
-            for i in range(40):
-                bstep(i)
-            torch.cuda.synchronize(dev)
-            dt_b = time.perf_counter() - t1
-            rows_b, _ = engb.op_times_ms()
-            engb.set_profiling(0)
-            kernel_ms = max(r[2] for r in rows_b)
-            pipe_b = HostPipeline(engb, depth=2, posteriors=True)
-            for i in range(4):
-                pipe_b.submit(piece_batches[i % len(piece_batches)], tag=i)
-            pipe_b.flush()
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            got = 0
-            for i in range(60):
-                got += len(pipe_b.submit(piece_batches[i % len(piece_batches)], tag=i))
-            got += len(pipe_b.flush())
-            torch.cuda.synchronize(dev)
-            dt_h = time.perf_counter() - t1
-            bf16x3 = {"device_resident": round(args.sites * 40 / dt_b, 1), "host_to_host": round(args.sites * got / dt_h, 1),
-                      "unit": "sites/s", "ms_per_launch": round(1e3 * dt_b / 40, 4), "readconv_launch_ms": round(kernel_ms, 4),
-                      "arithmetic": "read convolver: stem, strided convolution + shortcut and per-allele sums exact fp32; the six "
-                                    "32 -> 32 and seven 64 -> 64 residual-trunk convolutions as x w ~= xh wh + xh wl + xl wh on "
-                                    "v_mfma_f32_16x16x32_bf16 with the residual stream kept in fp32 registers; allele stage exact fp32",
-                      "note": "Engine(..., arithmetic='bf16x3'): selectable, never the default; `value` above is exact fp32"}
-            if cpu is not None and getattr(cpu_baseline, "reference_answers", None) is not None:
-                check, want_probs, want_post = cpu_baseline.reference_answers
-                gl, _, gp = engb.forward_batch(check, posteriors=True)
-                bf16x3["parity"] = {"max_abs_delta_allele_probability": float(np.abs(1.0 / (1.0 + np.exp(-gl[0].astype(np.float64))) - want_probs).max()),
-                                    "max_abs_delta_pair_posterior": float(np.abs(gp[0] - want_post).max()), "tolerance": 1e-4,
-                                    "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
-            del resb
-            engb.close()
-        except Exception as exc:
-            print(f"bf16x3 leg failed: {exc!r}", file=sys.stderr)
+                def bstep(i):
+                    r = resb[i % len(resb)]
+                    engb.forward(r["reads"], r["batch"].reads_per_allele0, r["batch"].alleles_per_site, stream=stream,
+                                 out=r["out"], posteriors=True)
+                for i in range(3):
+                    bstep(i)
+                torch.cuda.synchronize(dev)
+                engb.set_profiling(40, only="readconv_fused")
+                t1 = time.perf_counter()
+                for i in range(40):
+                    bstep(i)
+                torch.cuda.synchronize(dev)
+                dt_b = time.perf_counter() - t1
+                rows_b, _ = engb.op_times_ms()
+                engb.set_profiling(0)
+                kernel_ms = max(r[2] for r in rows_b)
+                pipe_b = HostPipeline(engb, depth=2, posteriors=True)
+                for i in range(4):
+                    pipe_b.submit(piece_batches[i % len(piece_batches)], tag=i)
+                pipe_b.flush()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                got = 0
+                for i in range(60):
+                    got += len(pipe_b.submit(piece_batches[i % len(piece_batches)], tag=i))
+                got += len(pipe_b.flush())
+                torch.cuda.synchronize(dev)
+                dt_h = time.perf_counter() - t1
+                split_layers = 7 if mode == "bf16x3" else 13
+                entry = {"device_resident": round(args.sites * 40 / dt_b, 1), "host_to_host": round(args.sites * got / dt_h, 1),
+                         "unit": "sites/s", "ms_per_launch": round(1e3 * dt_b / 40, 4), "readconv_launch_ms": round(kernel_ms, 4),
+                         "split_convolutions": split_layers}
+                if cpu is not None and getattr(cpu_baseline, "reference_answers", None) is not None:
+                    check, want_probs, want_post = cpu_baseline.reference_answers
+                    gl, _, gp = engb.forward_batch(check, posteriors=True)
+                    entry["parity"] = {"max_abs_delta_allele_probability": float(np.abs(1.0 / (1.0 + np.exp(-gl[0].astype(np.float64))) - want_probs).max()),
+                                       "max_abs_delta_pair_posterior": float(np.abs(gp[0] - want_post).max()), "tolerance": 1e-4,
+                                       "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
+                bf16x3[mode] = entry
+                del resb
+                engb.close()
+            except Exception as exc:
+                print(f"{mode} leg failed: {exc!r}", file=sys.stderr)
+        bf16x3["arithmetic"] = ("read convolver: stem, strided convolution + shortcut and per-allele sums exact fp32; the seven 64 -> 64 "
+                                "residual-trunk convolutions ('bf16x3') and the six 32 -> 32 ones too ('bf16x3+32') as x w ~= xh wh + xh wl "
+                                "+ xl wh on v_mfma_f32_16x16x32_bf16 with the residual stream kept in fp32 registers; allele stage exact fp32")
+        bf16x3["note"] = "Engine(..., arithmetic=...): selectable, never the default; `value` above is exact fp32"
 
         # ---- latency: the reference's deployment form is ONE site per call (caller_calling.py:872-891) ------------
         try:

@@ -32,7 +32,7 @@ SEG_R0A, SEG_R1A, SEG_AS = 0, 1, 2
 BUF_NONE, BUF_READS0, BUF_READS1, BUF_REF, BUF_FIRST_SCRATCH = -1, 0, 1, 2, 3
 (OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED, OP_LAYERNORM,
  OP_COMPRESSOR_FUSED) = range(1, 11)
-FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS, FLAG_WINOGRAD, FLAG_BF16X3 = 1, 2, 4, 8, 16, 32, 64
+FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS, FLAG_WINOGRAD, FLAG_BF16X3, FLAG_BF16X3_32 = 1, 2, 4, 8, 16, 32, 64, 128
 OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
             8: "readconv_fused", 9: "layernorm", 10: "compressor_fused"}
 
@@ -93,7 +93,8 @@ class Program:
     fused_read_convolver: bool = False
     fused_compressor: bool = False
     winograd: bool = False           # k3/s1/p1 convolutions run in Winograd form (F(2,3) / F(3,3)) where a kernel offers it
-    arithmetic: str = "fp32"         # "bf16x3": the read convolver's 64-channel trunk as 3-term bf16 splits (selectable mode)
+    arithmetic: str = "fp32"         # "bf16x3": the read convolver's 64-channel trunk as 3-term bf16 splits; "bf16x3+32": the 32-channel
+                                     # blocks too (selectable modes, never the default)
 
     def describe(self) -> str:
         lines = [f"program {self.spec_name}: {len(self.ops)} ops, {len(self.buffers)} buffers, "
@@ -198,10 +199,13 @@ def _is_canonical_read_convolver(nodes, cin) -> bool:
     return _canonical_read_convolver_extras(nodes, cin) == 0
 
 
+ARITHMETICS = ("fp32", "bf16x3", "bf16x3+32")
+
+
 class _Lowering:
     def __init__(self, spec: ns.ModelSpec, state, fused: bool, winograd: bool = True, arithmetic: str = "fp32"):
-        if arithmetic not in ("fp32", "bf16x3"):
-            raise ValueError(f"arithmetic must be 'fp32' or 'bf16x3', not {arithmetic!r}")
+        if arithmetic not in ARITHMETICS:
+            raise ValueError(f"arithmetic must be one of {ARITHMETICS}, not {arithmetic!r}")
         self.arithmetic = arithmetic
         self.used_bf16x3 = False
         self.spec = spec
@@ -396,10 +400,10 @@ class _Lowering:
             wflag = FLAG_WINOGRAD if self.winograd else 0
             # arithmetic mode bf16x3 (never the default): the 64 -> 64 trunk convolutions of the whole-kernel form on the
             # bf16 matrix cores as 3-term splits; their split weights ride behind the fp32 blob
-            if (self.arithmetic == "bf16x3" and self.fused is True and self.winograd and spec.window == 150 and extras == 0
+            if (self.arithmetic != "fp32" and self.fused is True and self.winograd and spec.window == 150 and extras == 0
                     and not softplus):
                 packed = np.concatenate([packed, readconv_pack.pack_bf16x3(nodes, self.folded)])
-                wflag |= FLAG_BF16X3
+                wflag |= FLAG_BF16X3 | (FLAG_BF16X3_32 if self.arithmetic == "bf16x3+32" else 0)
                 self.used_bf16x3 = True
             w_off = self.blob.add(packed)
             if self.fused == "trunk":
@@ -593,8 +597,8 @@ def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool 
     per pair) -- same fp32 arithmetic, results differ from the direct form by float re-association only."""
     low = _Lowering(spec, state, fused, winograd, arithmetic)
     n_experts, has_meta = low.lower()
-    if arithmetic == "bf16x3" and not low.used_bf16x3:
-        raise ValueError("arithmetic='bf16x3' exists for the canonical 150 bp ReLU read convolver in the whole-kernel "
+    if arithmetic != "fp32" and not low.used_bf16x3:
+        raise ValueError("arithmetic='bf16x3' / 'bf16x3+32' exists for the canonical 150 bp ReLU read convolver in the whole-kernel "
                          "Winograd form (fused=True, winograd=True): this model / these options do not run it")
     buffers = _allocate(low.ops, low.values)
     return Program(

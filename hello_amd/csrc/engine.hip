@@ -214,6 +214,8 @@ int validate_model(const hello_model_desc* d) {
                 !(d->window == 150 && (o.flags & HELLO_FLAG_WINOGRAD) && (o.flags & HELLO_FLAG_SRC_U8) && o.k == 0))
                 return fail(HELLO_ERR_MODEL, "op %d: the Softplus read convolver runs whole (from the bytes), in Winograd "
                                              "form, on 150 bp windows, without extra blocks", i);
+            if ((o.flags & HELLO_FLAG_BF16X3_32) && !(o.flags & HELLO_FLAG_BF16X3))
+                return fail(HELLO_ERR_MODEL, "op %d: HELLO_FLAG_BF16X3_32 extends HELLO_FLAG_BF16X3", i);
             if ((o.flags & HELLO_FLAG_BF16X3) &&
                 !(d->window == 150 && !wide && (o.flags & HELLO_FLAG_WINOGRAD) && (o.flags & HELLO_FLAG_SRC_U8) && o.k == 0 &&
                   !(o.flags & HELLO_FLAG_SOFTPLUS)))
@@ -808,7 +810,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.softplus = (o.flags & HELLO_FLAG_SOFTPLUS) ? 1 : 0;
                 a.extra_blocks = o.k;
                 a.winograd = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
-                a.bf16x3 = (o.flags & HELLO_FLAG_BF16X3) ? 1 : 0;
+                a.bf16x3 = (o.flags & HELLO_FLAG_BF16X3) ? ((o.flags & HELLO_FLAG_BF16X3_32) ? 2 : 1) : 0;
                 const bool wide = o.cout == 128;
                 if ((size_t)o.w_off + (wide ? hello::readconv_wide_weight_floats() : hello::readconv_weight_floats(o.k, a.winograd, d.window)) +
                         (a.bf16x3 ? hello::readconv_bf16x3_extra_floats(o.k) : 0) > e->n_weight_floats)

@@ -77,8 +77,9 @@ struct ReadConvArgs {
     int winograd;              // k3/s1 convolutions in Winograd form: F(3,3) trunk at 150 bp, else F(2,3) (weights packed accordingly)
     int window;                // pileup window: 150 | 250 (250: `reads` + Winograd form only)
     int softplus;              // Softplus instead of ReLU (`reads` + Winograd form, 150 bp only)
-    int bf16x3;                // arithmetic mode bf16x3 (`reads` + Winograd form, 150 bp, ReLU, no extra blocks): the 64-channel
-                               // trunk on the bf16 matrix cores as 3-term splits; its split weights follow the fp32 blob
+    int bf16x3;                // arithmetic mode bf16x3 (`reads` + Winograd form, 150 bp, ReLU, no extra blocks): 1 = the 64-channel
+                               // trunk on the bf16 matrix cores as 3-term splits, 2 = the 32-channel blocks too ("bf16x3+32");
+                               // the split weights follow the fp32 blob
 };
 bool readconv_supports_window(int window);
 int readconv_reads_per_group(int window);

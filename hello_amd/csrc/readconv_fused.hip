@@ -1338,7 +1338,7 @@ __device__ __forceinline__ void stem_conv3_pool_wino(const float* __restrict__ i
     });
 }
 
-template <class CF, bool STEM, int NB64, bool WINO, bool BF16 = false>
+template <class CF, bool STEM, int NB64, bool WINO, bool BF16 = false, bool BF16_32 = false>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
     constexpr bool F33 = WINO && CF::F33;                     // 64-channel residual blocks in F(3,3) form
@@ -1346,6 +1346,8 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     // cores as 3-term splits (bf16x3_layer); everything before them -- stem, 32-channel blocks, the strided convolution
     // and its shortcut -- and the per-allele sums stay exact fp32
     static_assert(!BF16 || (F33 && CF::ACT == ACT_RELU), "bf16x3: the 150 bp ReLU geometry of the Winograd kernel");
+    // BF16_32 ("bf16x3+32"): the six 32 -> 32 convolutions of the ResidualBlock(32)s too (otherwise exact fp32 F(3,3))
+    static_assert(!BF16_32 || BF16, "the 32-channel split layers extend the bf16x3 mode");
     using O = Offs<WINO, F33>;
     constexpr int L1 = CF::L1, RS1 = CF::RS1, L2 = CF::L2, RS2 = CF::RS2;
     static_assert(CF::COMPACT || WINO, "the zero-row 64-channel geometry is implemented for the Winograd form only");
@@ -1514,7 +1516,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     // the 64-channel layers' block
     const unsigned short* const WS32 = (const unsigned short*)(W + O::off_d(NB64)) + (1 + 2 * NB64) * 24576 + cb2 * 3072 + lane * 8;
     bf16x8 cwh[3], cwl[3];
-    if constexpr (BF16) {
+    if constexpr (BF16_32) {
         // the stem's fp32 output becomes the residual stream (registers) and, in place, the split image the first
         // convolution reads: every lane picks up the float4s it will own in every 32-channel layer
         const int j = lane & 15, q = lane >> 4, pg = wave / 2;
@@ -1534,7 +1536,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
         const int off_a = OFF_B + (2 * blk) * (O::W3232D + 32), off_b = off_a + (O::W3232D + 32);
-        if constexpr (BF16) {
+        if constexpr (BF16_32) {
             bf16x3_layer32<CF, BF_PLAIN, false, false>((const unsigned char*)X, (unsigned char*)H, cwh, cwl,
                                                        WS32 + (2 * blk + 1) * 6144, W + off_a + O::W3232D, sreg, wave, lane);
             __syncthreads();
@@ -1706,7 +1708,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     flush();
 }
 
-template <class CF, int NB64, bool WINO, bool STEM_ONLY = false, bool BF16 = false>
+template <class CF, int NB64, bool WINO, bool STEM_ONLY = false, bool BF16 = false, bool BF16_32 = false>
 static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     // the LDS opt-in is a per-device attribute of the function: once per device this process launches on
     // (threads that share a device race benignly: the call is idempotent)
@@ -1717,10 +1719,10 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     if (!configured) {
         hipError_t e = hipSuccess;
         if constexpr (!STEM_ONLY)
-            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false, NB64, WINO, BF16>,
+            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, false, NB64, WINO, BF16, BF16_32>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64, WINO, BF16>,
+            e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64, WINO, BF16, BF16_32>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
         if (e != hipSuccess) return e;
         configured = true;
@@ -1730,9 +1732,9 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     const unsigned groups = (unsigned)((a.n_reads + per_wg - 1) / per_wg);       // workgroups
     if (a.reads) {
         if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO, BF16>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO, BF16, BF16_32>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     } else if constexpr (!STEM_ONLY) {
-        hipLaunchKernelGGL((readconv_kernel<CF, false, NB64, WINO, BF16>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((readconv_kernel<CF, false, NB64, WINO, BF16, BF16_32>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);
     } else {
         return hipErrorInvalidValue;
     }
@@ -1748,7 +1750,8 @@ hipError_t launch_readconv_fused(const ReadConvArgs& a, hipStream_t stream) {
     if (a.window != 150) return hipErrorInvalidValue;
     if (a.bf16x3) {                // arithmetic mode bf16x3: canonical architecture, whole kernel from the bytes, Winograd form
         if (!a.reads || !a.winograd || a.extra_blocks != 0 || a.softplus) return hipErrorInvalidValue;
-        return launch_cfg<Geometry, 3, true, true, true>(a, stream);
+        return a.bf16x3 > 1 ? launch_cfg<Geometry, 3, true, true, true, true>(a, stream)
+                            : launch_cfg<Geometry, 3, true, true, true, false>(a, stream);
     }
     if (a.softplus) {              // the Softplus configuration: whole kernel, Winograd form
         if (!a.reads || !a.winograd || a.extra_blocks != 0) return hipErrorInvalidValue;

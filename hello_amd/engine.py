@@ -109,18 +109,20 @@ class Engine:
     def __init__(self, spec: ns.ModelSpec, state, device: int = 0, fused: bool = True, winograd: bool = True,
                  program: Optional["compiler.Program"] = None, arithmetic: Optional[str] = None):
         """``program``: an already compiled (or deliberately edited) program to load instead of compiling.
-        ``arithmetic``: "fp32" (exact fp32 everywhere, the default) or "bf16x3" -- the read convolver's 64 -> 64 trunk
+        ``arithmetic``: "fp32" (exact fp32 everywhere, the default), "bf16x3" -- the read convolver's seven 64 -> 64 trunk
         convolutions on the bf16 matrix cores as 3-term splits (x w ~= xh wh + xh wl + xl wh; ~2^-17 per product, the
-        residual stream kept in fp32); DESIGN.md section 3.1d gives its measured accuracy and speed.  An explicit "bf16x3"
+        residual stream kept in fp32) -- or "bf16x3+32" -- its six 32 -> 32 convolutions too; DESIGN.md section 3.2 gives
+        their measured accuracy and speed.  An explicit "bf16x3"
         raises where the mode does not exist (other read-convolver geometries, layer-by-layer paths); the environment
-        variable HELLO_ARITHMETIC=bf16x3 only changes the default of callers that pass nothing, and only where the mode
+        variable HELLO_ARITHMETIC=bf16x3 (or bf16x3+32) only changes the default of callers that pass nothing, and only where the mode
         exists (it is how the whole parity suite is run in this mode)."""
         self.lib = load_library()
         self.spec = spec
         if program is None:
-            if arithmetic is None and os.environ.get("HELLO_ARITHMETIC", "fp32") == "bf16x3":
+            if arithmetic is None and os.environ.get("HELLO_ARITHMETIC", "fp32") != "fp32":
                 try:
-                    program = compiler.compile_model(spec, state, fused=fused, winograd=winograd, arithmetic="bf16x3")
+                    program = compiler.compile_model(spec, state, fused=fused, winograd=winograd,
+                                                     arithmetic=os.environ["HELLO_ARITHMETIC"])
                 except ValueError:
                     program = None
             if program is None:

@@ -527,9 +527,10 @@ def test_bf16x3_mode_is_refused_where_it_does_not_exist():
         Engine(ns.build("single_tech"), weights.synth_state(ns.build("single_tech"), seed=1), device=0, arithmetic="fp16")
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3+32"])
 @pytest.mark.parametrize("cfg,kw", [("single_tech", dict(coverage=30)), ("hybrid_full", dict(coverage=20, hybrid_coverage=10)),
                                     ("single_tech_hp", dict(coverage=(20, 80), channels=7, tech="pacbio"))])
-def test_bf16x3_mode_frames_and_posteriors(cfg, kw):
+def test_bf16x3_mode_frames_and_posteriors(cfg, kw, mode):
     """The read convolver's 64-channel trunk on the bf16 matrix cores (3-term splits, fp32 residual stream): its
     per-allele frames against the exact-fp32 engine's (the same kernel up to the strided block) -- a relative deviation at
     the 1e-5 level of the frames' scale, never more than 1e-4 --, bit-reproducible, and the model's posteriors against
@@ -540,8 +541,8 @@ def test_bf16x3_mode_frames_and_posteriors(cfg, kw):
     state = weights.synth_state(spec, seed=21)
     hybrid = "hybrid_coverage" in kw
     batch = _with_extremes(synth.make_sites(150, seed=5 + len(cfg), **kw), 77, hybrid, kw.get("channels", 6))
-    exact, split = Engine(spec, state, device=0, arithmetic="fp32"), Engine(spec, state, device=0, arithmetic="bf16x3")
-    assert split.program.arithmetic == "bf16x3" and exact.program.arithmetic == "fp32"
+    exact, split = Engine(spec, state, device=0, arithmetic="fp32"), Engine(spec, state, device=0, arithmetic=mode)
+    assert split.program.arithmetic == mode and exact.program.arithmetic == "fp32"
     fused = [i for i, o in enumerate(split.program.ops) if o.kind == 8]
     assert len(fused) == (2 if hybrid else 1)
     for i in fused:
@@ -553,7 +554,7 @@ def test_bf16x3_mode_frames_and_posteriors(cfg, kw):
             eng.capture_op_output(None)
         scale = float(np.abs(frames[0]).max())
         dev = float(np.abs(frames[1] - frames[0]).max()) / scale
-        print(f"bf16x3 {cfg} op {i}: frames max |d| / scale = {dev:.2e} (scale {scale:.3g})")
+        print(f"{mode} {cfg} op {i}: frames max |d| / scale = {dev:.2e} (scale {scale:.3g})")
         assert 0 < dev < 1e-4
     logits, meta, post = split.forward_batch(batch, posteriors=True)
     again, _, post2 = split.forward_batch(batch, posteriors=True)
@@ -562,7 +563,7 @@ def test_bf16x3_mode_frames_and_posteriors(cfg, kw):
     want, _ = mo.forward_batch(mo.Oracle(spec, state, backend="torch"), batch, chunk_sites=1)
     d_oracle = float(np.abs(sigmoid(logits) - sigmoid(want)).max())
     d_exact = float(np.abs(post - exact_post).max())
-    print(f"bf16x3 {cfg}: allele probabilities vs oracle {d_oracle:.2e}, posteriors vs the fp32 engine {d_exact:.2e}")
+    print(f"{mode} {cfg}: allele probabilities vs oracle {d_oracle:.2e}, posteriors vs the fp32 engine {d_exact:.2e}")
     assert d_oracle < PROB_ATOL and d_exact < PROB_ATOL
     exact.close()
     split.close()

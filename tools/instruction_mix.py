@@ -4,7 +4,7 @@ issue-cycle estimate that goes with it.
 On gfx950 fp32 MFMA and the other vector / LDS / memory instructions of a SIMD issue one after the other
 (tools/mfma_valu_issue.hip): a v_mfma_f32_16x16x4_f32 takes 32 cycles, everything else ~4, scalar ~1.  The
 estimate  32*MFMA + 4*(VALU + LDS + VMEM) + SALU  per wave and group of reads lands within 4 % of the measured
-kernel time (2 waves per SIMD: time per group and workgroup slot = 2 x that).
+kernel time (2 waves per SIMD: time per group and workgroup slot = 2 x that, profiles/DESIGN_history_r01_r02.md section 7).
 
     python tools/instruction_mix.py [mangled-kernel-name-substring]
 """

@@ -1,7 +1,7 @@
 """How far inside the 1e-4 posterior tolerance the engine stays as the weights grow: the stress batches of
 tests/test_gpu_parity.py (the five BASELINE configurations with ragged extremes: 1-read next to 1000-read alleles, dummy
 reads only, identical alleles) at weight gains 0.5 ... 8 against the CPU oracle scored one site per call.  Nothing is
-asserted: the table is the evidence (profiles/r03_parity_margin.txt; DESIGN.md section 4 quotes it).
+asserted: the table is the evidence (profiles/r03_parity_margin_{fp32,bf16x3}.txt; DESIGN.md section 4 quotes them).
 
     python tools/parity_margin.py [--gains 0.5,1,2.5,4,6,8] [--arithmetic fp32]
 """
