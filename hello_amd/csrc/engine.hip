@@ -731,6 +731,17 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.src_u8 = (o.flags & HELLO_FLAG_SRC_U8) ? 1 : 0;
                 a.wino = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
                 if (!a.src) return fail(HELLO_ERR_ARG, "op %d reads an input the caller did not supply", op_index);
+                if (o.flags & HELLO_FLAG_BF16X3) {
+                    a.kpad = o.k * o.cin;
+                    a.cout_pad = ((o.cout + 127) / 128) * 128;
+                    if (a.wino || !hello::conv1d_bf16x3_supported(a))
+                        return fail(HELLO_ERR_MODEL, "op %d: this convolution has no bf16x3 form (float input, cin %% 32 == 0, "
+                                                     "cout %% 4 == 0, not Winograd-packed)", op_index);
+                    if ((size_t)o.w_off + (size_t)a.cout_pad * a.kpad > e->n_weight_floats)
+                        return fail(HELLO_ERR_MODEL, "op %d: split weight block truncated", op_index);
+                    HIP_TRY(hello::launch_conv1d_bf16x3(a, stream));
+                    break;
+                }
                 if (a.wino) {
                     a.kpad = (hello::conv1d_wino_outputs_per_tile(o.lin) + 2) * o.cin;
                     a.cout_pad = o.cout;
