@@ -254,12 +254,7 @@ hipError_t launch_conv1d(const ConvArgs& a, hipStream_t stream) {
     const bool two = (a.cout_pad % 64) == 0;
     const bool vec = !a.src_u8 && (a.cin % 4 == 0);
     {
-        static const long long cus = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-                n = 256;
-            return (long long)n;
-        }();
+        const long long cus = device_cus();
         const long long big_wgs = (long long)gx * (a.cout_pad / (vec && (a.cout_pad % 128) == 0 ? 128 : (two ? 64 : 32)));
         const long long act_bytes = (a.m_total / a.lout) * (long long)a.lin * a.cin * 4;
         if (!a.src_u8 && (a.cin % 16) == 0 && (a.cout % 16) == 0 && a.lout > 0 && (a.m_total % a.lout) == 0 && big_wgs * 4 <= cus &&

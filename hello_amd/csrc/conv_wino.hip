@@ -353,12 +353,7 @@ hipError_t launch_conv1d_wino(const ConvArgs& args, hipStream_t stream) {
     // 16-channel chunks and 3.84 ms with 8-channel chunks; 8 waves x 128 channels with double-buffered LDS 4.26 ms
     const int variant = (m == 3 ? 6 : 0) + (a.relu < 0 || a.relu > 2 ? 0 : a.relu) * 2 + (a.res ? 1 : 0);
     // small launches: 16 x 16 blocks per wave, no LDS (conv1d_wino_small_kernel)
-    static const long long cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        return (long long)n;
-    }();
+    const long long cus = device_cus();
     const long long big_wgs = (tiles + BMP - 1) / BMP * (a.cout / BN);
     if (big_wgs * SMALL_LAUNCH_DIVISOR <= cus && (a.cin % 16) == 0 && (long long)a.m_total * a.cin * 4 < (1LL << 31)) {
         const dim3 sgrid((unsigned)((tiles + 15) / 16 * (a.cout / 16)));

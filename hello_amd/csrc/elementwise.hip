@@ -349,4 +349,16 @@ hipError_t launch_posteriors(const float* logits, const float* meta, const int32
     return hipGetLastError();
 }
 
+int device_cus() {
+    static int cached[64] = {};          // benign race: every thread writes the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 }  // namespace hello

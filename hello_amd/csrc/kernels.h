@@ -7,6 +7,10 @@
 
 namespace hello {
 
+// Compute units of the CURRENT device (hipGetDevice), cached per device: launch plans and the small- / large-launch kernel
+// choice depend on it, and a process may drive several devices (256 when the query fails).
+int device_cus();
+
 struct ConvArgs {
     const void* src;      // float or uint8 [rows][lin][cin]
     float* dst;           // [rows][lout][cout]

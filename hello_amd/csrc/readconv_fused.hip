@@ -155,13 +155,7 @@ int readconv_frame_rows(int window) { return window == 250 ? Geometry250::L2 : G
 // not fill the chip (two workgroups per CU run at a time).  Pick the count in 1..8 that minimises
 // ceil(workgroups / resident slots) x groups, largest count on ties.
 int readconv_groups_per_workgroup(long long n_reads, int window) {
-    static const long long slots = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        return 2LL * cus;
-    }();
+    const long long slots = 2LL * device_cus();      // two workgroups per CU
     const int G = readconv_reads_per_group(window);
     const long long groups = (n_reads + G - 1) / G;
     int best = 1;
@@ -184,13 +178,7 @@ int readconv_groups_per_workgroup(long long n_reads, int window) {
 // largest n on ties.  Batches smaller than one round of n-group workgroups keep the single launch of
 // readconv_groups_per_workgroup.
 ReadConvPlan readconv_plan(long long n_reads, int window) {
-    static const long long slots = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        return 2LL * cus;
-    }();
+    const long long slots = 2LL * device_cus();      // two workgroups per CU
     const int G = readconv_reads_per_group(window);
     const long long groups = (n_reads + G - 1) / G;
     ReadConvPlan best{1, groups, 0};
