@@ -30,11 +30,12 @@ from . import weights as wts
 ROWS_READS0, ROWS_READS1, ROWS_ALLELES, ROWS_SITES = 0, 1, 2, 3
 SEG_R0A, SEG_R1A, SEG_AS = 0, 1, 2
 BUF_NONE, BUF_READS0, BUF_READS1, BUF_REF, BUF_FIRST_SCRATCH = -1, 0, 1, 2, 3
+OP_XATTN_FRONT = 11
 (OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED, OP_LAYERNORM,
  OP_COMPRESSOR_FUSED) = range(1, 11)
 FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS, FLAG_WINOGRAD, FLAG_BF16X3, FLAG_BF16X3_32 = 1, 2, 4, 8, 16, 32, 64, 128
 OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
-            8: "readconv_fused", 9: "layernorm", 10: "compressor_fused"}
+            8: "readconv_fused", 9: "layernorm", 10: "compressor_fused", 11: "xattn_front"}
 
 
 @dataclass
@@ -225,6 +226,7 @@ class _Lowering:
         self.arithmetic = arithmetic
         self.used_bf16x3 = False
         self.used_bf16x3_allele = False
+        self.used_xattn_front = False
         self.spec = spec
         self.state = state
         self.folded = wts.fold(spec, state)
@@ -309,6 +311,27 @@ class _Lowering:
                                macs_per_row=ns.macs(nodes, 36), exec_macs_per_row=readconv_pack.compressor_executed_macs(blocks)))
             self.used_fused_compressor = True
             return y
+        front = readconv_pack.xattn_front_match(nodes) if (self.fused is True and self.winograd and isinstance(x, tuple)
+                                                           and "allele" not in self.arithmetic) else None
+        if front is not None:
+            allele, sites = x
+            site = sites[front[0].pick]
+            if (site is not None and (allele.length, allele.channels) == (18, 128) and allele.domain == ROWS_ALLELES
+                    and site.domain == ROWS_SITES):
+                # the expert's front in ONE LDS-resident launch: MIX + 1x1 + the strided block's first convolution and its
+                # shortcut (xattn_front_kernel); the block's second convolution follows with the shortcut as its residual
+                mix, conv11, blk = front
+                y2, sc = self.new(ROWS_ALLELES, 9, 256), self.new(ROWS_ALLELES, 9, 256)
+                w_off = self.blob.add(readconv_pack.pack_xattn_front(conv11, blk, self.folded))
+                self.ops.append(Op(OP_XATTN_FRONT, ROWS_ALLELES, src0=allele.vid, src1=site.vid, dst=y2.vid, res=sc.vid,
+                                   cin=128, cout=256, k=3, stride=2, pad=1, lin=18, lout=9, flags=FLAG_RELU, seg=SEG_AS,
+                                   a0=float(mix.coeffs[0]), a1=float(mix.coeffs[1]), w_off=w_off, b_off=w_off,
+                                   name=conv11.key.rsplit(".network", 1)[0] + ".front",
+                                   macs_per_row=ns.macs([conv11], 18) + ns.macs([blk.body[0]], 18) + ns.macs(blk.shortcut, 18),
+                                   exec_macs_per_row=readconv_pack.xattn_front_executed_macs()))
+                self.used_xattn_front = True
+                x = self.conv(blk.body[1], y2, res=sc)
+                nodes = nodes[3:]
         for node in nodes:
             if isinstance(node, ns.Conv):
                 x = self.conv(node, x)
@@ -584,25 +607,35 @@ def _allocate(ops: List[Op], values: Dict[int, Value]):
     for i, o in enumerate(ops):
         for v in (o.src0, o.src1, o.res):
             if v >= 1000:
-                last_use[v] = i
+                last_use[v] = i        # (the fused expert front WRITES its `res` buffer: its readers come later and overwrite this)
     phys: List[Tuple[int, int]] = [(0, 0)] * BUF_FIRST_SCRATCH      # reserved ids
     free: Dict[int, List[int]] = {d: [] for d in range(4)}
     assigned: Dict[int, int] = {}
+    def place(vid):
+        v = values[vid]
+        need = v.floats_per_row
+        pool = free[v.domain]
+        if pool:
+            # best fit: smallest buffer that is large enough, else the largest one (it grows)
+            fits = [p for p in pool if phys[p][1] >= need]
+            pick = min(fits, key=lambda p: phys[p][1]) if fits else max(pool, key=lambda p: phys[p][1])
+            pool.remove(pick)
+            phys[pick] = (v.domain, max(phys[pick][1], need))
+        else:
+            pick = len(phys)
+            phys.append((v.domain, need))
+        assigned[vid] = pick
+
     for i, o in enumerate(ops):
+        if o.kind == OP_XATTN_FRONT:          # two outputs: dst (the strided convolution) and res (its shortcut)
+            place(o.dst)
+            place(o.res)
+            for vsrc in {o.src0, o.src1}:
+                if vsrc >= 1000 and last_use.get(vsrc) == i and vsrc in assigned:
+                    free[values[vsrc].domain].append(assigned[vsrc])
+            continue
         if o.kind != OP_HEAD:
-            v = values[o.dst]
-            need = v.floats_per_row
-            pool = free[v.domain]
-            if pool:
-                # best fit: smallest buffer that is large enough, else the largest one (it grows)
-                fits = [p for p in pool if phys[p][1] >= need]
-                pick = min(fits, key=lambda p: phys[p][1]) if fits else max(pool, key=lambda p: phys[p][1])
-                pool.remove(pick)
-                phys[pick] = (v.domain, max(phys[pick][1], need))
-            else:
-                pick = len(phys)
-                phys.append((v.domain, need))
-            assigned[o.dst] = pick
+            place(o.dst)
         # release inputs whose last use is this op (after the output was placed: no aliasing)
         for vsrc in {o.src0, o.src1, o.res}:
             if vsrc >= 1000 and last_use.get(vsrc) == i and vsrc in assigned:

@@ -165,7 +165,7 @@ int validate_model(const hello_model_desc* d) {
     };
     for (int i = 0; i < d->n_ops; ++i) {
         const hello_op& o = d->ops[i];
-        if (o.kind < HELLO_OP_CONV1D || o.kind > HELLO_OP_COMPRESSOR_FUSED)
+        if (o.kind < HELLO_OP_CONV1D || o.kind > HELLO_OP_XATTN_FRONT)
             return fail(HELLO_ERR_MODEL, "op %d: unknown kind %d", i, o.kind);
         if (o.domain < 0 || o.domain > 3) return fail(HELLO_ERR_MODEL, "op %d: bad domain", i);
         if (!buf_ok(o.src0, false)) return fail(HELLO_ERR_MODEL, "op %d: bad src0", i);
@@ -188,6 +188,14 @@ int validate_model(const hello_model_desc* d) {
               (o.flags & HELLO_FLAG_WINOGRAD) && o.w_off >= 0))
             return fail(HELLO_ERR_MODEL, "op %d: the fused compressor maps [36][64] rows to [18][128] with 2 or 3 identity blocks, "
                                          "Winograd form", i);
+        if (o.kind == HELLO_OP_XATTN_FRONT &&
+            !(o.domain == HELLO_ROWS_ALLELES && o.cin == 128 && o.cout == 256 && o.lin == 18 && o.lout == 9 && o.k == 3 && o.stride == 2 &&
+              o.pad == 1 && o.seg == HELLO_SEG_ALLELES_TO_SITES && o.w_off >= 0 && o.src1 != HELLO_BUF_NONE &&
+              o.res >= HELLO_BUF_FIRST_SCRATCH && o.res != o.dst && o.res != o.src0 && o.res != o.src1 && o.dst != o.src0 && o.dst != o.src1 &&
+              d->buffers[o.res].domain == HELLO_ROWS_ALLELES && d->buffers[o.res].floats_per_row >= 9 * 256 &&
+              d->buffers[o.src1].domain == HELLO_ROWS_SITES))
+            return fail(HELLO_ERR_MODEL, "op %d: the fused expert front maps [18][128] allele rows (src0) and site rows (src1) to two "
+                                         "distinct [9][256] allele buffers, dst and res", i);
         if (o.kind == HELLO_OP_LAYERNORM && (o.cin <= 0 || o.cin > 512 || o.lin <= 0 || o.w_off < 0 || o.b_off < 0 || !(o.a0 > 0.f)))
             return fail(HELLO_ERR_MODEL, "op %d: bad LayerNorm (1..512 channels, eps > 0)", i);
         if ((o.kind == HELLO_OP_SEGSUM || o.kind == HELLO_OP_MIX || o.kind == HELLO_OP_READCONV_FUSED) &&
@@ -280,6 +288,11 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
                                      : (size_t)((o.k * o.cin + 31) / 32) * 32;
             w_end = (size_t)o.w_off + cpad * kpad;
             b_end = (size_t)o.b_off + cpad;
+            if (o.flags & HELLO_FLAG_BF16X3) {       // split weights: [hi | lo][cout padded to 128][k * cin] bf16
+                const size_t c128 = (size_t)((o.cout + 127) / 128) * 128;
+                w_end = (size_t)o.w_off + c128 * (size_t)(o.k * o.cin);
+                b_end = (size_t)o.b_off + c128;
+            }
         } else if (o.kind == HELLO_OP_HEAD) {
             w_end = (size_t)o.w_off + (size_t)o.cout * o.cin;
             b_end = (size_t)o.b_off + o.cout;
@@ -288,6 +301,9 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
             b_end = (size_t)o.b_off + o.cin;
         } else if (o.kind == HELLO_OP_COMPRESSOR_FUSED) {
             w_end = (size_t)o.w_off + hello::compressor_weight_floats(o.k);
+            b_end = (size_t)o.b_off;
+        } else if (o.kind == HELLO_OP_XATTN_FRONT) {
+            w_end = (size_t)o.w_off + hello::xattn_front_weight_floats();
             b_end = (size_t)o.b_off;
         } else if (o.kind == HELLO_OP_READCONV_FUSED) {
             w_end = (size_t)o.w_off + (o.cout == 128 ? hello::readconv_wide_weight_floats()
@@ -375,7 +391,7 @@ int hello_engine_set_profiling(hello_engine* e, int max_forwards) {
 
 int hello_engine_set_profiling_filter(hello_engine* e, int32_t op_kind) {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
-    if (op_kind < 0 || op_kind > HELLO_OP_COMPRESSOR_FUSED) return fail(HELLO_ERR_ARG, "unknown op kind %d", op_kind);
+    if (op_kind < 0 || op_kind > HELLO_OP_XATTN_FRONT) return fail(HELLO_ERR_ARG, "unknown op kind %d", op_kind);
     e->prof_filter = op_kind;
     e->prof_count = 0;               // recordings made under another filter do not mix
     return HELLO_OK;
@@ -797,6 +813,20 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 HIP_TRY(hello::launch_compressor_fused(a, stream));
                 break;
             }
+            case HELLO_OP_XATTN_FRONT: {
+                hello::XattnFrontArgs a{};
+                a.alleles = (const float*)ptr(o.src0);
+                a.sites = (const float*)ptr(o.src1);
+                a.owner = e->site_of_allele;
+                a.y2 = (float*)ptr(o.dst);
+                a.sc = (float*)ptr(o.res);
+                a.w = e->d_weights + o.w_off;
+                a.n_items = rows;
+                a.a0 = o.a0;
+                a.a1 = o.a1;
+                HIP_TRY(hello::launch_xattn_front(a, stream));
+                break;
+            }
             case HELLO_OP_LAYERNORM:
                 HIP_TRY(hello::launch_layernorm((const float*)ptr(o.src0), (const float*)ptr(o.res), (float*)ptr(o.dst),
                                                 e->d_weights + o.w_off, e->d_weights + o.b_off, rows * o.lin, o.cin, o.a0,
@@ -855,7 +885,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
         if (op_index == e->debug_op) {
             // snapshot of this op's output before a later op reuses the buffer
             const size_t per_row = o.kind == HELLO_OP_CONCAT ? (size_t)o.lout * (o.cin + o.c1)
-                                   : (o.kind == HELLO_OP_CONV1D || o.kind == HELLO_OP_READCONV_FUSED || o.kind == HELLO_OP_COMPRESSOR_FUSED) ? (size_t)o.lout * o.cout
+                                   : (o.kind == HELLO_OP_CONV1D || o.kind == HELLO_OP_READCONV_FUSED || o.kind == HELLO_OP_COMPRESSOR_FUSED || o.kind == HELLO_OP_XATTN_FRONT) ? (size_t)o.lout * o.cout
                                    : (o.kind == HELLO_OP_MAXPOOL ? (size_t)o.lout * o.cin : (size_t)o.lin * o.cin);
             const size_t n = (size_t)rows * per_row;
             if (n * sizeof(float) > e->d_debug.cap) {

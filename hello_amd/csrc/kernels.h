@@ -133,6 +133,22 @@ int compressor_weight_floats(int blocks);
 bool compressor_supports_blocks(int blocks);
 hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream);
 
+// ---- fused front of the allele-level expert (readconv_fused.hip) ----------------------------------------------------------
+// architectures/xattn_subtract.py:9-60: x = a0 a + a1 s[owner], 1x1 128->128 + ReLU, then the strided block's first convolution
+// (k3 s2 p1 128->256 + ReLU -> y2) and its 1x1 s2 shortcut (-> sc); [items][18][128] -> two [items][9][256] tensors.
+struct XattnFrontArgs {
+    const float* alleles;      // [items][18][128] compressed allele frames
+    const float* sites;        // [sites][18][128] their per-site sums
+    const int32_t* owner;      // [items] site of each allele
+    float* y2;                 // [items][9][256]
+    float* sc;                 // [items][9][256]
+    const float* w;            // packed block, hello_amd/readconv_pack.py pack_xattn_front
+    long long n_items;
+    float a0, a1;              // LinearCombination coefficients (2, -1)
+};
+int xattn_front_weight_floats();
+hipError_t launch_xattn_front(const XattnFrontArgs& a, hipStream_t stream);
+
 // ---- pileup-tensor producer (featurize.hip) ----------------------------------------------------------
 struct FeaturizeArgs {
     const uint8_t* bases;            // all reads' bases, concatenated (ASCII)

@@ -203,7 +203,7 @@ ReadConvPlan readconv_plan(long long n_reads, int window) {
 // chunk swizzles: 16-byte chunk index of a row XORed with a function of the row
 template <int C>
 __device__ __forceinline__ int swz(int row) {
-    return C == 64 ? 2 * (row & 7) : (C == 32 ? 2 * ((row >> 1) & 3) : 2 * ((row >> 2) & 1));
+    return (C == 64 || C == 128) ? 2 * (row & 7) : (C == 32 ? 2 * ((row >> 1) & 3) : 2 * ((row >> 2) & 1));
 }
 
 // Images read by the Winograd layers (and by the stride-2 convolutions) are walked two rows per lane, so
@@ -212,7 +212,7 @@ __device__ __forceinline__ int swz(int row) {
 // trade places and the chunk is XORed with 2*((row>>2)&3).
 // SW_3 (64 channels): images walked THREE rows per lane (F(3,3) layers): chunk ^ 2*((row/3)&7); rows 3j..3j+2 share
 // their swizzle, and 16 lanes' rows 3j+i hit 16 distinct bank groups.
-enum { SW_OLD = 0, SW_W = 1, SW_3 = 2, SW_SPLIT = 3 };
+enum { SW_OLD = 0, SW_W = 1, SW_3 = 2, SW_SPLIT = 3, SW_GLOBAL = 4 };   // SW_GLOBAL: `out` is global memory, rows of COUT floats
 
 // ---- split images (arithmetic mode bf16x3: the 64-channel trunk on the bf16 matrix cores) ------------------------------
 // A value x is kept as two bf16: hi = bf16(x), lo = bf16(x - hi): 16 of its 24 mantissa bits.  A 64-channel row is 256
@@ -263,10 +263,10 @@ __device__ __forceinline__ int img_off(int row, int chunk) {     // float offset
     } else if constexpr (SW == SW_3) {
         static_assert(C % 64 == 0, "SW_3 images have whole bank rows of channels (64 | 128): the XOR stays inside a row's first 16 chunks");
         return row * C + 4 * (chunk ^ (2 * ((row / 3) & 7)));
-    } else if constexpr (C == 64) {
-        return row * 64 + 4 * (chunk ^ (2 * ((row >> 1) & 7)));
+    } else if constexpr (C == 64 || C == 128) {
+        return row * C + 4 * (chunk ^ (2 * ((row >> 1) & 7)));
     } else {
-        static_assert(C == 32, "SW_W images have 32 or 64 channels");
+        static_assert(C == 32, "SW_W images have 32, 64 or 128 channels");
         const int prow = (row & ~3) | ((row & 1) << 1) | ((row >> 1) & 1);
         return prow * 32 + 4 * (chunk ^ (2 * ((row >> 2) & 3)));
     }
@@ -350,7 +350,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
                                            f32x4 (&w)[KT * CIN / 16], const float* __restrict__ next_w,
                                            const float* __restrict__ bias, f32x4 (&sreg)[CF::NSREG],
                                            unsigned padmask, float* __restrict__ dump, int wave, int lane,
-                                           int = 0) {
+                                           int vrows_rt = 0) {      // SW_GLOBAL: output rows >= vrows_rt are not written
     constexpr int M = CIN / 16, NCB = COUT / 16, NPG = CF::NW / NCB, ITER = T / NPG;
     static_assert(NPG >= 1 && NCB * NPG == CF::NW && T % NPG == 0, "waves must tile channel blocks x position groups");
     const int cb = wave % NCB, pg = wave / NCB;
@@ -411,7 +411,8 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     };
     // output pointer of the k-th tile: base + constant; rows past the group go to the dump slot
     static_assert(SOUT != SW_SPLIT || (COUT == 64 && MODE == MODE_PLAIN), "split images: the 64-channel trunk's input");
-    float* const outbase = out + 16 * pg * COUT + img_off<COUT, SOUT == SW_SPLIT ? SW_OLD : SOUT>(j + LEAD, 4 * cb + q);
+    static_assert(SOUT != SW_GLOBAL || MODE == MODE_PLAIN, "global outputs: plain convolutions");
+    float* const outbase = out + 16 * pg * COUT + img_off<COUT, (SOUT == SW_SPLIT || SOUT == SW_GLOBAL) ? SW_OLD : SOUT>(j + LEAD, 4 * cb + q);
     auto out_ptr = [&](int k) -> float* {
         float* ptr = outbase + k * NPG * 16 * COUT;
         if constexpr (SOUT == SW_3)                                     // a swizzle without the tiles' 16-row period
@@ -441,6 +442,9 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
         if ((padmask >> k) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};      // the shared zero row between reads
         if constexpr (SOUT == SW_SPLIT) {                              // hi / lo bf16 parts for the bf16x3 trunk
             if ((pg + NPG * k) * 16 + j < VROWS) store_split((unsigned char*)out, 16 * (pg + NPG * k) + j + LEAD, 4 * cb + q, v);
+        } else if constexpr (SOUT == SW_GLOBAL) {                      // straight to HBM: [flat output row][COUT]
+            const int row = (pg + NPG * k) * 16 + j;
+            if (row < vrows_rt) *(f32x4*)(out + (long long)row * COUT + 16 * cb + 4 * q) = v;
         } else {
             *(f32x4*)out_ptr(k) = v;
         }
@@ -504,11 +508,32 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
             constexpr int tap0 = s0 / M, tap1 = s1 / M;
             constexpr int first0 = ((16 * t0 + RS_OUT - 1) / RS_OUT) * RS_OUT, last0 = ((16 * t0 + RS_OUT) / RS_OUT) * RS_OUT - 1;
             constexpr int first1 = ((16 * t1 + RS_OUT - 1) / RS_OUT) * RS_OUT, last1 = ((16 * t1 + RS_OUT) / RS_OUT) * RS_OUT - 1;
+            if constexpr (RS_OUT < 16) {
+                // short items (the allele stage's 9-row outputs): a tile holds up to two item starts
+                if constexpr (tap0 == 0) {
+                    bool f0 = false;
+                    static_for<0, 16>([&](auto jc) {
+                        constexpr int jj = decltype(jc)::value;
+                        if constexpr ((16 * t0 + jj) % RS_OUT == 0 && 16 * t0 + jj > 0) f0 = f0 || (j == jj);
+                    });
+                    x0 = f0 ? zero4 : x0;
+                }
+                if constexpr (tap1 == 0) {
+                    bool f1 = false;
+                    static_for<0, 16>([&](auto jc) {
+                        constexpr int jj = decltype(jc)::value;
+                        if constexpr ((16 * t1 + jj) % RS_OUT == 0 && 16 * t1 + jj > 0) f1 = f1 || (j == jj);
+                    });
+                    x1 = f1 ? zero4 : x1;
+                }
+                static_assert(RS_OUT >= 16 || STRIDE == 2, "short items: the stride-2 layer (no tap crosses an item's end)");
+            } else {
             if constexpr (tap0 == 0 && first0 > 0 && first0 <= 16 * t0 + 15) x0 = (j == first0 - 16 * t0) ? zero4 : x0;
             // (a stride-2 layer over rows of even length never reads past its row's end: 2 (L/2 - 1) + 1 = L - 1)
             if constexpr (STRIDE == 1 && tap0 == KT - 1 && last0 <= 16 * t0 + 15 && last0 < RS_OUT * CF::G - 1) x0 = (j == last0 - 16 * t0) ? zero4 : x0;
             if constexpr (tap1 == 0 && first1 > 0 && first1 <= 16 * t1 + 15) x1 = (j == first1 - 16 * t1) ? zero4 : x1;
             if constexpr (STRIDE == 1 && tap1 == KT - 1 && last1 <= 16 * t1 + 15 && last1 < RS_OUT * CF::G - 1) x1 = (j == last1 - 16 * t1) ? zero4 : x1;
+            }
         }
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[0], x0[0], a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0], x1[0], a1, 0, 0, 0);
@@ -1922,6 +1947,133 @@ hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream) 
     const unsigned grid = (unsigned)((a.n_items + cc::Cfg::G - 1) / cc::Cfg::G);
     if (a.blocks == 2) hipLaunchKernelGGL(compressor_kernel<2>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
     else hipLaunchKernelGGL(compressor_kernel<3>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+
+// =====================================================================================================================
+// Front of the allele-level expert (architectures/xattn_subtract.py:9-60; MixtureOfExpertsAdvanced.py:142-155), fused:
+//     x = a0 a + a1 s[site(a)]   (LinearCombination of the allele's and its site's compressed frames, [18][128])
+//     y1 = relu(1x1 128->128 (x))
+//     y2 = relu(k3 s2 p1 128->256 (y1))   and   sc = 1x1 s2 128->256 (y1)        -- the strided block's first conv and shortcut
+// One workgroup of 8 waves carries 8 items: x and y1 live in LDS (two images of 8 x 18 rows x 128 channels, stacked without
+// rows between the items), y2 and sc go straight to HBM ([item][9][256] each), where the block's second convolution (Winograd
+// kernel, residual = sc) picks them up.  Replaces four launches (MIX, two 1x1 and one strided CONV1D) and three HBM round
+// trips of [A][18][128].  The 256-channel convolutions run as two passes of 8 channel blocks (waves w and w + 8 of a
+// 16-wave layout); tap 0 of an item's first output row reads zero instead of the previous item's last row.
+namespace xf {
+struct Cfg {
+    static constexpr int ACT = rc::ACT_RELU;
+    static __device__ __forceinline__ float act(float x) { return fmaxf(x, 0.f); }
+    static constexpr int G = 8, NW = 8, THREADS = 64 * NW;
+    static constexpr int L = 18, LO = 9;                 // rows per item before / after the strided block
+    static constexpr int NSREG = 1;
+    static constexpr int A_FLOATS = (L * G + 2) * 128;   // x: leading zero row + 144 rows (+1)
+    static constexpr int B_ROWS = 2 * (16 * 5) + 2;      // y1: the strided layer's fifth (half-empty) tile reads up to row 160
+    static constexpr int LDS_BYTES = (A_FLOATS + B_ROWS * 128) * 4 + 64;
+    // packed weights (floats): conv_layer's [COUT/16][KT][CIN/16][64 lanes][4] + bias[COUT], three convolutions
+    static constexpr int W11 = 8 * 1 * 8 * 256, WS = 16 * 3 * 8 * 256, WSC = 16 * 1 * 8 * 256;
+    static constexpr int OFF_11 = 0, OFF_S = OFF_11 + W11 + 128, OFF_SC = OFF_S + WS + 256, TOTAL = OFF_SC + WSC + 256;
+};
+struct Cfg16 : Cfg {                                     // the 256-channel layers' wave layout: 16 channel blocks
+    static constexpr int NW = 16;
+};
+struct CfgLinear : Cfg16 {                               // the shortcut carries no activation
+    static __device__ __forceinline__ float act(float x) { return x; }
+};
+}  // namespace xf
+
+int xattn_front_weight_floats() { return xf::Cfg::TOTAL; }
+
+__global__ __launch_bounds__(xf::Cfg::THREADS, 2) void xattn_front_kernel(XattnFrontArgs a) {
+    using CF = xf::Cfg;
+    using CF16 = xf::Cfg16;
+    constexpr int G = CF::G, L = CF::L, LO = CF::LO;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const bufA = smem;
+    float* const bufB = smem + CF::A_FLOATS;
+    float* const dump = smem + CF::A_FLOATS + CF::B_ROWS * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long item0 = (long long)blockIdx.x * G;
+    const int n_here = (int)((a.n_items - item0) < G ? (a.n_items - item0) : G);
+    const float* __restrict__ W = a.w;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sreg[CF::NSREG];
+
+    f32x4 w11[8];
+    load_weights<8>(w11, W + CF::OFF_11, wave, lane);
+    {
+        // x = a0 a + a1 s: every thread requests its 9 + 9 float4 first (ONE round trip), then combines and stores
+        constexpr int NLD = G * L * 32 / CF::THREADS;
+        static_assert(NLD * CF::THREADS == G * L * 32, "the input image divides evenly over the threads");
+        const f32x4* src = (const f32x4*)(a.alleles + item0 * (L * 128));
+        f32x4 va[NLD], vs[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int f = tid + CF::THREADS * k;
+            const int it = f / (L * 32);
+            if (it < n_here) {
+                va[k] = src[f];
+                vs[k] = *((const f32x4*)(a.sites + (long long)a.owner[item0 + it] * (L * 128)) + (f - it * (L * 32)));
+            } else {
+                va[k] = zero4;
+                vs[k] = zero4;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int f = tid + CF::THREADS * k;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = a.a0 * va[k][e] + a.a1 * vs[k][e];       // LinearCombination, NNTools.py:771-777
+            *(f32x4*)(bufA + img_off<128, SW_OLD>(1 + (f >> 5), f & 31)) = v;
+        }
+        if (tid < 32) ((f32x4*)bufA)[tid] = zero4;                         // leading zero rows of both images
+        else if (tid < 64) ((f32x4*)bufB)[tid - 32] = zero4;
+    }
+    __syncthreads();
+    // 1x1 128 -> 128 + ReLU (8 channel blocks, 9 tiles each), written for the stride-2 walk of the next layers (SW_W)
+    conv_layer<CF, 128, 128, 1, 1, 0, L, L, L, L * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L * G, false, SW_OLD, SW_W>(
+        bufA, bufB, w11, nullptr, W + CF::OFF_11 + CF::W11, sreg, 0u, dump, wave, lane);
+    __syncthreads();
+    float* const y2 = a.y2 + item0 * (LO * 256);
+    float* const sc = a.sc + item0 * (LO * 256);
+    const int vrows = n_here * LO;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int w16 = wave + 8 * half;                                   // channel block 0..15
+        {
+            f32x4 ws[24];
+            load_weights<24>(ws, W + CF::OFF_S, w16, lane);
+            // k3 s2 p1 128 -> 256 + ReLU; tap 0 of an item's first row reads zero (BMASK), 72 rows = 4.5 tiles
+            conv_layer<CF16, 128, 256, 3, 2, 1, L, LO, LO, 5, MODE_PLAIN, false, GEOM_TRUNK, 16, LO * G, true, SW_W, SW_GLOBAL>(
+                bufB, y2, ws, nullptr, W + CF::OFF_S + CF::WS, sreg, 0u, dump, w16, lane, vrows);
+        }
+        {
+            f32x4 wsc[8];
+            load_weights<8>(wsc, W + CF::OFF_SC, w16, lane);
+            // its 1x1 s2 shortcut (no activation: MODE_TO_REGS' epilogue would keep it in registers, so the plain
+            // epilogue runs with the identity activation of a pass-through configuration)
+            conv_layer<xf::CfgLinear, 128, 256, 1, 2, 0, L, LO, LO, 5, MODE_PLAIN, false, GEOM_TRUNK, 16, LO * G, false, SW_W, SW_GLOBAL>(
+                bufB, sc, wsc, nullptr, W + CF::OFF_SC + CF::WSC, sreg, 0u, dump, w16, lane, vrows);
+        }
+    }
+}
+
+hipError_t launch_xattn_front(const XattnFrontArgs& a, hipStream_t stream) {
+    if (a.n_items <= 0) return hipSuccess;
+    if (!a.alleles || !a.sites || !a.owner || !a.y2 || !a.sc || !a.w) return hipErrorInvalidValue;
+    static bool configured_on[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured_on[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)xattn_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, xf::Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        configured_on[dev] = true;
+    }
+    const unsigned grid = (unsigned)((a.n_items + xf::Cfg::G - 1) / xf::Cfg::G);
+    hipLaunchKernelGGL(xattn_front_kernel, dim3(grid), dim3(xf::Cfg::THREADS), xf::Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 

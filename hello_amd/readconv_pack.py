@@ -165,6 +165,39 @@ def pack(nodes, folded, cin=None, winograd: bool = False, window: int = 150) -> 
     return blob
 
 
+def xattn_front_match(nodes):
+    """(mix, conv 1x1, strided residual block) when ``nodes`` opens like the canonical allele-level expert
+    (architectures/xattn_subtract.py:9-60): LinearCombination of the allele's and its site's frames, Conv 1x1 128->128 + ReLU,
+    then a residual block whose body starts k3 s2 p1 128->256 + ReLU and whose shortcut is a 1x1 s2 128->256 convolution
+    without activation; else None.  What xattn_front_kernel (readconv_fused.hip) fuses."""
+    def conv_is(n, cin, cout, k, stride, pad, act):
+        return (isinstance(n, ns.Conv) and (n.cin, n.cout, n.k, n.stride, n.pad, n.dilation, n.groups, n.act) ==
+                (cin, cout, k, stride, pad, 1, 1, act) and n.norm != "ln")
+    if len(nodes) < 3 or not isinstance(nodes[0], ns.Mix) or not conv_is(nodes[1], 128, 128, 1, 1, 0, "relu"):
+        return None
+    blk = nodes[2]
+    if not (isinstance(blk, ns.Residual) and len(blk.body) == 2 and len(blk.shortcut) == 1
+            and conv_is(blk.body[0], 128, 256, 3, 2, 1, "relu") and conv_is(blk.shortcut[0], 128, 256, 1, 2, 0, "none")
+            and isinstance(blk.body[1], ns.Conv)):
+        return None
+    return nodes[0], nodes[1], blk
+
+
+def pack_xattn_front(conv11, blk, folded) -> np.ndarray:
+    """Weights of xattn_front_kernel: the 1x1, the strided convolution and its shortcut, each in conv_layer's order
+    [cout/16][taps][cin/16][64 lanes][4] followed by its bias."""
+    blob = np.concatenate([_pack_conv(*folded[conv11.key]), _pack_conv(*folded[blk.body[0].key]),
+                           _pack_conv(*folded[blk.shortcut[0].key])])
+    assert blob.size == (8 * 8 * 256 + 128) + (16 * 3 * 8 * 256 + 256) + (16 * 8 * 256 + 256), blob.size
+    return blob
+
+
+def xattn_front_executed_macs() -> float:
+    """MACs the kernel's MFMAs execute per item: 9 + 2 x 5 x (24 + 8) tiles-steps of 4 MFMAs (16 x 16 x 4) per wave, 8 waves,
+    8 items (the 72 output rows of a workgroup fill 4.5 tiles: the fifth is half empty)."""
+    return (9 * 8 + 2 * 5 * (24 + 8)) * 4 * 8 * 1024.0 / 8
+
+
 def to_bf16_bits(x: np.ndarray) -> np.ndarray:
     """float32 -> bf16 bit patterns (uint16), round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)

@@ -90,6 +90,12 @@ typedef enum hello_op_kind {
                               * one LDS-resident kernel: 1x1 64->64, strided block 64->128 with its 1x1 shortcut, k (2 | 3)
                               * identity residual blocks; src0 rows [36][64] -> dst rows [18][128]; ReLU; k3/s1 convolutions
                               * in Winograd F(3,3) form, weights packed by hello_amd/readconv_pack.py pack_compressor       */
+    ,
+    HELLO_OP_XATTN_FRONT = 11 /* the front of the allele-level expert (architectures/xattn_subtract.py:9-60) in one LDS-resident
+                              * kernel: x = a0 src0[a] + a1 src1[site(a)] ([18][128] rows), 1x1 128->128 + ReLU, then the strided
+                              * block's first convolution (k3 s2 p1 128->256 + ReLU) -> dst and its 1x1 s2 shortcut -> the buffer
+                              * named by `res` (an OUTPUT here: the block's second convolution reads it as its residual); both
+                              * [9][256] rows; weights packed by hello_amd/readconv_pack.py pack_xattn_front                  */
 } hello_op_kind;
 
 #define HELLO_FLAG_RELU     1

