@@ -361,7 +361,8 @@ class RecordWriter:
 
 def run(network, shard_paths: Sequence[str], prefix_of, include_hp: bool = False, genomes=None, wanted=None,
         reader_threads: int = 4, record_threads: int = 0, sites_per_launch: int = 8192, reads_per_launch: int = 320_000,
-        read_ahead: Optional[int] = None, depth: int = 2, tags: Optional[list] = None, loader=None, scorer=None) -> "RunStats":
+        read_ahead: Optional[int] = None, depth: int = 2, tags: Optional[list] = None, loader=None, scorer=None,
+        writer_threads: int = 2) -> "RunStats":
     """Score shard files in order with bounded read-ahead: at most ``read_ahead`` loaded shards wait for the GPU, at most
     ``depth`` launches are in flight and at most two scored launches wait for the record writer, whatever the number of
     shards -- host memory is flat over a run."""
@@ -373,6 +374,7 @@ def run(network, shard_paths: Sequence[str], prefix_of, include_hp: bool = False
     read_ahead = read_ahead or max(2 * reader_threads, 4)
     results: "queue.Queue" = queue.Queue(maxsize=2)
     failure: List[BaseException] = []
+    position = {tag: i for i, tag in enumerate(tags)}
 
     def record_loop():
         while True:
@@ -391,8 +393,11 @@ def run(network, shard_paths: Sequence[str], prefix_of, include_hp: bool = False
 
     stats = RunStats()
     t_start = time.perf_counter()
-    thread = threading.Thread(target=record_loop, name="hello-records", daemon=True)
-    thread.start()
+    # the record stage's C call is multi-threaded; the per-shard file writes around it are not: two writer threads take
+    # launches alternately (a launch's shards are written by one thread; the final sort orders records by key, then shard)
+    threads = [threading.Thread(target=record_loop, name=f"hello-records-{k}", daemon=True) for k in range(max(1, writer_threads))]
+    for thread in threads:
+        thread.start()
     try:
         with ThreadPoolExecutor(max_workers=max(1, reader_threads), thread_name_prefix="hello-reader") as pool:
             futures, nxt = [], 0
@@ -428,13 +433,15 @@ def run(network, shard_paths: Sequence[str], prefix_of, include_hp: bool = False
             for done in scorer.flush():
                 results.put(done)
     finally:
-        results.put(None)
-        thread.join()
+        for _ in threads:
+            results.put(None)
+        for thread in threads:
+            thread.join()
     if failure:
         raise failure[0]
     stats.seconds = time.perf_counter() - t_start
     stats.stage_seconds, stats.record_seconds = scorer.stage_seconds, writer.seconds
-    stats.outputs = writer.outputs
+    stats.outputs = sorted(writer.outputs, key=lambda o: position.get(o.tag, 0))       # shard order, whatever thread wrote them
     return stats
 
 

@@ -614,3 +614,24 @@ def test_bf16x3_mode_frames_and_posteriors(cfg, kw, mode):
     assert d_oracle < PROB_ATOL and d_exact < PROB_ATOL
     exact.close()
     split.close()
+
+
+def test_a_site_scored_alone_and_inside_a_large_launch_agree_to_rounding():
+    """launches that cannot fill the chip take the small-launch kernel family (other K-summation order), and a
+    site's per-allele read sums are cut where the fused kernel's workgroups end, so a site's logits depend on the launch it
+    is part of -- at rounding level only: one site per call against the same sites inside a 2 048-site launch."""
+    from hello_amd.engine import Engine
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=9)
+    eng = Engine(spec, state, device=0, arithmetic="fp32")
+    batch = synth.make_sites(2048, seed=12, coverage=30)
+    big, _ = eng.forward_batch(batch)
+    aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
+    worst = 0.0
+    for s in (0, 1, 511, 1024, 2046, 2047):
+        alone, _ = eng.forward_batch(batch.site_slice(s, s + 1))
+        ref = big[:, aoff[s]:aoff[s + 1]]
+        worst = max(worst, float(np.abs(alone - ref).max() / max(1.0, np.abs(ref).max())))
+    print(f"one site per call vs inside a 2 048-site launch: max |d logit| / scale = {worst:.2e}")
+    assert worst < 2e-6
+    eng.close()

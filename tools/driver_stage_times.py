@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--threads", type=int, default=min(16, len(os.sched_getaffinity(0))))
     ap.add_argument("--config", default="single_tech")
+    ap.add_argument("--arithmetic", default="fp32")
     args = ap.parse_args()
     logging.basicConfig(level=logging.WARNING)
     rng = np.random.default_rng(7)
@@ -91,7 +92,8 @@ def main():
         spec = ns.build(args.config)
         model = os.path.join(base, "model.hello.npz")
         loader.save_native(model, args.config, weights.synth_state(spec, seed=1))
-        print(f"# python tools/driver_stage_times.py --sites {args.sites} --shard_sites {args.shard_sites} --threads {args.threads}   "
+        print(f"# python tools/driver_stage_times.py --sites {args.sites} --shard_sites {args.shard_sites} --threads {args.threads} "
+              f"--arithmetic {args.arithmetic}   "
               f"({args.config}, {args.coverage} reads per site, {len(os.sched_getaffinity(0))} CPUs visible)")
         for shard_sites in [int(x) for x in args.shard_sites.split(",")]:
             payload, n_reads = template_payload(rng, shard_sites, args.coverage)
@@ -100,7 +102,8 @@ def main():
                 sdir, work = os.path.join(base, f"shards_{shard_sites}_{label}"), os.path.join(base, f"work_{shard_sites}_{label}")
                 os.makedirs(sdir)
                 write_shards(sdir, payload, count, 700 * shard_sites + 10_000)
-                argv = ["--network", model, "--workdir", work, "--shards", sdir, "--num_threads", str(args.threads)]
+                argv = ["--network", model, "--workdir", work, "--shards", sdir, "--num_threads", str(args.threads),
+                        "--arithmetic", args.arithmetic]
                 captured = []
                 handler = logging.Handler()
                 handler.emit = lambda record, captured=captured: captured.append(record.getMessage())
