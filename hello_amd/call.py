@@ -263,6 +263,14 @@ def _launch_ranks(args) -> int:
     return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode
 
 
+def _resident_mb() -> float:
+    try:
+        with open("/proc/self/statm") as fh:
+            return int(fh.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e6
+    except (OSError, ValueError, IndexError):
+        return float("nan")
+
+
 def shard_read_totals(paths: Sequence[str], threads: int = 4) -> np.ndarray:
     """Reads the featurizer will write per shard (both technologies; dummy reads included): the weight shards are dealt
     to ranks by.  Only the count arrays of each file are read."""
@@ -338,8 +346,9 @@ def main(args) -> str:
                    sites_per_launch=getattr(args, "sites_per_launch", 8192), tags=numbers[lo:hi])
     network.close()
     logger.info("rank %d: %d shards, %d sites, %d reads in %d launches, %.2f s (%.0f sites/s; waiting for readers %.2f s, "
-                "staging %.2f s, record stage %.2f s on its thread)", rank, hi - lo, stats.sites, stats.reads, stats.launches,
-                stats.seconds, stats.sites / max(stats.seconds, 1e-9), stats.wait_read, stats.stage_seconds, stats.record_seconds)
+                "staging %.2f s, record stage %.2f s on its threads; resident set after the loop %.0f MB)", rank, hi - lo,
+                stats.sites, stats.reads, stats.launches, stats.seconds, stats.sites / max(stats.seconds, 1e-9), stats.wait_read,
+                stats.stage_seconds, stats.record_seconds, _resident_mb())
     for out in stats.outputs:                           # call.py:225-229
         if SENTINEL not in open(out.prefix + ".log").read():
             raise ValueError("Did not run: log file %s doesn't have termination string" % (out.prefix + ".log"))
