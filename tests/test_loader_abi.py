@@ -277,3 +277,58 @@ def test_engine_fails_loudly_without_a_gpu():
     spec = ns.build("single_tech")
     with pytest.raises(RuntimeError, match="HIP|device|gfx950"):
         Engine(spec, weights.synth_state(spec, seed=1))
+
+
+def test_expert_front_is_one_fused_op_with_two_outputs_and_the_kernels_weight_layout():
+    """The allele-level expert's front (MIX, 1x1, strided convolution, shortcut: xattn_subtract.py:9-60) lowers to ONE op whose
+    `res` buffer is its second OUTPUT (the shortcut), read as the residual of the block's second convolution; unfused lowerings
+    (fused="trunk", the +allele arithmetic) keep the four launches; other expert shapes (MoEMergedAdvanced's) are not matched."""
+    from hello_amd import readconv_pack as rp
+    spec = ns.build("hybrid_full")
+    state = weights.synth_state(spec, seed=1)
+    prog = compiler.compile_model(spec, state)
+    fronts = [(i, o) for i, o in enumerate(prog.ops) if o.kind == compiler.OP_XATTN_FRONT]
+    assert len(fronts) == 3 and not any(o.kind == compiler.OP_MIX for o in prog.ops)
+    for i, o in fronts:
+        nxt = prog.ops[i + 1]
+        assert (o.cin, o.cout, o.lin, o.lout, o.a0, o.a1) == (128, 256, 18, 9, 2.0, -1.0)
+        assert len({o.src0, o.src1, o.dst, o.res}) == 4 and o.res >= compiler.BUF_FIRST_SCRATCH
+        assert nxt.kind == compiler.OP_CONV1D and nxt.src0 == o.dst and nxt.res == o.res and (nxt.cin, nxt.cout, nxt.k) == (256, 256, 3)
+        assert prog.buffers[o.dst][1] >= 9 * 256 and prog.buffers[o.res][1] >= 9 * 256
+    assert not any(o.kind == compiler.OP_XATTN_FRONT for o in compiler.compile_model(spec, state, fused="trunk").ops)
+    assert not any(o.kind == compiler.OP_XATTN_FRONT for o in compiler.compile_model(ns.build("merged_single"), weights.synth_state(ns.build("merged_single"), seed=1)).ops)
+    mix, conv11, blk = rp.xattn_front_match(spec.nets["xattn0"])
+    blob = rp.pack_xattn_front(conv11, blk, weights.fold(spec, state))
+    w, b = weights.fold(spec, state)[blk.body[0].key]                  # the strided convolution: [cb 16][tap 3][m 8][64 lanes][4]
+    got = blob[8 * 8 * 256 + 128:][:16 * 3 * 8 * 256].reshape(16, 3, 8, 64, 4)
+    for cb, tap, m, lane in ((0, 0, 0, 0), (15, 2, 7, 63), (9, 1, 3, 21)):
+        np.testing.assert_array_equal(got[cb, tap, m, lane], w[16 * cb + (lane & 15), 16 * m + 4 * (lane >> 4):16 * m + 4 * (lane >> 4) + 4, tap])
+
+
+def test_arithmetic_modes_lower_to_flags_and_split_weight_blocks():
+    from hello_amd import readconv_pack as rp
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=1)
+    base = compiler.compile_model(spec, state)
+    sizes = {}
+    for mode, flags in (("bf16x3", compiler.FLAG_BF16X3), ("bf16x3+32", compiler.FLAG_BF16X3 | compiler.FLAG_BF16X3_32)):
+        prog = compiler.compile_model(spec, state, arithmetic=mode)
+        op = next(o for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED)
+        assert op.flags & (compiler.FLAG_BF16X3 | compiler.FLAG_BF16X3_32) == flags and prog.arithmetic == mode
+        sizes[mode] = prog.weights.size - base.weights.size
+        assert [o.kind for o in prog.ops] == [o.kind for o in base.ops]          # only the read convolver changes
+    assert sizes["bf16x3"] == sizes["bf16x3+32"] == 7 * 12288 + 6 * 3072          # one split block serves both levels
+    allele = compiler.compile_model(spec, state, arithmetic="bf16x3+32+allele")
+    convs = [o for o in allele.ops if o.kind == compiler.OP_CONV1D]
+    assert len(convs) == 8 and all(o.flags & compiler.FLAG_BF16X3 and not o.flags & compiler.FLAG_WINOGRAD for o in convs)
+    # hi + lo reproduce a weight to 2^-17 of its magnitude
+    w = np.float32([0.3337, -1.25e-3, 7.0, 1e-20])
+    hi = rp.to_bf16_bits(w)
+    hi_f = (hi.astype(np.uint32) << 16).view(np.float32)
+    lo_f = (rp.to_bf16_bits(w - hi_f).astype(np.uint32) << 16).view(np.float32)
+    assert np.all(np.abs(w - (hi_f + lo_f)) <= np.abs(w) * 2.0 ** -17)
+    for bad, kw in (("bf16x3", dict(winograd=False)), ("bf16x3+32", dict(fused="trunk")), ("fp16", {})):
+        with pytest.raises(ValueError):
+            compiler.compile_model(spec, state, arithmetic=bad, **kw)
+    with pytest.raises(ValueError, match="bf16x3"):
+        compiler.compile_model(ns.build("merged_hybrid_250"), weights.synth_state(ns.build("merged_hybrid_250"), seed=1), arithmetic="bf16x3")
