@@ -345,12 +345,14 @@ __device__ __forceinline__ float row_shl(float v, int n) {
 //   VROWS    output rows >= VROWS are discarded
 template <class CF, int CIN, int COUT, int KT, int STRIDE, int PAD, int RS_IN, int RS_OUT, int LOUT, int T, int MODE,
           bool ROLL, int GEOM = GEOM_TRUNK, int TS = 16, int VROWS = RS_OUT * CF::G, bool BMASK = false,
-          int SIN = SW_OLD, int SOUT = SW_OLD>
+          int SIN = SW_OLD, int SOUT = SW_OLD, bool PARTIAL = false>
 __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* __restrict__ out,
                                            f32x4 (&w)[KT * CIN / 16], const float* __restrict__ next_w,
                                            const float* __restrict__ bias, f32x4 (&sreg)[CF::NSREG],
                                            unsigned padmask, float* __restrict__ dump, int wave, int lane,
-                                           int vrows_rt = 0) {      // SW_GLOBAL: output rows >= vrows_rt are not written
+                                           int vrows_rt = 0,        // SW_GLOBAL: output rows >= vrows_rt are not written
+                                           int live_tiles = 1 << 30) {   // PARTIAL: only the wave's first `live_tiles` tiles hold
+                                                                          // items (a partly filled workgroup): later pairs are skipped
     constexpr int M = CIN / 16, NCB = COUT / 16, NPG = CF::NW / NCB, ITER = T / NPG;
     static_assert(NPG >= 1 && NCB * NPG == CF::NW && T % NPG == 0, "waves must tile channel blocks x position groups");
     const int cb = wave % NCB, pg = wave / NCB;
@@ -463,7 +465,8 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     // order is pinned with sched_barrier.  Each tile accumulates in two chains (even / odd k steps): with
     // four chains in flight a chain is revisited every 128 cycles, far beyond the 40-cycle dependent latency.
     constexpr int S = KT * M, NP = ITER / 2, NU = NP * S, DEPTH = 2;
-    constexpr bool DEFER = (MODE != MODE_TO_REGS) && (S >= 3);
+    constexpr bool DEFER = (MODE != MODE_TO_REGS) && (S >= 3) && !PARTIAL;   // (a skipped pair could not run its predecessor's epilogue)
+    static_assert(!PARTIAL || (!ROLL && NPG == 1), "partial workgroups: plain layers, one position group");
     // An odd share leaves one lone tile.  It runs in the same pipeline as a pseudo-pair: its k steps are
     // split in two halves that play the roles of the two tiles (each with its own weight registers).
     constexpr bool LONE = (ITER % 2) != 0;
@@ -494,6 +497,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
         constexpr int ls = u < NU ? u % S : u - NU;                 // step within the current (pseudo-)pair
         constexpr int ip = (u < NU ? u / S : NP) - 1;              // the pair whose epilogue may be pending
         constexpr bool pending = DEFER && ip >= 0 && (u < NU || HS >= 3);
+        if (PARTIAL && t0 >= live_tiles) return;                   // wave-uniform: this pair (or lone tile) holds no items
         if constexpr (u + DEPTH < NUT) issue(std::integral_constant<int, u + DEPTH>{});
         if constexpr (pending && ls == 0) {
             res0 = residual(2 * ip);
@@ -2033,32 +2037,39 @@ __global__ __launch_bounds__(xf::Cfg::THREADS, 2) void xattn_front_kernel(XattnF
         else if (tid < 64) ((f32x4*)bufB)[tid - 32] = zero4;
     }
     __syncthreads();
-    // 1x1 128 -> 128 + ReLU (8 channel blocks, 9 tiles each), written for the stride-2 walk of the next layers (SW_W)
-    conv_layer<CF, 128, 128, 1, 1, 0, L, L, L, L * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L * G, false, SW_OLD, SW_W>(
-        bufA, bufB, w11, nullptr, W + CF::OFF_11 + CF::W11, sreg, 0u, dump, wave, lane);
-    __syncthreads();
+    // a partly filled workgroup (the last one of a launch; the only one of a one-site call) skips the tile pairs that hold
+    // no items
+    const int vrows = n_here * LO;
     float* const y2 = a.y2 + item0 * (LO * 256);
     float* const sc = a.sc + item0 * (LO * 256);
-    const int vrows = n_here * LO;
+    auto layers = [&](auto partial) {
+        constexpr bool PARTIAL = decltype(partial)::value;
+        const int live1 = (n_here * L + 15) / 16, live2 = (n_here * LO + 15) / 16;
+        // 1x1 128 -> 128 + ReLU (8 channel blocks, 9 tiles each), written for the stride-2 walk of the next layers (SW_W)
+        conv_layer<CF, 128, 128, 1, 1, 0, L, L, L, L * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L * G, false, SW_OLD, SW_W, PARTIAL>(
+            bufA, bufB, w11, nullptr, W + CF::OFF_11 + CF::W11, sreg, 0u, dump, wave, lane, 0, live1);
+        __syncthreads();
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const int w16 = wave + 8 * half;                                   // channel block 0..15
-        {
-            f32x4 ws[24];
-            load_weights<24>(ws, W + CF::OFF_S, w16, lane);
-            // k3 s2 p1 128 -> 256 + ReLU; tap 0 of an item's first row reads zero (BMASK), 72 rows = 4.5 tiles
-            conv_layer<CF16, 128, 256, 3, 2, 1, L, LO, LO, 5, MODE_PLAIN, false, GEOM_TRUNK, 16, LO * G, true, SW_W, SW_GLOBAL>(
-                bufB, y2, ws, nullptr, W + CF::OFF_S + CF::WS, sreg, 0u, dump, w16, lane, vrows);
+        for (int half = 0; half < 2; ++half) {
+            const int w16 = wave + 8 * half;                               // channel block 0..15
+            {
+                f32x4 ws[24];
+                load_weights<24>(ws, W + CF::OFF_S, w16, lane);
+                // k3 s2 p1 128 -> 256 + ReLU; tap 0 of an item's first row reads zero (BMASK), 72 rows = 4.5 tiles
+                conv_layer<CF16, 128, 256, 3, 2, 1, L, LO, LO, 5, MODE_PLAIN, false, GEOM_TRUNK, 16, LO * G, true, SW_W, SW_GLOBAL, PARTIAL>(
+                    bufB, y2, ws, nullptr, W + CF::OFF_S + CF::WS, sreg, 0u, dump, w16, lane, vrows, live2);
+            }
+            {
+                f32x4 wsc[8];
+                load_weights<8>(wsc, W + CF::OFF_SC, w16, lane);
+                // its 1x1 s2 shortcut: no activation (a configuration whose act() is the identity)
+                conv_layer<xf::CfgLinear, 128, 256, 1, 2, 0, L, LO, LO, 5, MODE_PLAIN, false, GEOM_TRUNK, 16, LO * G, false, SW_W, SW_GLOBAL,
+                           PARTIAL>(bufB, sc, wsc, nullptr, W + CF::OFF_SC + CF::WSC, sreg, 0u, dump, w16, lane, vrows, live2);
+            }
         }
-        {
-            f32x4 wsc[8];
-            load_weights<8>(wsc, W + CF::OFF_SC, w16, lane);
-            // its 1x1 s2 shortcut (no activation: MODE_TO_REGS' epilogue would keep it in registers, so the plain
-            // epilogue runs with the identity activation of a pass-through configuration)
-            conv_layer<xf::CfgLinear, 128, 256, 1, 2, 0, L, LO, LO, 5, MODE_PLAIN, false, GEOM_TRUNK, 16, LO * G, false, SW_W, SW_GLOBAL>(
-                bufB, sc, wsc, nullptr, W + CF::OFF_SC + CF::WSC, sreg, 0u, dump, w16, lane, vrows);
-        }
-    }
+    };
+    if (n_here == G) layers(std::false_type{});
+    else layers(std::true_type{});
 }
 
 hipError_t launch_xattn_front(const XattnFrontArgs& a, hipStream_t stream) {
