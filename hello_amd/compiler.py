@@ -601,6 +601,22 @@ class _Lowering:
         return n_experts, has_meta
 
 
+def _fold_site_sums(ops: List[Op]) -> List[Op]:
+    """The fused expert front forms a site's row itself when that row is nothing but the sum of the site's rows of the
+    front's own allele input (reduceSlots, MixtureOfExpertsAdvanced.py:142-147) and nobody else reads it: the SEGSUM op goes,
+    the front's src1 becomes BUF_NONE.  Same bits: the kernel adds the rows in allele order from zero, as segsum_kernel does."""
+    drop = set()
+    for o in ops:
+        if o.kind != OP_XATTN_FRONT or o.src1 == BUF_NONE:
+            continue
+        makers = [j for j, m in enumerate(ops) if m.kind == OP_SEGSUM and m.dst == o.src1]
+        readers = [r for r in ops if r is not o and o.src1 in (r.src0, r.src1, r.res)]
+        if len(makers) == 1 and not readers and ops[makers[0]].seg == SEG_AS and ops[makers[0]].src0 == o.src0:
+            drop.add(makers[0])
+            o.src1 = BUF_NONE
+    return [o for j, o in enumerate(ops) if j not in drop]
+
+
 def _allocate(ops: List[Op], values: Dict[int, Value]):
     """Greedy liveness packing of virtual activations into physical scratch buffers, per domain."""
     last_use: Dict[int, int] = {}
@@ -650,15 +666,20 @@ def _allocate(ops: List[Op], values: Dict[int, Value]):
     return phys
 
 
-def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool = True, arithmetic: str = "fp32") -> Program:
+def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool = True, arithmetic: str = "fp32",
+                  fold_site_sums: bool = True) -> Program:
     """``winograd``: k3/s1/p1 convolutions are evaluated in Winograd form -- F(3,3) (5 instead of 9 contractions per
     3 positions) where the row length / the fused kernel's geometry is whole triples, else F(2,3) (4 instead of 6
-    per pair) -- same fp32 arithmetic, results differ from the direct form by float re-association only."""
+    per pair) -- same fp32 arithmetic, results differ from the direct form by float re-association only.
+    ``fold_site_sums``: the expert front sums a site's alleles itself (one launch and one [sites][18][128] buffer less; the
+    same bits); False keeps the SEGSUM op (tests compare the two)."""
     low = _Lowering(spec, state, fused, winograd, arithmetic)
     n_experts, has_meta = low.lower()
     if arithmetic != "fp32" and not low.used_bf16x3:
         raise ValueError("arithmetic='bf16x3' / 'bf16x3+32' exists for the canonical 150 bp ReLU read convolver in the whole-kernel "
                          "Winograd form (fused=True, winograd=True): this model / these options do not run it")
+    if fold_site_sums:
+        low.ops = _fold_site_sums(low.ops)
     buffers = _allocate(low.ops, low.values)
     return Program(
         spec_name=spec.name, window=spec.window, channels0=spec.channels[0],

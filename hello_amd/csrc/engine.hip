@@ -190,12 +190,12 @@ int validate_model(const hello_model_desc* d) {
                                          "Winograd form", i);
         if (o.kind == HELLO_OP_XATTN_FRONT &&
             !(o.domain == HELLO_ROWS_ALLELES && o.cin == 128 && o.cout == 256 && o.lin == 18 && o.lout == 9 && o.k == 3 && o.stride == 2 &&
-              o.pad == 1 && o.seg == HELLO_SEG_ALLELES_TO_SITES && o.w_off >= 0 && o.src1 != HELLO_BUF_NONE &&
+              o.pad == 1 && o.seg == HELLO_SEG_ALLELES_TO_SITES && o.w_off >= 0 &&
               o.res >= HELLO_BUF_FIRST_SCRATCH && o.res != o.dst && o.res != o.src0 && o.res != o.src1 && o.dst != o.src0 && o.dst != o.src1 &&
               d->buffers[o.res].domain == HELLO_ROWS_ALLELES && d->buffers[o.res].floats_per_row >= 9 * 256 &&
-              d->buffers[o.src1].domain == HELLO_ROWS_SITES))
-            return fail(HELLO_ERR_MODEL, "op %d: the fused expert front maps [18][128] allele rows (src0) and site rows (src1) to two "
-                                         "distinct [9][256] allele buffers, dst and res", i);
+              (o.src1 == HELLO_BUF_NONE || d->buffers[o.src1].domain == HELLO_ROWS_SITES)))
+            return fail(HELLO_ERR_MODEL, "op %d: the fused expert front maps [18][128] allele rows (src0) and site rows (src1, or none: "
+                                         "the sites' sums of src0) to two distinct [9][256] allele buffers, dst and res", i);
         if (o.kind == HELLO_OP_LAYERNORM && (o.cin <= 0 || o.cin > 512 || o.lin <= 0 || o.w_off < 0 || o.b_off < 0 || !(o.a0 > 0.f)))
             return fail(HELLO_ERR_MODEL, "op %d: bad LayerNorm (1..512 channels, eps > 0)", i);
         if ((o.kind == HELLO_OP_SEGSUM || o.kind == HELLO_OP_MIX || o.kind == HELLO_OP_READCONV_FUSED) &&
@@ -816,8 +816,9 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
             case HELLO_OP_XATTN_FRONT: {
                 hello::XattnFrontArgs a{};
                 a.alleles = (const float*)ptr(o.src0);
-                a.sites = (const float*)ptr(o.src1);
+                a.sites = o.src1 == HELLO_BUF_NONE ? nullptr : (const float*)ptr(o.src1);
                 a.owner = e->site_of_allele;
+                a.site_off = e->aoff;
                 a.y2 = (float*)ptr(o.dst);
                 a.sc = (float*)ptr(o.res);
                 a.w = e->d_weights + o.w_off;

@@ -138,8 +138,9 @@ hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream);
 // (k3 s2 p1 128->256 + ReLU -> y2) and its 1x1 s2 shortcut (-> sc); [items][18][128] -> two [items][9][256] tensors.
 struct XattnFrontArgs {
     const float* alleles;      // [items][18][128] compressed allele frames
-    const float* sites;        // [sites][18][128] their per-site sums
+    const float* sites;        // [sites][18][128] their per-site sums; nullptr: the kernel forms a site's sum from its alleles' rows
     const int32_t* owner;      // [items] site of each allele
+    const int32_t* site_off;   // [sites + 1] first allele of each site (read when sites == nullptr)
     float* y2;                 // [items][9][256]
     float* sc;                 // [items][9][256]
     const float* w;            // packed block, hello_amd/readconv_pack.py pack_xattn_front

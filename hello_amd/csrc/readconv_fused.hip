@@ -2013,16 +2013,48 @@ __global__ __launch_bounds__(xf::Cfg::THREADS, 2) void xattn_front_kernel(XattnF
         static_assert(NLD * CF::THREADS == G * L * 32, "the input image divides evenly over the threads");
         const f32x4* src = (const f32x4*)(a.alleles + item0 * (L * 128));
         f32x4 va[NLD], vs[NLD];
+        if (a.sites) {
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int f = tid + CF::THREADS * k;
-            const int it = f / (L * 32);
-            if (it < n_here) {
-                va[k] = src[f];
-                vs[k] = *((const f32x4*)(a.sites + (long long)a.owner[item0 + it] * (L * 128)) + (f - it * (L * 32)));
-            } else {
+            for (int k = 0; k < NLD; ++k) {
+                const int f = tid + CF::THREADS * k;
+                const int it = f / (L * 32);
+                if (it < n_here) {
+                    va[k] = src[f];
+                    vs[k] = *((const f32x4*)(a.sites + (long long)a.owner[item0 + it] * (L * 128)) + (f - it * (L * 32)));
+                } else {
+                    va[k] = zero4;
+                    vs[k] = zero4;
+                }
+            }
+        } else {
+            // the site sum folded in (reduceSlots over the site's alleles, MixtureOfExpertsAdvanced.py:23-34): rows added in
+            // allele order from zero, as segsum_kernel adds them -- the same bits; the r-th rows of all nine are requested together
+            const f32x4* first[NLD];
+            int count[NLD], most = 0;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int f = tid + CF::THREADS * k;
+                const int it = f / (L * 32);
+                count[k] = 0;
+                first[k] = src;
                 va[k] = zero4;
                 vs[k] = zero4;
+                if (it < n_here) {
+                    va[k] = src[f];
+                    const int site = a.owner[item0 + it];
+                    const int lo = a.site_off[site];
+                    count[k] = a.site_off[site + 1] - lo;
+                    first[k] = (const f32x4*)(a.alleles + (long long)lo * (L * 128)) + (f - it * (L * 32));
+                    most = count[k] > most ? count[k] : most;
+                }
+            }
+            for (int r = 0; r < most; ++r) {
+                f32x4 row[NLD];
+#pragma unroll
+                for (int k = 0; k < NLD; ++k) row[k] = r < count[k] ? first[k][(long long)r * (L * 32)] : zero4;
+#pragma unroll
+                for (int k = 0; k < NLD; ++k)
+                    if (r < count[k]) vs[k] = vs[k] + row[k];
             }
         }
 #pragma unroll
@@ -2074,7 +2106,7 @@ __global__ __launch_bounds__(xf::Cfg::THREADS, 2) void xattn_front_kernel(XattnF
 
 hipError_t launch_xattn_front(const XattnFrontArgs& a, hipStream_t stream) {
     if (a.n_items <= 0) return hipSuccess;
-    if (!a.alleles || !a.sites || !a.owner || !a.y2 || !a.sc || !a.w) return hipErrorInvalidValue;
+    if (!a.alleles || (!a.sites && !a.site_off) || !a.owner || !a.y2 || !a.sc || !a.w) return hipErrorInvalidValue;
     static bool configured_on[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;

@@ -162,6 +162,30 @@ def test_fused_expert_front_outputs_match_the_layer_kernels(name, n_sites):
     layered.close()
 
 
+def test_site_sum_folded_into_the_expert_front_gives_the_same_bits():
+    """The single-tech expert's front forms its sites' sums itself (no SEGSUM launch, no [sites][18][128] buffer): logits and
+    posteriors bit-identical to the program that keeps the SEGSUM op, on sites of 1..7 alleles, a partly filled last
+    workgroup, and one site per call."""
+    from hello_amd import compiler
+    from hello_amd.engine import Engine
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=33)
+    batch = _with_extremes(synth.make_sites(301, seed=44, coverage=12), 55, False, 6)
+    assert len(set(batch.alleles_per_site.tolist())) >= 3
+    folded = Engine(spec, state, device=0, arithmetic="fp32")
+    front = next(o for o in folded.program.ops if o.kind == compiler.OP_XATTN_FRONT)
+    assert front.src1 == compiler.BUF_NONE and not any(o.kind == compiler.OP_SEGSUM for o in folded.program.ops)
+    prog = compiler.compile_model(spec, state, fold_site_sums=False)
+    assert any(o.kind == compiler.OP_SEGSUM for o in prog.ops) and len(prog.ops) == len(folded.program.ops) + 1
+    kept = Engine(spec, state, device=0, program=prog)
+    for b in (batch, batch.site_slice(7, 8), batch.site_slice(batch.n_sites - 3, batch.n_sites)):
+        got = folded.forward_batch(b, posteriors=True)
+        want = kept.forward_batch(b, posteriors=True)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+    folded.close()
+    kept.close()
+
+
 @pytest.mark.parametrize("name", ["single_tech_batched", "hybrid_full", "hybrid_ensemble2", "hybrid_no_ensemble",
                                   "merged_single", "merged_hybrid", "merged_hybrid_250", "single_tech_addendum",
                                   "hybrid_no_ensemble_addendum", "single_tech_softplus",

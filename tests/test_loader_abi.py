@@ -332,3 +332,19 @@ def test_arithmetic_modes_lower_to_flags_and_split_weight_blocks():
             compiler.compile_model(spec, state, arithmetic=bad, **kw)
     with pytest.raises(ValueError, match="bf16x3"):
         compiler.compile_model(ns.build("merged_hybrid_250"), weights.synth_state(ns.build("merged_hybrid_250"), seed=1), arithmetic="bf16x3")
+
+
+def test_site_sum_is_folded_into_the_expert_front_only_when_it_has_no_other_reader():
+    """compiler._fold_site_sums: the single-tech program loses its SEGSUM op (the front's src1 becomes BUF_NONE and one buffer
+    goes); programs whose site sums feed several experts or the meta expert keep theirs."""
+    from hello_amd import compiler, netspec as ns, weights
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=2)
+    folded, kept = compiler.compile_model(spec, state), compiler.compile_model(spec, state, fold_site_sums=False)
+    assert [o.kind for o in folded.ops].count(compiler.OP_SEGSUM) == 0 and [o.kind for o in kept.ops].count(compiler.OP_SEGSUM) == 1
+    assert next(o for o in folded.ops if o.kind == compiler.OP_XATTN_FRONT).src1 == compiler.BUF_NONE
+    assert len(folded.buffers) == len(kept.buffers) - 1 and np.array_equal(folded.weights, kept.weights)
+    spec = ns.build("hybrid_full")
+    prog = compiler.compile_model(spec, weights.synth_state(spec, seed=2))
+    fronts = [o for o in prog.ops if o.kind == compiler.OP_XATTN_FRONT]
+    assert len(fronts) == 3 and all(o.src1 != compiler.BUF_NONE for o in fronts)
