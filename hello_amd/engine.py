@@ -103,6 +103,20 @@ def n_pairs(alleles_per_site) -> int:
     return int((a * (a + 1) // 2).sum())
 
 
+def model_desc(program: "compiler.Program"):
+    """-> (hello_model_desc of a compiled program, the ctypes arrays it points into -- keep them alive while it is used)."""
+    ops = (HelloOp * len(program.ops))()
+    for dst, o in zip(ops, program.ops):
+        for name, _ in HelloOp._fields_:
+            setattr(dst, name, getattr(o, name))
+    bufs = (HelloBuffer * len(program.buffers))()
+    for dst, (dom, fpr) in zip(bufs, program.buffers):
+        dst.domain, dst.floats_per_row = dom, fpr
+    desc = HelloModelDesc(1, program.window, program.channels0, program.channels1, program.n_experts, int(program.has_meta),
+                          int(program.uses_ref), len(program.buffers), bufs, len(program.ops), ops)
+    return desc, (ops, bufs)
+
+
 class Engine:
     """One compiled model resident on one GPU (one instance per process and device)."""
 
@@ -129,15 +143,7 @@ class Engine:
                 program = compiler.compile_model(spec, state, fused=fused, winograd=winograd, arithmetic=arithmetic or "fp32")
         self.program = program
         p = self.program
-        self._ops = (HelloOp * len(p.ops))()
-        for dst, o in zip(self._ops, p.ops):
-            for name, _ in HelloOp._fields_:
-                setattr(dst, name, getattr(o, name))
-        self._bufs = (HelloBuffer * len(p.buffers))()
-        for dst, (dom, fpr) in zip(self._bufs, p.buffers):
-            dst.domain, dst.floats_per_row = dom, fpr
-        desc = HelloModelDesc(1, p.window, p.channels0, p.channels1, p.n_experts, int(p.has_meta),
-                              int(p.uses_ref), len(p.buffers), self._bufs, len(p.ops), self._ops)
+        desc, self._desc_arrays = model_desc(p)
         blob = np.ascontiguousarray(p.weights, dtype=np.float32)
         handle = C.c_void_p()
         _check(self.lib.hello_engine_create(C.byref(desc), blob.ctypes.data, blob.nbytes, device,

@@ -187,3 +187,35 @@ def test_non_integer_pileups_are_rejected():
     with pytest.raises(ValueError, match="integers"):
         net(fd, seg)
     net.close()
+
+
+def test_the_ctypes_stub_of_integration_md_runs_as_written():
+    """INTEGRATION.md section 3 shows the binding a maintainer would write against include/hello_mi355x.h: the code block
+    is executed verbatim (create, one host-path forward, destroy) and its logits must equal the maintained binding's."""
+    import os
+    import re
+    from hello_amd import compiler, netspec as ns, synth, weights as wts
+    from hello_amd.engine import Engine, model_desc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    section = text[text.index("## 3. Binding the C ABI directly"):]
+    code = re.search(r"```python\n(.*?)```", section, re.S).group(1)
+    spec = ns.build("single_tech")
+    state = wts.synth_state(spec, seed=4)
+    batch = synth.make_sites(12, seed=8, coverage=10)
+    program = compiler.compile_model(spec, state)
+    desc, keep = model_desc(program)
+    names = dict(desc=desc, weights=np.ascontiguousarray(program.weights, np.float32), n_experts=program.n_experts,
+                 reads0=np.ascontiguousarray(batch.reads0), reads_per_allele0=np.ascontiguousarray(batch.reads_per_allele0, np.int32),
+                 alleles_per_site=np.ascontiguousarray(batch.alleles_per_site, np.int32), S=batch.n_sites, A=batch.n_alleles,
+                 R0=batch.reads0.shape[0])
+    cwd = os.getcwd()
+    os.chdir(root)                                    # the stub names the library relative to the repository root
+    try:
+        exec(compile(code, "INTEGRATION.md section 3", "exec"), names)
+    finally:
+        os.chdir(cwd)
+    eng = Engine(spec, state, device=0, program=program)
+    want, _ = eng.forward_batch(batch)
+    eng.close()
+    assert names["logits"].shape == want.shape and np.array_equal(names["logits"], want)
