@@ -466,7 +466,7 @@ __device__ __forceinline__ void conv_layer(const float* __restrict__ in, float* 
     // four chains in flight a chain is revisited every 128 cycles, far beyond the 40-cycle dependent latency.
     constexpr int S = KT * M, NP = ITER / 2, NU = NP * S, DEPTH = 2;
     constexpr bool DEFER = (MODE != MODE_TO_REGS) && (S >= 3) && !PARTIAL;   // (a skipped pair could not run its predecessor's epilogue)
-    static_assert(!PARTIAL || (!ROLL && NPG == 1), "partial workgroups: plain layers, one position group");
+    static_assert(!PARTIAL || !ROLL, "partial workgroups: plain layers (live_tiles counts the tiles of THIS wave: pg + NPG k)");
     // An odd share leaves one lone tile.  It runs in the same pipeline as a pseudo-pair: its k steps are
     // split in two halves that play the roles of the two tiles (each with its own weight registers).
     constexpr bool LONE = (ITER % 2) != 0;
@@ -1878,9 +1878,17 @@ __global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(Compres
     }
     __syncthreads();
     f32x4 sreg[CF::NSREG];
+    // a partly filled workgroup (the last one of a launch; the only one of a one-site call) skips the 16-row tiles that hold
+    // no items: tile t of the 64-channel image is tile (wave / 4) + 2 k of its position group, of the 128-channel image tile k
+    const bool full = n_here == G;
+    const int live0 = (n_here * L0 + 15) / 16, live1 = (n_here * L1 + 15) / 16;
     // 1x1 64 -> 64 + ReLU (4 channel blocks x 2 position groups), written for the stride-2 walk of the next layer (SW_W)
-    conv_layer<CF, 64, 64, 1, 1, 0, L0, L0, L0, L0 * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L0 * G, false, SW_OLD, SW_W>(
-        bufA, bufB, w11, nullptr, W + CF::OFF_11 + CF::W11, sreg, 0u, dump, wave, lane);
+    if (full)
+        conv_layer<CF, 64, 64, 1, 1, 0, L0, L0, L0, L0 * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L0 * G, false, SW_OLD, SW_W>(
+            bufA, bufB, w11, nullptr, W + CF::OFF_11 + CF::W11, sreg, 0u, dump, wave, lane);
+    else
+        conv_layer<CF, 64, 64, 1, 1, 0, L0, L0, L0, L0 * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L0 * G, false, SW_OLD, SW_W, true>(
+            bufA, bufB, w11, nullptr, W + CF::OFF_11 + CF::W11, sreg, 0u, dump, wave, lane, 0, (live0 - wave / 4 + 1) / 2);
     f32x4 ws[12], wsc[4];
     load_weights<12>(ws, W + CF::OFF_S, wave, lane);
     load_weights<4>(wsc, W + CF::OFF_SC, wave, lane);
@@ -1888,8 +1896,12 @@ __global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(Compres
     // bufA becomes the 128-channel image: rows 0 and 18 G + 1 are its zero rows
     if (tid < 64) ((f32x4*)bufA)[(tid & 31) + (tid >> 5) * (L1 * G + 1) * 32] = zero4;
     // strided block: k3 s2 64 -> 128 + ReLU (tap 0 of an item's first row reads zero, not the previous item's last row)
-    conv_layer<CF, 64, 128, 3, 2, 1, L0, L1, L1, L1 * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L1 * G, true, SW_W, SW_3>(
-        bufB, bufA, ws, nullptr, W + CF::OFF_S + CF::WS, sreg, 0u, dump, wave, lane);
+    if (full)
+        conv_layer<CF, 64, 128, 3, 2, 1, L0, L1, L1, L1 * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L1 * G, true, SW_W, SW_3>(
+            bufB, bufA, ws, nullptr, W + CF::OFF_S + CF::WS, sreg, 0u, dump, wave, lane);
+    else
+        conv_layer<CF, 64, 128, 3, 2, 1, L0, L1, L1, L1 * G / 16, MODE_PLAIN, false, GEOM_TRUNK, 16, L1 * G, true, SW_W, SW_3, true>(
+            bufB, bufA, ws, nullptr, W + CF::OFF_S + CF::WS, sreg, 0u, dump, wave, lane, 0, live1);
     // its 1x1 s2 shortcut, in the row order the F(3,3) epilogue of the block's second conv holds its outputs in
     conv_layer<CF, 64, 128, 1, 2, 0, L0, L1, L1, CF::NSREG, MODE_TO_REGS, false, GEOM_WTRIPLE, 16, L1 * G, false, SW_W, SW_3>(
         bufB, nullptr, wsc, nullptr, W + CF::OFF_SC + CF::WSC, sreg, 0u, dump, wave, lane);
