@@ -8,6 +8,7 @@ CPU fallback: if the HIP library or a gfx950 device is missing, construction rai
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import os
 from typing import Optional, Sequence, Tuple
 
@@ -15,6 +16,8 @@ import numpy as np
 
 from . import compiler
 from . import netspec as ns
+
+_log = logging.getLogger(__name__)
 
 # HELLO_LIB overrides the library path (kernel experiments); the default is the in-tree build
 _LIB_PATH = os.environ.get("HELLO_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -137,6 +140,8 @@ class Engine:
                 try:
                     program = compiler.compile_model(spec, state, fused=fused, winograd=winograd,
                                                      arithmetic=os.environ["HELLO_ARITHMETIC"])
+                    _log.warning("HELLO_ARITHMETIC=%s: engine for %s created in that arithmetic (not the exact-fp32 default)",
+                                 os.environ["HELLO_ARITHMETIC"], spec.name)
                 except ValueError:
                     program = None
             if program is None:
