@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -37,6 +39,18 @@ int set_last_error(int code, const char* fmt, ...) {
     va_end(ap);
     g_last_error = buf;
     return code;
+}
+// No C++ exception crosses the C ABI: every entry point that allocates is a function-try-block ending here.
+int exception_status(const char* where) noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        try { return set_last_error(HELLO_ERR_NOMEM, "%s: out of host memory", where); } catch (...) { return HELLO_ERR_NOMEM; }
+    } catch (const std::exception& ex) {
+        try { return set_last_error(HELLO_ERR_ARG, "%s: %s", where, ex.what()); } catch (...) { return HELLO_ERR_ARG; }
+    } catch (...) {
+        try { return set_last_error(HELLO_ERR_ARG, "%s: unknown C++ exception", where); } catch (...) { return HELLO_ERR_ARG; }
+    }
 }
 }  // namespace hello
 
@@ -254,7 +268,7 @@ const char* hello_last_error(void) { return g_last_error.c_str(); }
 int hello_abi_version(void) { return HELLO_ABI_VERSION; }
 
 int hello_engine_create(const hello_model_desc* desc, const void* folded_weights, size_t nbytes,
-                        int hip_device, hello_engine** out) {
+                        int hip_device, hello_engine** out) try {
     if (!out) return fail(HELLO_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (int rc = validate_model(desc)) return rc;
@@ -329,6 +343,8 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
     }
     *out = e;
     return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_engine_create");
 }
 
 void hello_engine_destroy(hello_engine* e) {
@@ -398,7 +414,7 @@ int hello_engine_set_profiling_filter(hello_engine* e, int32_t op_kind) {
 }
 
 int hello_engine_op_times_ms(hello_engine* e, float* ms_sum, int32_t capacity, int32_t* n_ops,
-                             int32_t* n_forwards) {
+                             int32_t* n_forwards) try {
     if (!e || !ms_sum || !n_ops || !n_forwards) return fail(HELLO_ERR_ARG, "NULL argument");
     if (e->prof_count == 0) return fail(HELLO_ERR_ARG, "no forward was recorded with profiling enabled");
     const int n = (int)e->ops.size() < capacity ? (int)e->ops.size() : capacity;
@@ -416,9 +432,11 @@ int hello_engine_op_times_ms(hello_engine* e, float* ms_sum, int32_t capacity, i
     *n_ops = n;
     *n_forwards = e->prof_count;
     return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_engine_op_times_ms");
 }
 
-int hello_engine_debug_capture(hello_engine* e, int32_t op_index) {
+int hello_engine_debug_capture(hello_engine* e, int32_t op_index) try {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
     if (op_index < -1 || op_index >= (int)e->ops.size()) return fail(HELLO_ERR_ARG, "op index %d out of range", op_index);
     if (op_index >= 0 && e->ops[op_index].kind == HELLO_OP_HEAD)
@@ -426,9 +444,11 @@ int hello_engine_debug_capture(hello_engine* e, int32_t op_index) {
     e->debug_op = op_index;
     e->debug_floats = 0;
     return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_engine_debug_capture");
 }
 
-int hello_engine_debug_read(hello_engine* e, float* out, int64_t capacity, int64_t* n_floats) {
+int hello_engine_debug_read(hello_engine* e, float* out, int64_t capacity, int64_t* n_floats) try {
     if (!e || !n_floats) return fail(HELLO_ERR_ARG, "NULL argument");
     *n_floats = (int64_t)e->debug_floats;
     if (!out) return HELLO_OK;
@@ -438,6 +458,8 @@ int hello_engine_debug_read(hello_engine* e, float* out, int64_t capacity, int64
     HIP_TRY(hipStreamSynchronize(e->last_stream ? e->last_stream : e->own_stream));
     HIP_TRY(hipMemcpy(out, e->d_debug.p, e->debug_floats * sizeof(float), hipMemcpyDeviceToHost));
     return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_engine_debug_read");
 }
 
 // Build every per-batch index array on the host (pinned), ship them in one copy.
@@ -579,7 +601,7 @@ static int stage_batch_indices(hello_engine* e, const int32_t* rpa0, const int32
 int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* rpa0,
                          const uint8_t* reads1, const int32_t* rpa1, const int32_t* aps,
                          const uint8_t* ref_onehot, int32_t S, int32_t A, int64_t R0, int64_t R1,
-                         float* logits, float* meta, float* posteriors, int32_t flags, void* hip_stream) {
+                         float* logits, float* meta, float* posteriors, int32_t flags, void* hip_stream) try {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
     const hello_model_desc& d = e->desc;
     const bool two_tech = d.channels1 > 0;
@@ -930,11 +952,13 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
         if (posteriors) memcpy(posteriors, src, post_bytes);
     }
     return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_engine_forward");
 }
 
 int hello_engine_posteriors(hello_engine* e, const float* logits, const float* meta, const int32_t* aps,
                             int32_t S, int32_t A, int64_t n_pairs_total, float* out, int32_t flags,
-                            void* hip_stream) {
+                            void* hip_stream) try {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
     if (!logits || !aps || !out || S <= 0 || A <= 0) return fail(HELLO_ERR_ARG, "bad argument");
     const hello_model_desc& d = e->desc;
@@ -991,6 +1015,8 @@ int hello_engine_posteriors(hello_engine* e, const float* logits, const float* m
     // the host vectors above die with this frame: the copies from them must have completed
     HIP_TRY(hipStreamSynchronize(stream));
     return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_engine_posteriors");
 }
 
 int hello_engine_featurize(hello_engine* e, const uint8_t* bases, const uint8_t* quals, const int64_t* read_offsets,
@@ -1000,7 +1026,7 @@ int hello_engine_featurize(hello_engine* e, const uint8_t* bases, const uint8_t*
                            const int64_t* ref_window_offsets, const int64_t* window_starts,
                            const int64_t* assembly_starts, const int64_t* assembly_stops, int64_t n_reads,
                            int32_t n_sites, int32_t feature_length, int32_t channels, uint8_t* out,
-                           int32_t flags, void* hip_stream) {
+                           int32_t flags, void* hip_stream) try {
     if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
     if (!bases || !quals || !read_offsets || !cigars || !cigar_offsets || !ref_starts || !mapq || !orientation ||
         !hp || !site_of_read || !ref_windows || !ref_window_offsets || !window_starts || !assembly_starts ||
@@ -1070,6 +1096,8 @@ int hello_engine_featurize(hello_engine* e, const uint8_t* bases, const uint8_t*
     // host inputs were pageable: the copies above are complete only after this
     if (!in_dev || !out_dev) HIP_TRY(hipStreamSynchronize(stream));
     return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_engine_featurize");
 }
 
 }  // extern "C"

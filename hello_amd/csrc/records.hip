@@ -25,6 +25,7 @@
 
 namespace hello {
 int set_last_error(int code, const char* fmt, ...);      // engine.hip
+int exception_status(const char* where) noexcept;         // engine.hip
 }
 
 struct hello_records {
@@ -331,7 +332,7 @@ extern "C" {
 
 int hello_site_records(const hello_site_table* t, const float* posteriors, int64_t n_pairs_total, const float* meta,
                        const int32_t* shard_site_off, int32_t n_shards, const hello_features_format* fmt,
-                       int32_t n_threads, hello_records** out) {
+                       int32_t n_threads, hello_records** out) try {
     using hello::set_last_error;
     if (!t || !posteriors || !out) return set_last_error(HELLO_ERR_ARG, "NULL pointer");
     const int32_t S = t->n_sites;
@@ -388,6 +389,7 @@ int hello_site_records(const hello_site_table* t, const float* posteriors, int64
 
     auto work = [&](int w) {
         Chunk& ch = chunks[w];
+        try {
         ch.lo = (int32_t)((int64_t)S * w / T);
         ch.hi = (int32_t)((int64_t)S * (w + 1) / T);
         ch.shard_len.assign(ch.hi - ch.lo, 0);
@@ -484,6 +486,11 @@ int hello_site_records(const hello_site_table* t, const float* posteriors, int64
                 pk.op('u');
             }
         }
+        } catch (const std::exception& ex) {      // a worker thread must not unwind out of its job (std::bad_alloc on a huge launch)
+            ch.failure.set("record stage, sites %d..%d: %s", ch.lo, ch.hi, ex.what());
+        } catch (...) {
+            ch.failure.set("record stage, sites %d..%d: unknown C++ exception", ch.lo, ch.hi);
+        }
     };
     pool().run(T, work);
     for (auto& ch : chunks)
@@ -542,9 +549,11 @@ int hello_site_records(const hello_site_table* t, const float* posteriors, int64
     }
     *out = rec;
     return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_site_records");
 }
 
-int hello_records_get(const hello_records* r, hello_records_view* v) {
+int hello_records_get(const hello_records* r, hello_records_view* v) try {
     if (!r || !v) return hello::set_last_error(HELLO_ERR_ARG, "NULL pointer");
     v->n_sites = r->n_sites;
     v->n_shards = r->n_shards;
@@ -560,6 +569,8 @@ int hello_records_get(const hello_records* r, hello_records_view* v) {
     v->best_p = r->best_p.data();
     v->qual = r->qual.data();
     return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_records_get");
 }
 
 void hello_records_destroy(hello_records* r) { delete r; }

@@ -37,7 +37,8 @@ typedef enum hello_status {
     HELLO_ERR_SHAPE = -2,    /* counts do not add up (sum reads_per_allele != n_reads, ...)  */
     HELLO_ERR_MODEL = -3,    /* malformed model description                                  */
     HELLO_ERR_HIP = -4,      /* a HIP runtime call failed                                    */
-    HELLO_ERR_NOGPU = -5     /* no gfx950 device visible                                     */
+    HELLO_ERR_NOGPU = -5,    /* no gfx950 device visible                                     */
+    HELLO_ERR_NOMEM = -6     /* host memory exhausted inside the library (no C++ exception crosses the boundary) */
 } hello_status;
 
 /* ---- model description: a flat program over activation buffers ------------------------------
