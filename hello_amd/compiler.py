@@ -126,15 +126,26 @@ class _WeightBlob:
         return np.concatenate(self.parts) if self.parts else np.zeros(0, np.float32)
 
 
-def pack_conv(w: np.ndarray, b: np.ndarray, groups: int = 1):
+def grouped_native(node) -> bool:
+    """A grouped convolution the kernels run group by group (a workgroup's channel block inside one group, hello_op.c1):
+    no multiplications by the zero blocks of the block-diagonal dense form."""
+    return (node.groups > 1 and node.cin % node.groups == 0 and node.cout % node.groups == 0
+            and (node.cout // node.groups) % 128 == 0 and (node.cin // node.groups) % 16 == 0)
+
+
+def pack_conv(w: np.ndarray, b: np.ndarray, groups: int = 1, expand: bool = True):
     """[cout, cin/groups, k] -> dense [cout_pad32][kpad32] with K index = tap*cin + c (channels-last
-    im2col order); grouped convs are expanded to block-diagonal dense weights."""
+    im2col order); grouped convs are expanded to block-diagonal dense weights unless ``expand`` is False (then a
+    row holds its own group's k * cin/groups inputs only: the kernels' grouped form)."""
     cout, cg, k = w.shape
-    cin = cg * groups
+    cin = cg * groups if expand else cg
     dense = np.zeros((cout, cin, k), np.float32)
     og = cout // groups
-    for g in range(groups):
-        dense[g * og:(g + 1) * og, g * cg:(g + 1) * cg] = w[g * og:(g + 1) * og]
+    if expand:
+        for g in range(groups):
+            dense[g * og:(g + 1) * og, g * cg:(g + 1) * cg] = w[g * og:(g + 1) * og]
+    else:
+        dense[:] = w
     kreal = k * cin
     kpad = -(-kreal // 32) * 32
     cpad = -(-cout // 32) * 32
@@ -255,8 +266,8 @@ class _Lowering:
     # -- single nodes ------------------------------------------------------------------------
     @staticmethod
     def _winograd_ok(node: ns.Conv, x: Value) -> bool:
-        return (node.k == 3 and node.stride == 1 and node.pad == 1 and node.groups == 1 and node.dilation == 1
-                and not x.u8 and node.cin % 8 == 0 and node.cout % 64 == 0)
+        return (node.k == 3 and node.stride == 1 and node.pad == 1 and (node.groups == 1 or grouped_native(node))
+                and node.dilation == 1 and not x.u8 and node.cin % 8 == 0 and node.cout % 64 == 0)
 
     def conv(self, node: ns.Conv, x: Value, res: Optional[Value] = None) -> Value:
         if node.act not in ("relu", "none", "softplus"):
@@ -274,7 +285,8 @@ class _Lowering:
             packed, bias = pack_conv_bf16x3(w, b)
             self.used_bf16x3_allele = True
         else:
-            packed, bias = pack_conv_winograd(w, b, x.length) if wino else pack_conv(w, b, node.groups)
+            native = grouped_native(node) and not x.u8        # w is [cout, cin / groups, k]: each row its own group's inputs
+            packed, bias = (pack_conv_winograd(w, b, x.length) if wino else pack_conv(w, b, node.groups, expand=not native))
         lout = ns.out_length([node], x.length)
         m = winograd_outputs_per_tile(lout)
         y = self.new(x.domain, lout, node.cout)
@@ -286,9 +298,10 @@ class _Lowering:
             lin=x.length, lout=lout,
             flags=((0 if layer_norm else act_flag) | (FLAG_SRC_U8 if x.u8 else 0) | (FLAG_WINOGRAD if wino else 0)
                    | (FLAG_BF16X3 if split else 0)),
+            c1=node.groups if (not split and grouped_native(node) and not x.u8) else 0,
             w_off=self.blob.add(packed), b_off=self.blob.add(bias), name=node.key,
             macs_per_row=lout * node.cout * (node.cin // node.groups) * node.k,
-            exec_macs_per_row=float(-(-lout // m) * (m + 2) * node.cout * node.cin) if wino else 0.0))
+            exec_macs_per_row=float(-(-lout // m) * (m + 2) * node.cout * (node.cin // node.groups)) if wino else 0.0))
         if layer_norm:
             gamma, beta, eps = wts.layer_norm_params(node, self.state)
             z = self.new(x.domain, lout, node.cout)

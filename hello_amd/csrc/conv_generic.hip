@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
     const int cb0 = blockIdx.y * (32 * NCB);
     const SrcT* src = (const SrcT*)a.src;
     const int kreal = a.k * a.cin;
+    const int goff = a.groups > 1 ? (cb0 / (a.cout / a.groups)) * a.cin : 0;     // first input channel of this block's group
 
     // per-thread gather rows: m = lrow + RPP*j
     long long row_base[NA];  // item * lin
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
                 const int pos = pos_base[j] + tap;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (kk < kreal && pos >= 0 && pos < a.lin)
-                    v = *(const f32x4*)((const float*)src + ((row_base[j] + pos) * a.cin + c));
+                    v = *(const f32x4*)((const float*)src + ((row_base[j] + pos) * a.cin_stride + goff + c));
                 ra[j] = v;
             }
         } else {
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
                     const int c = k1 - tap * a.cin;
                     const int pos = pos_base[j] + tap;
                     if (k1 < kreal && pos >= 0 && pos < a.lin)
-                        v[e] = load_scalar(src + ((row_base[j] + pos) * a.cin + c));
+                        v[e] = load_scalar(src + ((row_base[j] + pos) * a.cin_stride + goff + c));
                 }
                 ra[j] = v;
             }
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs a) {
     const int p = live ? (int)(mg - item * a.lout) : 0;
     const int pos0 = p * a.stride - a.pad;
     const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.src, 0, (int)((a.m_total / a.lout) * (long long)a.lin * a.cin * 4), 0x00020000);
+        (void*)a.src, 0, (int)((a.m_total / a.lout) * (long long)a.lin * a.cin_stride * 4), 0x00020000);
+    const int goff = a.groups > 1 ? (cb / (a.cout / a.groups)) * a.cin : 0;
     const int gpt = a.cin / 16;                                              // groups per tap
     const int groups = a.k * gpt, per_wave = (groups + 3) / 4;
     const int g0 = wave * per_wave, g1 = g0 + per_wave < groups ? g0 + per_wave : groups;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void conv1d_small_kernel(ConvArgs a) {
             const int g = gb + i;
             if (g < g1) {
                 const int tap = g / gpt, m = g - tap * gpt, pos = pos0 + tap;
-                const unsigned off = (live && pos >= 0 && pos < a.lin) ? (unsigned)((((int)item * a.lin + pos) * a.cin + 16 * m + 4 * q) * 4)
+                const unsigned off = (live && pos >= 0 && pos < a.lin) ? (unsigned)((((int)item * a.lin + pos) * a.cin_stride + goff + 16 * m + 4 * q) * 4)
                                                                        : 0x80000000u;
                 x[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc, off, 0, 0));
                 w[i] = *(const f32x4*)(wrow + 16 * g);
@@ -256,7 +258,7 @@ hipError_t launch_conv1d(const ConvArgs& a, hipStream_t stream) {
     {
         const long long cus = device_cus();
         const long long big_wgs = (long long)gx * (a.cout_pad / (vec && (a.cout_pad % 128) == 0 ? 128 : (two ? 64 : 32)));
-        const long long act_bytes = (a.m_total / a.lout) * (long long)a.lin * a.cin * 4;
+        const long long act_bytes = (a.m_total / a.lout) * (long long)a.lin * a.cin_stride * 4;
         if (!a.src_u8 && (a.cin % 16) == 0 && (a.cout % 16) == 0 && a.lout > 0 && (a.m_total % a.lout) == 0 && big_wgs * 4 <= cus &&
             act_bytes < (1LL << 31)) {
             const dim3 sgrid((unsigned)((a.m_total + 15) / 16 * (a.cout / 16)));

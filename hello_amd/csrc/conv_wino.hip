@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     // SGPR, out-of-range lanes read zeros): the 64 tiles of a workgroup span few rows, so the activation
     // descriptor starts at the first of them and an offset of 2 GiB marks "zero padding / row past the tile".
     const unsigned item0 = m0 / (unsigned)PP;
-    const long long left = (long long)(items - item0) * L * a.cin * 4;
+    const long long left = (long long)(items - item0) * L * a.cin_stride * 4;
+    const int goff = a.groups > 1 ? (cb0 / (a.cout / a.groups)) * a.cin : 0;     // first input channel of this block's group
     // A workgroup's tiles are numbered from its first row's first tile: x = p0 + r with p0 < PP and r < 80, so
     // x / PP is one 32-bit multiply-high by a wave-uniform reciprocal (exact for x * PP < 2^32) instead of a
     // 64-bit division per lane.
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     const unsigned tiles_left = mp_total - m0;
     const unsigned magic = 0xffffffffu / (unsigned)PP + 1u;
     const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const float*)a.src + (long long)item0 * L * a.cin), 0, (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+        (void*)((const float*)a.src + (long long)item0 * L * a.cin_stride), 0, (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.w + (long long)cb0 * a.kpad), 0, BN * a.kpad * 4, 0x00020000);
 
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
             const unsigned x = p0 + (unsigned)row;
             const unsigned irow = PP == 1 ? x : __umulhi(x, magic);       // rows past the workgroup's first
             const int pos = M * (int)(x - irow * (unsigned)PP) - 1 + tap;
-            if (pos >= 0 && pos < L) act_off[j] = (unsigned)(((int)irow * L + pos) * a.cin + csub) * 4u;
+            if (pos >= 0 && pos < L) act_off[j] = (unsigned)(((int)irow * L + pos) * a.cin_stride + goff + csub) * 4u;
         }
     }
 
@@ -241,12 +242,13 @@ __global__ __launch_bounds__(256) void conv1d_wino_small_kernel(ConvArgs a) {
     const int p = live ? (int)(T - item * (unsigned)PP) : 0;
     // activations through a buffer descriptor: taps outside the row (and dead tiles) read zeros
     const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.src, 0, (int)((long long)a.wino_rows * L * a.cin * 4), 0x00020000);
+        (void*)a.src, 0, (int)((long long)a.wino_rows * L * a.cin_stride * 4), 0x00020000);
+    const int goff = a.groups > 1 ? (cb / (a.cout / a.groups)) * a.cin : 0;
     unsigned act_off[NT];
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
         const int pos = M * p - 1 + tap;
-        act_off[tap] = (live && pos >= 0 && pos < L) ? (unsigned)((((int)item * L + pos) * a.cin + 4 * q) * 4) : 0x80000000u;
+        act_off[tap] = (live && pos >= 0 && pos < L) ? (unsigned)((((int)item * L + pos) * a.cin_stride + goff + 4 * q) * 4) : 0x80000000u;
     }
     const float* wrow = a.w + (long long)(cb + j) * a.kpad + (q >> 1) * (NT * 8) + 4 * (q & 1);
     const int groups = a.cin / 16, per_wave = (groups + 3) / 4;
@@ -355,7 +357,7 @@ hipError_t launch_conv1d_wino(const ConvArgs& args, hipStream_t stream) {
     // small launches: 16 x 16 blocks per wave, no LDS (conv1d_wino_small_kernel)
     const long long cus = device_cus();
     const long long big_wgs = (tiles + BMP - 1) / BMP * (a.cout / BN);
-    if (big_wgs * SMALL_LAUNCH_DIVISOR <= cus && (a.cin % 16) == 0 && (long long)a.m_total * a.cin * 4 < (1LL << 31)) {
+    if (big_wgs * SMALL_LAUNCH_DIVISOR <= cus && (a.cin % 16) == 0 && (long long)a.m_total * a.cin_stride * 4 < (1LL << 31)) {
         const dim3 sgrid((unsigned)((tiles + 15) / 16 * (a.cout / 16)));
         switch (variant) {
 #define HELLO_WINO_SMALL_CASE(V, MM, ACT, RES) \

@@ -194,6 +194,10 @@ int validate_model(const hello_model_desc* d) {
             if (o.cin <= 0 || o.cout <= 0 || (o.cout % 4) || o.k <= 0 || o.stride <= 0 || o.pad < 0 ||
                 o.lin <= 0 || o.lout <= 0 || o.w_off < 0 || o.b_off < 0)
                 return fail(HELLO_ERR_MODEL, "op %d: bad conv geometry", i);
+            if (o.c1 > 1 && !(o.cin % o.c1 == 0 && o.cout % o.c1 == 0 && (o.cout / o.c1) % 128 == 0 && (o.cin / o.c1) % 16 == 0 &&
+                              !(o.flags & (HELLO_FLAG_SRC_U8 | HELLO_FLAG_BF16X3))))
+                return fail(HELLO_ERR_MODEL, "op %d: a grouped convolution (c1 = %d groups) needs float input, cin / groups a multiple of 16 "
+                                             "and cout / groups a multiple of 128 (a workgroup's channel block lies inside one group)", i, o.c1);
             if ((o.lin + 2 * o.pad - o.k) / o.stride + 1 != o.lout)
                 return fail(HELLO_ERR_MODEL, "op %d: lout inconsistent", i);
         }
@@ -298,8 +302,9 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
         if (o.kind == HELLO_OP_CONV1D) {
             const bool wino = (o.flags & HELLO_FLAG_WINOGRAD) != 0;
             const size_t cpad = wino ? (size_t)o.cout : (size_t)((o.cout + 31) / 32) * 32;
-            const size_t kpad = wino ? (size_t)(hello::conv1d_wino_outputs_per_tile(o.lin) + 2) * o.cin
-                                     : (size_t)((o.k * o.cin + 31) / 32) * 32;
+            const int cing = o.cin / (o.c1 > 1 ? o.c1 : 1);          // input channels a filter reads (grouped convolutions)
+            const size_t kpad = wino ? (size_t)(hello::conv1d_wino_outputs_per_tile(o.lin) + 2) * cing
+                                     : (size_t)((o.k * cing + 31) / 32) * 32;
             w_end = (size_t)o.w_off + cpad * kpad;
             b_end = (size_t)o.b_off + cpad;
             if (o.flags & HELLO_FLAG_BF16X3) {       // split weights: [hi | lo][cout padded to 128][k * cin] bf16
@@ -761,9 +766,10 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.w = e->d_weights + o.w_off;
                 a.bias = e->d_weights + o.b_off;
                 a.m_total = rows * o.lout;
-                a.lin = o.lin; a.lout = o.lout; a.cin = o.cin; a.cout = o.cout;
+                a.groups = o.c1 > 1 ? o.c1 : 1;
+                a.lin = o.lin; a.lout = o.lout; a.cin = o.cin / a.groups; a.cin_stride = o.cin; a.cout = o.cout;
                 a.k = o.k; a.stride = o.stride; a.pad = o.pad;
-                a.kpad = ((o.k * o.cin + 31) / 32) * 32;
+                a.kpad = ((o.k * a.cin + 31) / 32) * 32;
                 a.cout_pad = ((o.cout + 31) / 32) * 32;
                 a.relu = (o.flags & HELLO_FLAG_RELU) ? 1 : ((o.flags & HELLO_FLAG_SOFTPLUS) ? 2 : 0);
                 a.src_u8 = (o.flags & HELLO_FLAG_SRC_U8) ? 1 : 0;
@@ -781,7 +787,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                     break;
                 }
                 if (a.wino) {
-                    a.kpad = (hello::conv1d_wino_outputs_per_tile(o.lin) + 2) * o.cin;
+                    a.kpad = (hello::conv1d_wino_outputs_per_tile(o.lin) + 2) * a.cin;
                     a.cout_pad = o.cout;
                     if (!hello::conv1d_wino_supported(a))
                         return fail(HELLO_ERR_MODEL, "op %d: this convolution has no Winograd form", op_index);

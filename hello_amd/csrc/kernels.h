@@ -18,7 +18,10 @@ struct ConvArgs {
     const float* w;       // packed [cout_pad][kpad], k index = tap*cin + c, zero padded
     const float* bias;    // [cout_pad]
     long long m_total;    // rows * lout
-    int lin, lout, cin, cout, k, stride, pad;
+    int lin, lout, cin, cout, k, stride, pad;     // cin: input channels a filter reads (= row channels / groups)
+    int cin_stride;       // channels of an activation row (cin x groups)
+    int groups;           // grouped convolution (nn.Conv1d groups): output block g reads input channels [g cin, (g + 1) cin); every
+                          // workgroup's channel block lies inside one group (cout / groups a multiple of 128)
     int kpad;             // multiple of 32
     int cout_pad;         // multiple of 32
     int relu;                  // activation: 0 none, 1 ReLU, 2 Softplus (beta 1, threshold 20)

@@ -131,7 +131,9 @@ typedef struct hello_op {
     int32_t lin, lout;   /* positions per row before / after */
     int32_t flags;
     int32_t seg;         /* hello_segment (SEGSUM / MIX / READCONV_FUSED) */
-    int32_t c1;          /* CONCAT: channels of src1 */
+    int32_t c1;          /* CONCAT: channels of src1; CONV1D: groups of a grouped convolution (nn.Conv1d groups; 0 / 1 = dense):
+                          * output block g reads input channels [g cin/groups, (g+1) cin/groups), weights packed per output
+                          * channel over ITS group's k * cin/groups inputs; cout/groups a multiple of 128, cin/groups of 16 */
     float a0, a1;        /* MIX coefficients */
     int64_t w_off;       /* float offset of the packed weights in the weight blob */
     int64_t b_off;       /* float offset of the bias */

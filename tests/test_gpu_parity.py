@@ -162,6 +162,35 @@ def test_fused_expert_front_outputs_match_the_layer_kernels(name, n_sites):
     layered.close()
 
 
+def test_grouped_convolutions_run_group_by_group_and_match_the_block_diagonal_form(monkeypatch):
+    """The 250 bp family's combiner (ConvCombiner250FeatureMap.py:5-24, groups = 2): its four grouped convolutions run group by
+    group (hello_op.c1; two of them in Winograd form) instead of as block-diagonal dense layers -- logits against the same
+    model lowered the dense way (half of whose multiplications are by zero blocks), and a malformed group count is refused."""
+    from hello_amd import compiler
+    from hello_amd.engine import Engine
+    spec = ns.build("merged_hybrid_250")
+    state = weights.synth_state(spec, seed=12)
+    batch = synth.make_sites(40, seed=19, coverage=9, hybrid_coverage=6, window=250)
+    native = Engine(spec, state, device=0, arithmetic="fp32")
+    grouped = [o for o in native.program.ops if o.kind == compiler.OP_CONV1D and o.c1 > 1]
+    assert len(grouped) == 4 and sum(1 for o in grouped if o.flags & compiler.FLAG_WINOGRAD) == 2
+    monkeypatch.setattr(compiler, "grouped_native", lambda node: False)
+    dense_prog = compiler.compile_model(spec, state)
+    monkeypatch.undo()
+    assert not any(o.c1 > 1 for o in dense_prog.ops if o.kind == compiler.OP_CONV1D)
+    dense = Engine(spec, state, device=0, program=dense_prog)
+    got, gm = native.forward_batch(batch)
+    want, wm = dense.forward_batch(batch)
+    scale = float(np.abs(want).max())
+    assert np.abs(got - want).max() <= 2e-5 * scale and np.abs(gm - wm).max() < 1e-5
+    dense.close()
+    prog = compiler.compile_model(spec, state)
+    next(o for o in prog.ops if o.kind == compiler.OP_CONV1D and o.c1 > 1).c1 = 3
+    with pytest.raises(RuntimeError, match="grouped convolution"):
+        Engine(spec, state, device=0, program=prog)
+    native.close()
+
+
 def test_site_sum_folded_into_the_expert_front_gives_the_same_bits():
     """The single-tech expert's front forms its sites' sums itself (no SEGSUM launch, no [sites][18][128] buffer): logits and
     posteriors bit-identical to the program that keeps the SEGSUM op, on sites of 1..7 alleles, a partly filled last

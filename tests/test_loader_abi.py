@@ -348,3 +348,24 @@ def test_site_sum_is_folded_into_the_expert_front_only_when_it_has_no_other_read
     prog = compiler.compile_model(spec, weights.synth_state(spec, seed=2))
     fronts = [o for o in prog.ops if o.kind == compiler.OP_XATTN_FRONT]
     assert len(fronts) == 3 and all(o.src1 != compiler.BUF_NONE for o in fronts)
+
+
+def test_grouped_convolutions_are_lowered_with_their_group_count_and_compact_weights():
+    """compiler.grouped_native: a grouped convolution whose groups are whole channel blocks keeps its group count (hello_op.c1) and
+    packs every output channel over ITS group's inputs only; one that does not fit is expanded to block-diagonal dense weights."""
+    from hello_amd import compiler, netspec as ns, weights
+    spec = ns.build("merged_hybrid_250")
+    prog = compiler.compile_model(spec, weights.synth_state(spec, seed=1))
+    grouped = [o for o in prog.ops if o.kind == compiler.OP_CONV1D and o.c1 > 1]
+    assert [(o.cin, o.cout, o.k, o.stride, o.c1) for o in grouped] == [(256, 256, 3, 1, 2), (256, 512, 1, 2, 2), (256, 512, 3, 2, 2),
+                                                                        (512, 512, 3, 1, 2)]
+    w = np.arange(8 * 3 * 3, dtype=np.float32).reshape(8, 3, 3)                 # cout 8, 2 groups of 3 inputs, k 3
+    dense, _ = compiler.pack_conv(w, np.zeros(8, np.float32), groups=2)
+    compact, _ = compiler.pack_conv(w, np.zeros(8, np.float32), groups=2, expand=False)
+    assert dense.shape == (32, 32) and compact.shape == (32, 32)
+    assert np.array_equal(compact[:8, :9], w.transpose(0, 2, 1).reshape(8, 9)) and not compact[:, 9:].any()
+    d = dense[:8, :18].reshape(8, 3, 6)                                          # [cout][tap][cin]
+    assert np.array_equal(d[:4, :, :3], w[:4].transpose(0, 2, 1)) and not d[:4, :, 3:].any()
+    assert np.array_equal(d[4:, :, 3:], w[4:].transpose(0, 2, 1)) and not d[4:, :, :3].any()
+    small = ns.Conv(key="x", cin=32, cout=64, k=3, groups=2)
+    assert not compiler.grouped_native(small)
