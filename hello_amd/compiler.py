@@ -520,6 +520,24 @@ class _Lowering:
             return x
 
         def expert(idx, allele: Value, site: Value):
+            from . import readconv_pack
+            nodes = spec.nets[f"expert{idx}"]
+            front = (readconv_pack.xattn_front_match(nodes, mixed_ahead=True)
+                     if (additive and self.fused is True and self.winograd and "allele" not in self.arithmetic
+                         and (allele.length, allele.channels) == (18, 128)) else None)
+            if front is not None:
+                # the same fused front as MoEAttention's experts (xattn_front_kernel), with x = a - (s - a) formed in that order
+                _, conv11, blk = front
+                y2, sc = self.new(ROWS_ALLELES, 9, 256), self.new(ROWS_ALLELES, 9, 256)
+                w_off = self.blob.add(readconv_pack.pack_xattn_front(conv11, blk, self.folded))
+                self.ops.append(Op(OP_XATTN_FRONT, ROWS_ALLELES, src0=allele.vid, src1=site.vid, dst=y2.vid, res=sc.vid,
+                                   cin=128, cout=256, k=3, stride=2, pad=1, lin=18, lout=9, flags=FLAG_RELU | FLAG_MIX_REST, seg=SEG_AS,
+                                   a0=2.0, a1=-1.0, w_off=w_off, b_off=w_off, name=conv11.key.rsplit(".network", 1)[0] + ".front",
+                                   macs_per_row=ns.macs([conv11], 18) + ns.macs([blk.body[0]], 18) + ns.macs(blk.shortcut, 18),
+                                   exec_macs_per_row=readconv_pack.xattn_front_executed_macs()))
+                self.used_xattn_front = True
+                self.net(nodes[2:], self.conv(blk.body[1], y2, res=sc), head_slot=idx)
+                return
             if additive:
                 x = mix(allele, site, 2.0, -1.0, FLAG_MIX_REST)              # a - (s - a), in that rounding order
             else:

@@ -853,6 +853,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.n_items = rows;
                 a.a0 = o.a0;
                 a.a1 = o.a1;
+                a.rest = (o.flags & HELLO_FLAG_MIX_REST) ? 1 : 0;
                 HIP_TRY(hello::launch_xattn_front(a, stream));
                 break;
             }

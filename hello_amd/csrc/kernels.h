@@ -149,6 +149,7 @@ struct XattnFrontArgs {
     const float* w;            // packed block, hello_amd/readconv_pack.py pack_xattn_front
     long long n_items;
     float a0, a1;              // LinearCombination coefficients (2, -1)
+    int rest;                  // x = a - (s - a) in that rounding order (MoEMergedAdvanced, :372-383) instead of a0 a + a1 s
 };
 int xattn_front_weight_floats();
 hipError_t launch_xattn_front(const XattnFrontArgs& a, hipStream_t stream);

@@ -2074,7 +2074,8 @@ __global__ __launch_bounds__(xf::Cfg::THREADS, 2) void xattn_front_kernel(XattnF
             const int f = tid + CF::THREADS * k;
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = a.a0 * va[k][e] + a.a1 * vs[k][e];       // LinearCombination, NNTools.py:771-777
+            for (int e = 0; e < 4; ++e)                                                  // LinearCombination, NNTools.py:771-777
+                v[e] = a.rest ? va[k][e] - (vs[k][e] - va[k][e]) : a.a0 * va[k][e] + a.a1 * vs[k][e];
             *(f32x4*)(bufA + img_off<128, SW_OLD>(1 + (f >> 5), f & 31)) = v;
         }
         if (tid < 32) ((f32x4*)bufA)[tid] = zero4;                         // leading zero rows of both images

@@ -165,7 +165,7 @@ def pack(nodes, folded, cin=None, winograd: bool = False, window: int = 150) -> 
     return blob
 
 
-def xattn_front_match(nodes):
+def xattn_front_match(nodes, mixed_ahead: bool = False):
     """(mix, conv 1x1, strided residual block) when ``nodes`` opens like the canonical allele-level expert
     (architectures/xattn_subtract.py:9-60): LinearCombination of the allele's and its site's frames, Conv 1x1 128->128 + ReLU,
     then a residual block whose body starts k3 s2 p1 128->256 + ReLU and whose shortcut is a 1x1 s2 128->256 convolution
@@ -173,7 +173,9 @@ def xattn_front_match(nodes):
     def conv_is(n, cin, cout, k, stride, pad, act):
         return (isinstance(n, ns.Conv) and (n.cin, n.cout, n.k, n.stride, n.pad, n.dilation, n.groups, n.act) ==
                 (cin, cout, k, stride, pad, 1, 1, act) and n.norm != "ln")
-    if len(nodes) < 3 or not isinstance(nodes[0], ns.Mix) or not conv_is(nodes[1], 128, 128, 1, 1, 0, "relu"):
+    if mixed_ahead:          # MoEMergedAdvanced: the caller forms a - (s - a) itself, the expert opens with the 1x1
+        nodes = [None] + list(nodes)
+    if len(nodes) < 3 or not (mixed_ahead or isinstance(nodes[0], ns.Mix)) or not conv_is(nodes[1], 128, 128, 1, 1, 0, "relu"):
         return None
     blk = nodes[2]
     if not (isinstance(blk, ns.Residual) and len(blk.body) == 2 and len(blk.shortcut) == 1

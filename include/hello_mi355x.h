@@ -93,7 +93,8 @@ typedef enum hello_op_kind {
                               * in Winograd F(3,3) form, weights packed by hello_amd/readconv_pack.py pack_compressor       */
     ,
     HELLO_OP_XATTN_FRONT = 11 /* the front of the allele-level expert (architectures/xattn_subtract.py:9-60) in one LDS-resident
-                              * kernel: x = a0 src0[a] + a1 src1[site(a)] ([18][128] rows; src1 = HELLO_BUF_NONE: the site's row is
+                              * kernel: x = a0 src0[a] + a1 src1[site(a)] (HELLO_FLAG_MIX_REST: x = src0[a] - (src1[site(a)] - src0[a]), as
+                              * MIX) ([18][128] rows; src1 = HELLO_BUF_NONE: the site's row is
                               * the sum of its alleles' src0 rows, formed in the kernel in allele order -- the SEGSUM of src0 over
                               * HELLO_SEG_ALLELES_TO_SITES folded in, same bits), 1x1 128->128 + ReLU, then the strided
                               * block's first convolution (k3 s2 p1 128->256 + ReLU) -> dst and its 1x1 s2 shortcut -> the buffer

@@ -118,7 +118,8 @@ def test_fused_compressor_output_matches_oracle(engines, name):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
 
 
-@pytest.mark.parametrize("name,n_sites", [("single_tech_batched", None), ("hybrid_full", None), ("single_tech_batched", 700)])
+@pytest.mark.parametrize("name,n_sites", [("single_tech_batched", None), ("hybrid_full", None), ("single_tech_batched", 700),
+                                          ("merged_single", None), ("merged_hybrid", None)])
 def test_fused_expert_front_outputs_match_the_layer_kernels(name, n_sites):
     """Kernel-level parity of xattn_front_kernel (MIX + 1x1 + the strided block's first convolution and its shortcut in one
     LDS-resident launch): both of its outputs -- the strided convolution's [items][9][256] rows (dst) and, through the op that

@@ -296,7 +296,12 @@ def test_expert_front_is_one_fused_op_with_two_outputs_and_the_kernels_weight_la
         assert nxt.kind == compiler.OP_CONV1D and nxt.src0 == o.dst and nxt.res == o.res and (nxt.cin, nxt.cout, nxt.k) == (256, 256, 3)
         assert prog.buffers[o.dst][1] >= 9 * 256 and prog.buffers[o.res][1] >= 9 * 256
     assert not any(o.kind == compiler.OP_XATTN_FRONT for o in compiler.compile_model(spec, state, fused="trunk").ops)
-    assert not any(o.kind == compiler.OP_XATTN_FRONT for o in compiler.compile_model(ns.build("merged_single"), weights.synth_state(ns.build("merged_single"), seed=1)).ops)
+    # MoEMergedAdvanced's additive experts take the same op with x = a - (s - a) formed in that rounding order (MIX_REST)
+    merged = compiler.compile_model(ns.build("merged_single"), weights.synth_state(ns.build("merged_single"), seed=1))
+    f2 = [o for o in merged.ops if o.kind == compiler.OP_XATTN_FRONT]
+    assert len(f2) == 1 and f2[0].flags & compiler.FLAG_MIX_REST and not any(o.kind == compiler.OP_MIX for o in merged.ops)
+    m250 = compiler.compile_model(ns.build("merged_hybrid_250"), weights.synth_state(ns.build("merged_hybrid_250"), seed=1))
+    assert not any(o.kind == compiler.OP_XATTN_FRONT for o in m250.ops)          # other row lengths: layer by layer
     mix, conv11, blk = rp.xattn_front_match(spec.nets["xattn0"])
     blob = rp.pack_xattn_front(conv11, blk, weights.fold(spec, state))
     w, b = weights.fold(spec, state)[blk.body[0].key]                  # the strided convolution: [cb 16][tap 3][m 8][64 lanes][4]
