@@ -204,7 +204,7 @@ int validate_model(const hello_model_desc* d) {
         if (o.kind == HELLO_OP_COMPRESSOR_FUSED &&
             !(o.cin == 64 && o.cout == 128 && o.lin == 36 && o.lout == 18 && hello::compressor_supports_blocks(o.k) &&
               (o.flags & HELLO_FLAG_WINOGRAD) && o.w_off >= 0))
-            return fail(HELLO_ERR_MODEL, "op %d: the fused compressor maps [36][64] rows to [18][128] with 2 or 3 identity blocks, "
+            return fail(HELLO_ERR_MODEL, "op %d: the fused compressor maps [36][64] rows to [18][128] with 2 to 4 identity blocks, "
                                          "Winograd form", i);
         if (o.kind == HELLO_OP_XATTN_FRONT &&
             !(o.domain == HELLO_ROWS_ALLELES && o.cin == 128 && o.cout == 256 && o.lin == 18 && o.lout == 9 && o.k == 3 && o.stride == 2 &&

@@ -1835,7 +1835,7 @@ struct Cfg {
 }  // namespace cc
 
 int compressor_weight_floats(int blocks) { return cc::Cfg::total(blocks); }
-bool compressor_supports_blocks(int blocks) { return blocks == 2 || blocks == 3; }
+bool compressor_supports_blocks(int blocks) { return blocks >= 2 && blocks <= 4; }
 
 template <int NB>
 __global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(CompressorArgs a) {
@@ -1957,12 +1957,15 @@ hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream) 
         hipError_t e = hipFuncSetAttribute((const void*)compressor_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cc::Cfg::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)compressor_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, cc::Cfg::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)compressor_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cc::Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         configured_on[dev] = true;
     }
     const unsigned grid = (unsigned)((a.n_items + cc::Cfg::G - 1) / cc::Cfg::G);
     if (a.blocks == 2) hipLaunchKernelGGL(compressor_kernel<2>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL(compressor_kernel<3>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
+    else if (a.blocks == 3) hipLaunchKernelGGL(compressor_kernel<3>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(compressor_kernel<4>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 

@@ -253,8 +253,8 @@ def pack_bf16x3(nodes, folded) -> np.ndarray:
 # ------------------------------------------------------------------------------------------------
 # fused allele-level compressor (compressor_kernel in readconv_fused.hip)
 # ------------------------------------------------------------------------------------------------
-COMPRESSOR_BLOCKS = (2, 3)    # identity residual blocks the kernel is instantiated for (architectures/compressor_conv_small.py
-                              # has 2, ExpertAlleleConvolver250FeatureMap.py 3)
+COMPRESSOR_BLOCKS = (2, 3, 4) # identity residual blocks the kernel is instantiated for (architectures/compressor_conv_small.py
+                              # has 2, ExpertAlleleConvolver250FeatureMap.py 3, the transfer-learning addendum appends 2 to 2)
 
 
 def compressor_blocks(nodes) -> int:

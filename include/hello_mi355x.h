@@ -88,7 +88,7 @@ typedef enum hello_op_kind {
                               * eps in a0; flags: HELLO_FLAG_RELU | HELLO_FLAG_SOFTPLUS                                */
     ,
     HELLO_OP_COMPRESSOR_FUSED = 10 /* the whole allele-level compressor (architectures/compressor_conv_small.py:8-55) in
-                              * one LDS-resident kernel: 1x1 64->64, strided block 64->128 with its 1x1 shortcut, k (2 | 3)
+                              * one LDS-resident kernel: 1x1 64->64, strided block 64->128 with its 1x1 shortcut, k (2 .. 4)
                               * identity residual blocks; src0 rows [36][64] -> dst rows [18][128]; ReLU; k3/s1 convolutions
                               * in Winograd F(3,3) form, weights packed by hello_amd/readconv_pack.py pack_compressor       */
     ,

@@ -186,6 +186,11 @@ def test_canonical_compressor_is_one_fused_op_with_the_kernels_weight_layout():
     assert all(o.exec_macs_per_row == rp.compressor_executed_macs(2) < o.macs_per_row == 5_160_960 for o in fused)
     for kw in (dict(winograd=False), dict(fused=False), dict(fused="trunk")):                 # layer by layer otherwise
         assert not compiler.compile_model(spec, state, **kw).fused_compressor
+    # the transfer-learning addendum appends two identity blocks to the compressor's two: still one fused op (k = 4)
+    add = ns.build("single_tech_addendum")
+    aprog = compiler.compile_model(add, weights.synth_state(add, seed=1))
+    assert rp.compressor_blocks(add.nets["compressor0"]) == 4
+    assert [o.k for o in aprog.ops if o.kind == compiler.OP_COMPRESSOR_FUSED] == [4] and aprog.fused_compressor
     # 250 bp models: rows of 61 positions, not the kernel's geometry
     assert not compiler.compile_model(ns.build("merged_hybrid_250"), weights.synth_state(ns.build("merged_hybrid_250"), seed=1)).fused_compressor
 
