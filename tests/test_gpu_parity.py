@@ -185,6 +185,11 @@ def test_grouped_convolutions_run_group_by_group_and_match_the_block_diagonal_fo
     scale = float(np.abs(want).max())
     assert np.abs(got - want).max() <= 2e-5 * scale and np.abs(gm - wm).max() < 1e-5
     dense.close()
+    direct = Engine(spec, state, device=0, winograd=False, arithmetic="fp32")       # all four in the direct-form kernels, still by group
+    assert sum(1 for o in direct.program.ops if o.kind == compiler.OP_CONV1D and o.c1 > 1 and not o.flags & compiler.FLAG_WINOGRAD) == 4
+    dl, dm = direct.forward_batch(batch)
+    assert np.abs(dl - want).max() <= 2e-5 * scale and np.abs(dm - wm).max() < 1e-5
+    direct.close()
     prog = compiler.compile_model(spec, state)
     next(o for o in prog.ops if o.kind == compiler.OP_CONV1D and o.c1 > 1).c1 = 3
     with pytest.raises(RuntimeError, match="grouped convolution"):
