@@ -648,6 +648,27 @@ def _fold_site_sums(ops: List[Op]) -> List[Op]:
     return [o for j, o in enumerate(ops) if j not in drop]
 
 
+def _fold_concats(ops: List[Op]) -> List[Op]:
+    """A channel-wise CONCAT whose only reader is a dense Winograd convolution with ReLU and no residual (the combiners' first
+    layer, ConvCombiner: MixtureOfExpertsAdvanced.py:205-214) is never materialised: the convolution reads its two sources
+    chunk by chunk (conv1d_wino_kernel's two-source form: src1 = the second tensor, seg = channels of the first).  Same bits:
+    the K loop visits the same channels in the same order."""
+    drop = set()
+    for j, c in enumerate(ops):
+        if c.kind != OP_CONCAT or c.cin % 16 or c.c1 % 16:
+            continue
+        readers = [r for r in ops if r is not c and c.dst in (r.src0, r.src1, r.res)]
+        if len(readers) != 1:
+            continue
+        r = readers[0]
+        if (r.kind == OP_CONV1D and r.src0 == c.dst and r.src1 == BUF_NONE and r.res == BUF_NONE and r.c1 <= 1
+                and (r.flags & FLAG_WINOGRAD) and (r.flags & FLAG_RELU) and not (r.flags & (FLAG_BF16X3 | FLAG_SOFTPLUS))
+                and r.cin == c.cin + c.c1):
+            r.src0, r.src1, r.seg = c.src0, c.src1, c.cin
+            drop.add(j)
+    return [o for j, o in enumerate(ops) if j not in drop]
+
+
 def _allocate(ops: List[Op], values: Dict[int, Value]):
     """Greedy liveness packing of virtual activations into physical scratch buffers, per domain."""
     last_use: Dict[int, int] = {}
@@ -702,8 +723,9 @@ def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool 
     """``winograd``: k3/s1/p1 convolutions are evaluated in Winograd form -- F(3,3) (5 instead of 9 contractions per
     3 positions) where the row length / the fused kernel's geometry is whole triples, else F(2,3) (4 instead of 6
     per pair) -- same fp32 arithmetic, results differ from the direct form by float re-association only.
-    ``fold_site_sums``: the expert front sums a site's alleles itself (one launch and one [sites][18][128] buffer less; the
-    same bits); False keeps the SEGSUM op (tests compare the two)."""
+    ``fold_site_sums``: glue ops folded into their consumers -- the expert front sums a site's alleles itself, a combiner's first
+    convolution reads the two tensors of its CONCAT directly (one launch and one buffer less each; the same bits); False keeps
+    the SEGSUM / CONCAT ops (tests compare the two)."""
     low = _Lowering(spec, state, fused, winograd, arithmetic)
     n_experts, has_meta = low.lower()
     if arithmetic != "fp32" and not low.used_bf16x3:
@@ -711,6 +733,7 @@ def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool 
                          "Winograd form (fused=True, winograd=True): this model / these options do not run it")
     if fold_site_sums:
         low.ops = _fold_site_sums(low.ops)
+        low.ops = _fold_concats(low.ops)
     buffers = _allocate(low.ops, low.values)
     return Program(
         spec_name=spec.name, window=spec.window, channels0=spec.channels[0],

@@ -35,7 +35,9 @@ constexpr int SMALL_LAUNCH_DIVISOR = 4;   // the small kernel serves launches of
 // positions instead of 9 (1.8x fewer MFMAs; F(2,3) needs 20 for a 9-position row, this 15).  Chosen by the
 // launcher whenever the row length is a multiple of 3 (9, 18, 36, 150), and the weights are packed to match.
 // ACT: 0 none | 1 ReLU | 2 Softplus; RES: a residual input is added after the activation.
-template <int M, int ACT, bool RES>
+// TWO: the input is the channel-wise concatenation of two tensors that is never materialised (a CONCAT op folded into
+// this convolution): chunks below a.split come from a.src (rows of a.split channels), the others from a.src2.
+template <int M, int ACT, bool RES, bool TWO = false>
 __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     constexpr int NT = M + 2;                 // taps per tile == Winograd components
     constexpr int CPC = 8;                    // input channels per chunk
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     // SGPR, out-of-range lanes read zeros): the 64 tiles of a workgroup span few rows, so the activation
     // descriptor starts at the first of them and an offset of 2 GiB marks "zero padding / row past the tile".
     const unsigned item0 = m0 / (unsigned)PP;
-    const long long left = (long long)(items - item0) * L * a.cin_stride * 4;
+    const int stride0 = TWO ? a.split : a.cin_stride, stride1 = TWO ? a.cin - a.split : 0;     // channels per position of the source(s)
+    const long long left = (long long)(items - item0) * L * stride0 * 4;
     const int goff = a.groups > 1 ? (cb0 / (a.cout / a.groups)) * a.cin : 0;     // first input channel of this block's group
     // A workgroup's tiles are numbered from its first row's first tile: x = p0 + r with p0 < PP and r < 80, so
     // x / PP is one 32-bit multiply-high by a wave-uniform reciprocal (exact for x * PP < 2^32) instead of a
@@ -75,13 +78,16 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
     const unsigned tiles_left = mp_total - m0;
     const unsigned magic = 0xffffffffu / (unsigned)PP + 1u;
     const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const float*)a.src + (long long)item0 * L * a.cin_stride), 0, (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+        (void*)((const float*)a.src + (long long)item0 * L * stride0), 0, (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+    const long long left1 = (long long)(items - item0) * L * stride1 * 4;
+    const __amdgpu_buffer_rsrc_t act_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(TWO ? a.src2 + (long long)item0 * L * stride1 : (const float*)a.src), 0, (int)(left1 < 0x7fffffffLL ? left1 : 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.w + (long long)cb0 * a.kpad), 0, BN * a.kpad * 4, 0x00020000);
 
     // float4 number i = t + 256 j of a chunk is (row i / QPR, tap (i % QPR) / 2, channel half i & 1); the last pass
     // overhangs the tile (rows >= 64): those lanes load zeros into LDS rows nobody reads
-    unsigned act_off[NQ], w_off[NQ];
+    unsigned act_off[NQ], act_off1[NQ], w_off[NQ];
     int lds_off[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
@@ -90,20 +96,27 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
         const int tap = q >> 1, csub = (q & 1) * 4;
         lds_off[j] = row * LD + q * 4;
         w_off[j] = (unsigned)(row * a.kpad + q * 4) * 4u;
-        act_off[j] = 0x80000000u;
+        act_off[j] = act_off1[j] = 0x80000000u;
         if (row < BMP && (unsigned)row < tiles_left) {
             const unsigned x = p0 + (unsigned)row;
             const unsigned irow = PP == 1 ? x : __umulhi(x, magic);       // rows past the workgroup's first
             const int pos = M * (int)(x - irow * (unsigned)PP) - 1 + tap;
-            if (pos >= 0 && pos < L) act_off[j] = (unsigned)(((int)irow * L + pos) * a.cin_stride + goff + csub) * 4u;
+            if (pos >= 0 && pos < L) {
+                act_off[j] = (unsigned)(((int)irow * L + pos) * stride0 + goff + csub) * 4u;
+                if constexpr (TWO) act_off1[j] = (unsigned)(((int)irow * L + pos) * stride1 + csub) * 4u;
+            }
         }
     }
 
     f32x4 ra[NQ], rw[NQ];
     auto prefetch = [&](int kb) {
+        const bool second = TWO && kb * CPC >= a.split;                      // wave-uniform: which source holds this chunk's channels
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc, act_off[j], kb * CPC * 4, 0));
+            if (second)
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc1, act_off1[j], (kb * CPC - a.split) * 4, 0));
+            else
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc, act_off[j], kb * CPC * 4, 0));
             rw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off[j], kb * KC * 4, 0));
         }
     };
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(256, 3) void conv1d_wino_kernel(ConvArgs a) {
 // straight from global memory (the weights in the layout the large kernel packs: a 16-channel group is two 8-channel
 // groups), two groups ahead; one b128 feeds four MFMAs per component.  D[channel][tile]: lane (j, q) ends with
 // channels 4 q .. 4 q + 3 of tile j; waves 1..3 hand their accumulators to wave 0 through LDS, added in wave order.
-template <int M, int ACT, bool RES>
+template <int M, int ACT, bool RES, bool TWO = false>
 __global__ __launch_bounds__(256) void conv1d_wino_small_kernel(ConvArgs a) {
     constexpr int NT = M + 2;
     __shared__ __attribute__((aligned(16))) f32x4 s_red[3][NT][64];
@@ -242,13 +255,18 @@ __global__ __launch_bounds__(256) void conv1d_wino_small_kernel(ConvArgs a) {
     const int p = live ? (int)(T - item * (unsigned)PP) : 0;
     // activations through a buffer descriptor: taps outside the row (and dead tiles) read zeros
     const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.src, 0, (int)((long long)a.wino_rows * L * a.cin_stride * 4), 0x00020000);
+        (void*)a.src, 0, (int)((long long)a.wino_rows * L * (TWO ? a.split : a.cin_stride) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t act_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(TWO ? (const void*)a.src2 : a.src), 0, (int)((long long)a.wino_rows * L * (TWO ? a.cin - a.split : 0) * 4), 0x00020000);
+    const int stride0 = TWO ? a.split : a.cin_stride, stride1 = TWO ? a.cin - a.split : 0;
     const int goff = a.groups > 1 ? (cb / (a.cout / a.groups)) * a.cin : 0;
-    unsigned act_off[NT];
+    unsigned act_off[NT], act_off1[NT];
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
         const int pos = M * p - 1 + tap;
-        act_off[tap] = (live && pos >= 0 && pos < L) ? (unsigned)((((int)item * L + pos) * a.cin_stride + goff + 4 * q) * 4) : 0x80000000u;
+        const bool inside = live && pos >= 0 && pos < L;
+        act_off[tap] = inside ? (unsigned)((((int)item * L + pos) * stride0 + goff + 4 * q) * 4) : 0x80000000u;
+        act_off1[tap] = (TWO && inside) ? (unsigned)((((int)item * L + pos) * stride1 + 4 * q) * 4) : 0x80000000u;
     }
     const float* wrow = a.w + (long long)(cb + j) * a.kpad + (q >> 1) * (NT * 8) + 4 * (q & 1);
     const int groups = a.cin / 16, per_wave = (groups + 3) / 4;
@@ -261,9 +279,11 @@ __global__ __launch_bounds__(256) void conv1d_wino_small_kernel(ConvArgs a) {
 
     f32x4 d[3][NT], w[3][NT];                                                // operands of groups m, m + 1, m + 2
     auto request = [&](int m, f32x4 (&dd)[NT], f32x4 (&ww)[NT]) {
+        const bool second = TWO && m * 16 >= a.split;                        // wave-uniform (split is a multiple of 16)
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap)
-            dd[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc, act_off[tap], m * 64, 0));
+            dd[tap] = second ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc1, act_off1[tap], (m * 16 - a.split) * 4, 0))
+                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(act_rsrc, act_off[tap], m * 64, 0));
 #pragma unroll
         for (int c = 0; c < NT; ++c) ww[c] = *(const f32x4*)(wrow + (long long)m * (2 * NT * 8) + c * 8);
     };
@@ -357,6 +377,20 @@ hipError_t launch_conv1d_wino(const ConvArgs& args, hipStream_t stream) {
     // small launches: 16 x 16 blocks per wave, no LDS (conv1d_wino_small_kernel)
     const long long cus = device_cus();
     const long long big_wgs = (tiles + BMP - 1) / BMP * (a.cout / BN);
+    if (a.src2) {
+        // two-source form: ReLU, no residual, no groups, both parts whole 16-channel groups (what the compiler folds)
+        if (a.relu != 1 || a.res || a.groups > 1 || a.split <= 0 || a.split >= a.cin || (a.split % 16) || ((a.cin - a.split) % 16))
+            return hipErrorInvalidValue;
+        if (big_wgs * SMALL_LAUNCH_DIVISOR <= cus && (long long)a.m_total * a.cin * 4 < (1LL << 31)) {
+            const dim3 sgrid((unsigned)((tiles + 15) / 16 * (a.cout / 16)));
+            if (m == 3) hipLaunchKernelGGL((conv1d_wino_small_kernel<3, 1, false, true>), sgrid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv1d_wino_small_kernel<2, 1, false, true>), sgrid, dim3(256), 0, stream, a);
+        } else {
+            if (m == 3) hipLaunchKernelGGL((conv1d_wino_kernel<3, 1, false, true>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((conv1d_wino_kernel<2, 1, false, true>), grid, dim3(256), 0, stream, a);
+        }
+        return hipGetLastError();
+    }
     if (big_wgs * SMALL_LAUNCH_DIVISOR <= cus && (a.cin % 16) == 0 && (long long)a.m_total * a.cin_stride * 4 < (1LL << 31)) {
         const dim3 sgrid((unsigned)((tiles + 15) / 16 * (a.cout / 16)));
         switch (variant) {

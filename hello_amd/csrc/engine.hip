@@ -194,6 +194,12 @@ int validate_model(const hello_model_desc* d) {
             if (o.cin <= 0 || o.cout <= 0 || (o.cout % 4) || o.k <= 0 || o.stride <= 0 || o.pad < 0 ||
                 o.lin <= 0 || o.lout <= 0 || o.w_off < 0 || o.b_off < 0)
                 return fail(HELLO_ERR_MODEL, "op %d: bad conv geometry", i);
+            if (o.src1 != HELLO_BUF_NONE &&
+                !((o.flags & HELLO_FLAG_WINOGRAD) && (o.flags & HELLO_FLAG_RELU) && !(o.flags & (HELLO_FLAG_BF16X3 | HELLO_FLAG_SOFTPLUS)) &&
+                  o.res == HELLO_BUF_NONE && o.c1 <= 1 && o.seg > 0 && o.seg < o.cin && o.seg % 16 == 0 && (o.cin - o.seg) % 16 == 0 &&
+                  o.src1 != o.dst && o.src1 >= HELLO_BUF_FIRST_SCRATCH && d->buffers[o.src1].domain == o.domain))
+                return fail(HELLO_ERR_MODEL, "op %d: a two-source convolution (src1: a folded CONCAT) is a dense Winograd convolution with "
+                                             "ReLU and no residual whose sources hold seg and cin - seg channels, multiples of 16", i);
             if (o.c1 > 1 && !(o.cin % o.c1 == 0 && o.cout % o.c1 == 0 && (o.cout / o.c1) % 128 == 0 && (o.cin / o.c1) % 16 == 0 &&
                               !(o.flags & (HELLO_FLAG_SRC_U8 | HELLO_FLAG_BF16X3))))
                 return fail(HELLO_ERR_MODEL, "op %d: a grouped convolution (c1 = %d groups) needs float input, cin / groups a multiple of 16 "
@@ -767,6 +773,8 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.bias = e->d_weights + o.b_off;
                 a.m_total = rows * o.lout;
                 a.groups = o.c1 > 1 ? o.c1 : 1;
+                a.src2 = o.src1 != HELLO_BUF_NONE ? (const float*)ptr(o.src1) : nullptr;
+                a.split = o.src1 != HELLO_BUF_NONE ? o.seg : 0;
                 a.lin = o.lin; a.lout = o.lout; a.cin = o.cin / a.groups; a.cin_stride = o.cin; a.cout = o.cout;
                 a.k = o.k; a.stride = o.stride; a.pad = o.pad;
                 a.kpad = ((o.k * a.cin + 31) / 32) * 32;

@@ -13,6 +13,9 @@ int device_cus();
 
 struct ConvArgs {
     const void* src;      // float or uint8 [rows][lin][cin]
+    const float* src2;    // conv_wino.hip, two-source form (a CONCAT folded in): channels [split, cin) come from this tensor
+                          // [rows][lin][cin - split] and channels [0, split) from src [rows][lin][split]; nullptr otherwise
+    int split;
     float* dst;           // [rows][lout][cout]
     const float* res;     // optional residual, same shape as dst, added after the activation
     const float* w;       // packed [cout_pad][kpad], k index = tap*cin + c, zero padded

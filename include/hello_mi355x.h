@@ -124,14 +124,15 @@ typedef enum hello_op_kind {
 typedef struct hello_op {
     int32_t kind;        /* hello_op_kind */
     int32_t domain;      /* hello_domain of dst rows */
-    int32_t src0, src1;  /* buffer ids */
+    int32_t src0, src1;  /* buffer ids; CONV1D with src1 != HELLO_BUF_NONE: a CONCAT folded in -- input channels [0, seg) are src0's
+                          * rows [lin][seg], channels [seg, cin) src1's rows [lin][cin - seg] (dense Winograd form, ReLU, no residual) */
     int32_t dst;         /* buffer id; HEAD: output slot */
     int32_t res;         /* residual buffer id or HELLO_BUF_NONE */
     int32_t cin, cout;   /* channels */
     int32_t k, stride, pad;     /* READCONV_FUSED: k = extra identity 64-channel blocks after the canonical 3 (0 | 2) */
     int32_t lin, lout;   /* positions per row before / after */
     int32_t flags;
-    int32_t seg;         /* hello_segment (SEGSUM / MIX / READCONV_FUSED) */
+    int32_t seg;         /* hello_segment (SEGSUM / MIX / READCONV_FUSED); two-source CONV1D: channels of src0 */
     int32_t c1;          /* CONCAT: channels of src1; CONV1D: groups of a grouped convolution (nn.Conv1d groups; 0 / 1 = dense):
                           * output block g reads input channels [g cin/groups, (g+1) cin/groups), weights packed per output
                           * channel over ITS group's k * cin/groups inputs; cout/groups a multiple of 128, cin/groups of 16 */

@@ -163,6 +163,30 @@ def test_fused_expert_front_outputs_match_the_layer_kernels(name, n_sites):
     layered.close()
 
 
+@pytest.mark.parametrize("cfg,n_sites", [("hybrid_no_ensemble", 37), ("hybrid_no_ensemble", 700), ("hybrid_full", 300),
+                                         ("hybrid_no_ensemble_wide", 90)])
+def test_concat_folded_into_the_combiners_first_convolution_gives_the_same_bits(cfg, n_sites):
+    """The combiners' CONCAT ops (allele level and site level) are folded into the Winograd convolution that reads them
+    (two-source form of conv1d_wino_kernel / conv1d_wino_small_kernel): logits, meta weights and posteriors bit-identical to the
+    program that materialises the concatenations -- small launches (the small kernels) and launches of the tiled kernel."""
+    from hello_amd import compiler
+    from hello_amd.engine import Engine
+    spec = ns.build(cfg)
+    state = weights.synth_state(spec, seed=41)
+    batch = synth.make_sites(n_sites, seed=23, coverage=11, hybrid_coverage=7)
+    folded = Engine(spec, state, device=0, arithmetic="fp32")
+    two = [o for o in folded.program.ops if o.kind == compiler.OP_CONV1D and o.src1 != compiler.BUF_NONE]
+    assert len(two) == 2 and not any(o.kind == compiler.OP_CONCAT for o in folded.program.ops)
+    prog = compiler.compile_model(spec, state, fold_site_sums=False)
+    assert sum(1 for o in prog.ops if o.kind == compiler.OP_CONCAT) == 2
+    kept = Engine(spec, state, device=0, program=prog)
+    got, want = folded.forward_batch(batch, posteriors=True), kept.forward_batch(batch, posteriors=True)
+    for g, w in zip(got, want):
+        assert (g is None and w is None) or np.array_equal(g, w)
+    folded.close()
+    kept.close()
+
+
 def test_grouped_convolutions_run_group_by_group_and_match_the_block_diagonal_form(monkeypatch):
     """The 250 bp family's combiner (ConvCombiner250FeatureMap.py:5-24, groups = 2): its four grouped convolutions run group by
     group (hello_op.c1; two of them in Winograd form) instead of as block-diagonal dense layers -- logits against the same
