@@ -379,3 +379,18 @@ def test_grouped_convolutions_are_lowered_with_their_group_count_and_compact_wei
     assert np.array_equal(d[4:, :, 3:], w[4:].transpose(0, 2, 1)) and not d[4:, :, :3].any()
     small = ns.Conv(key="x", cin=32, cout=64, k=3, groups=2)
     assert not compiler.grouped_native(small)
+
+
+def test_combiner_concats_are_folded_into_two_source_convolutions():
+    """compiler._fold_concats: the hybrid models' two CONCAT ops (allele level, site level) disappear into the Winograd convolution
+    that reads them (src1 = second tensor, seg = channels of the first); a CONCAT feeding a grouped convolution stays."""
+    from hello_amd import compiler, netspec as ns, weights
+    spec = ns.build("hybrid_no_ensemble")
+    state = weights.synth_state(spec, seed=2)
+    folded, kept = compiler.compile_model(spec, state), compiler.compile_model(spec, state, fold_site_sums=False)
+    assert not any(o.kind == compiler.OP_CONCAT for o in folded.ops) and sum(o.kind == compiler.OP_CONCAT for o in kept.ops) == 2
+    two = [o for o in folded.ops if o.kind == compiler.OP_CONV1D and o.src1 != compiler.BUF_NONE]
+    assert [(o.cin, o.cout, o.seg, o.k, bool(o.flags & compiler.FLAG_WINOGRAD)) for o in two] == [(256, 512, 128, 3, True)] * 2
+    assert all(len({o.src0, o.src1, o.dst}) == 3 for o in two) and np.array_equal(folded.weights, kept.weights)
+    m250 = compiler.compile_model(ns.build("merged_hybrid_250"), weights.synth_state(ns.build("merged_hybrid_250"), seed=2))
+    assert sum(o.kind == compiler.OP_CONCAT for o in m250.ops) == 1                 # its reader is a grouped convolution
