@@ -22,7 +22,12 @@ the shared counts, pins and feeds ONLY its range through its own pipeline (host 
 keeps its logits resident; ONE RCCL gather at the end of the run brings every rank's logits to rank 0, inside the
 timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S] [--launches-per-step B] [--scaling weak|strong]
+At N > 1 the line also carries the run's audit trail, collected with one ``all_gather_object`` AFTER the closing fence:
+``ranks`` (per rank: device index, PCI address, UUID, sites, reads, own seconds, launches, pinned bytes, CPUs), ``distinct_devices``,
+``backend``, ``gather_ms`` (two events around the one gather), ``slowest_rank``, ``balance`` = min / max reads per rank; and with
+``--scaling both`` (the default) ``strong_scaling``: a second timed region of the same K steps over the N = 1 stream cut N ways.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S] [--launches-per-step B] [--scaling weak|strong|both]
 """
 import argparse
 import json
@@ -138,6 +143,21 @@ def cpu_baseline(seed, budget_s=12.0):
                                     "sample": f"{done} sites in chunks of {chunk}, one process, {dt:.1f} s"}}
 
 
+def shard_cpu_ranges(cpus):
+    """[0, 1, 2, 5] -> "0-2,5" (a rank's CPU list, compact)."""
+    out, run = [], []
+    for c in sorted(cpus):
+        if run and c == run[-1] + 1:
+            run.append(c)
+        else:
+            if run:
+                out.append(run)
+            run = [c]
+    if run:
+        out.append(run)
+    return ",".join(str(r[0]) if len(r) == 1 else f"{r[0]}-{r[-1]}" for r in out)
+
+
 def rank_pieces(pool_counts, launches_total, rank, world):
     """The global step batch is ``launches_total`` pool batches back to back (cycling the pool).  Every rank
     computes the same read-balanced partition of its sites (hello_amd.shard.partition_sites) from the shared
@@ -176,9 +196,11 @@ def main():
     ap.add_argument("--fused", choices=["full", "trunk", "none"], default="full",
                     help="read convolver: one fused kernel from the bytes / layer-by-layer stem + fused trunk / "
                          "layer by layer")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+    ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
                     help="N > 1: weak = every GPU gets --launches-per-step launches per step (global batch N times as "
-                         "large); strong = the N = 1 stream (--launches-per-step launches per step in total) cut N ways")
+                         "large); strong = the N = 1 stream (--launches-per-step launches per step in total) cut N ways; "
+                         "both (default) = `value` is the weak run and a second timed region of the same K steps reports the "
+                         "strong one as `strong_scaling` (at N = 1 the two coincide and only one region runs)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--op-times", action="store_true", help="print per-op device times to stderr")
     args = ap.parse_args()
@@ -237,24 +259,23 @@ def main():
 
     spec = ns.build("single_tech")
     state = weights.synth_state(spec, seed=args.seed)
-    eng = Engine(spec, state, device=dev_index, fused={"full": True, "trunk": "trunk", "none": False}[args.fused])
+    # the headline is exact fp32 and says so from the engine's own record of what it computes in (never from a literal)
+    eng = Engine(spec, state, device=dev_index, fused={"full": True, "trunk": "trunk", "none": False}[args.fused], arithmetic="fp32")
+    if eng.program.arithmetic != "fp32":
+        raise SystemExit(f"the headline engine computes in {eng.program.arithmetic!r}: `value` / dtype 'f32' are exact fp32 only")
 
     # ---- the pinned host pool (the same seeded batches on every rank: one global site stream) ---------------
     pool = [synth.make_sites(args.sites, seed=1000 + i + args.seed, coverage=30) for i in range(args.pool)]
     counts = [dict(reads_per_site=shard.reads_per_site(b), alleles_per_site=b.alleles_per_site) for b in pool]
-    global_launches = args.launches_per_step * (world if args.scaling == "weak" else 1)
-    pieces, sizes = rank_pieces(counts, global_launches, rank, world)
-    # a rank pins what it feeds and nothing else: whole pool batches once each, a cut batch only as its slice
-    whole = {k: pin_batch(pool[k]) for k in sorted({k for k, lo, hi in pieces if (lo, hi) == (0, pool[k].n_sites)})}
-    cut = {(k, lo, hi): pin_batch(pool[k].site_slice(lo, hi)) for k, lo, hi in pieces if (lo, hi) != (0, pool[k].n_sites)}
-    piece_batches = [whole[k] if (lo, hi) == (0, pool[k].n_sites) else cut[(k, lo, hi)] for k, lo, hi in pieces]
-    pinned_bytes = sum(int(b.reads0.numel()) for b in list(whole.values()) + list(cut.values()))
-    step_sites = sum(hi - lo for _, lo, hi in pieces)
-    step_alleles = sizes[rank][1]
-    assert step_sites == sizes[rank][0] and step_alleles == sum(int(b.n_alleles) for b in piece_batches)
     pipe = HostPipeline(eng, depth=2, posteriors=True)
-    # a rank's logits of the whole run stay resident for the single gather at the end
-    sink = torch.zeros((eng.n_experts, max(args.steps, 1) * step_alleles), dtype=torch.float32, device=dev) if dist is not None else None
+    pinned_cache = {}
+
+    def pinned(k, lo, hi):
+        """A rank pins what it feeds and nothing else: whole pool batches once each, a cut batch only as its slice."""
+        key = (k, lo, hi)
+        if key not in pinned_cache:
+            pinned_cache[key] = pin_batch(pool[k] if (lo, hi) == (0, pool[k].n_sites) else pool[k].site_slice(lo, hi))
+        return pinned_cache[key]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -263,47 +284,94 @@ def main():
             if backend == "nccl":
                 torch.cuda.synchronize(dev)
 
-    def run_steps(n_steps, keep):
-        """n_steps passes over this rank's pieces through the pipeline; every result is harvested to host
-        memory before this returns.  -> number of launches harvested."""
-        harvested, col = 0, 0
-        for s in range(n_steps):
-            for p, b in enumerate(piece_batches):
-                snk = (sink, None, col, 0) if (sink is not None and keep is not None) else None
-                for item in pipe.submit(b, tag=(s, p), sink=snk):
-                    harvested += 1
-                    if keep is not None:
-                        keep.append(item)
-                col += int(b.n_alleles)
-        for item in pipe.flush():
-            harvested += 1
-            if keep is not None:
-                keep.append(item)
-        return harvested
+    identity = shard.device_identity(dev_index)
 
-    run_steps(args.warmup, None)
-    fence()
-    n_launches = args.steps * len(piece_batches)
-    eng.set_profiling(min(n_launches, 4096), only="readconv_fused")     # two events per launch: the dominant kernel
-    results = []
-    t0 = time.perf_counter()
-    harvested = run_steps(args.steps, results)
-    gathered = None
-    if dist is not None:
-        # the one collective of the path: every rank's logits of the run -> rank 0 (SURVEY.md 8e), then to its host
-        run_sizes = [(s * args.steps, a * args.steps) for s, a in sizes]
-        gathered, _ = shard.gather_results(sink, None, run_sizes, eng.n_experts, False, dst=0)
-        if gathered is not None:
-            gathered = gathered.cpu()
-    fence()
-    dt = time.perf_counter() - t0
-    assert harvested == n_launches, (harvested, n_launches)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    sites_total = sum(s for s, _ in sizes) * args.steps
-    value = sites_total / dt
+    def timed_region(mode, profile):
+        """W untimed + exactly K timed steps of this rank's share of the global step batch under ``mode`` (weak | strong),
+        fenced on both sides, results harvested to host and -- at N > 1 -- gathered to rank 0 inside the region.
+        -> dict: the run's aggregate numbers (same on every rank) + this rank's own report."""
+        global_launches = args.launches_per_step * (world if mode == "weak" else 1)
+        pieces, sizes = rank_pieces(counts, global_launches, rank, world)
+        piece_batches = [pinned(k, lo, hi) for k, lo, hi in pieces]
+        step_sites = sum(hi - lo for _, lo, hi in pieces)
+        step_alleles = sizes[rank][1]
+        step_reads = sum(int(b.reads0.shape[0]) for b in piece_batches)
+        assert step_sites == sizes[rank][0] and step_alleles == sum(int(b.n_alleles) for b in piece_batches)
+        # a rank's logits of the whole run stay resident for the single gather at the end
+        sink = (torch.zeros((eng.n_experts, max(args.steps, 1) * max(step_alleles, 1)), dtype=torch.float32, device=dev)
+                if dist is not None else None)
+
+        def run_steps(n_steps, keep):
+            """n_steps passes over this rank's pieces through the pipeline; every result is harvested to host
+            memory before this returns.  -> number of launches harvested."""
+            harvested, col = 0, 0
+            for s in range(n_steps):
+                for p, b in enumerate(piece_batches):
+                    snk = (sink, None, col, 0) if (sink is not None and keep is not None) else None
+                    for item in pipe.submit(b, tag=(s, p), sink=snk):
+                        harvested += 1
+                        if keep is not None:
+                            keep.append(item)
+                    col += int(b.n_alleles)
+            for item in pipe.flush():
+                harvested += 1
+                if keep is not None:
+                    keep.append(item)
+            return harvested
+
+        run_steps(args.warmup, None)
+        fence()
+        n_launches = args.steps * len(piece_batches)
+        if profile:
+            eng.set_profiling(min(max(n_launches, 1), 4096), only="readconv_fused")     # two events per launch: the dominant kernel
+        results = []
+        t0 = time.perf_counter()
+        harvested = run_steps(args.steps, results)
+        t_scored = time.perf_counter()
+        gathered, gather_ms, gather_host_ms = None, None, None
+        if dist is not None:
+            # the one collective of the path: every rank's logits of the run -> rank 0 (SURVEY.md 8e), then to its host.
+            # Timed with two events on the current stream (RCCL orders its work with it) and with the host clock.
+            run_sizes = [(s * args.steps, a * args.steps) for s, a in sizes]
+            ev0 = ev1 = None
+            if backend == "nccl":
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            g0 = time.perf_counter()
+            gathered, _ = shard.gather_results(sink, None, run_sizes, eng.n_experts, False, dst=0)
+            if ev1 is not None:
+                ev1.record()
+            if gathered is not None:
+                gathered = gathered.cpu()
+            if ev1 is not None:
+                ev1.synchronize()
+                gather_ms = float(ev0.elapsed_time(ev1))
+            gather_host_ms = 1e3 * (time.perf_counter() - g0)
+        own_dt = time.perf_counter() - t0                # this rank's clock before the closing fence (who was slowest)
+        fence()
+        dt = time.perf_counter() - t0
+        assert harvested == n_launches, (harvested, n_launches)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        sites_total = sum(s for s, _ in sizes) * args.steps
+        report = dict(rank=rank, local_rank=local_rank, host=os.uname().nodename, pid=os.getpid(), **identity,
+                      sites=int(step_sites * args.steps), alleles=int(step_alleles * args.steps), reads=int(step_reads * args.steps),
+                      launches=int(n_launches), timed_seconds=round(own_dt, 6), scored_seconds=round(t_scored - t0, 6),
+                      gather_ms=None if gather_ms is None else round(gather_ms, 4),
+                      gather_host_ms=None if gather_host_ms is None else round(gather_host_ms, 4),
+                      pinned_input_bytes=int(sum(int(b.reads0.numel()) for b in {id(b): b for b in piece_batches}.values())),
+                      cpus_pinned=len(cpus), cpu_list=shard_cpu_ranges(cpus))
+        return dict(mode=mode, dt=dt, value=sites_total / dt, sites_total=sites_total, sizes=sizes, pieces=pieces,
+                    piece_batches=piece_batches, results=results, gathered=gathered, n_launches=n_launches, report=report,
+                    gather_ms=gather_ms, gather_host_ms=gather_host_ms)
+
+    headline_mode = "strong" if args.scaling == "strong" else "weak"
+    run = timed_region(headline_mode, profile=True)
+    dt, value, sizes, pieces, piece_batches = run["dt"], run["value"], run["sizes"], run["pieces"], run["piece_batches"]
+    results, gathered, n_launches, sites_total = run["results"], run["gathered"], run["n_launches"], run["sites_total"]
+    pinned_bytes = run["report"]["pinned_input_bytes"]
 
     # ---- the dominant kernel's launch time over the timed region (HIP events on the launch stream) ---------
     op_rows, n_fw = eng.op_times_ms()
@@ -331,13 +399,20 @@ def main():
     finite = all(np.isfinite(lg).all() and np.isfinite(po).all() for _, lg, _, po in results[:len(piece_batches)])
     del results
 
-    traffic = None
+    # HBM bytes from the committed PMC passes of the same command (profiles/hbm_traffic.json, tools/profile_round.sh): the
+    # dominant kernel per launch (`traffic`, the contract's field) and EVERY kernel of the forward (`forward_traffic`)
+    traffic = forward_traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("bytes_per_launch")
+            tjson = json.load(open(tpath))
+            traffic = tjson.get("bytes_per_launch")
+            if tjson.get("bytes_per_forward") is not None:
+                forward_traffic = {"bytes": tjson["bytes_per_forward"], "algorithmic_bytes": tjson.get("algorithmic_bytes_per_forward"),
+                                   "by_kernel": tjson.get("bytes_per_forward_by_kernel"), "source": "profiles/hbm_traffic.json "
+                                   "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950-corrected: 2 x FETCH + WRITE)"}
         except Exception:
-            traffic = None
+            traffic = forward_traffic = None
     flops_launch = float(np.mean([site_flops(spec, pool[k].site_slice(lo, hi))[0] for k, lo, hi in pieces]))
     launch_s = dt / n_launches
     roofline = {
@@ -346,7 +421,7 @@ def main():
         # convolutions run in Winograd form (F(3,3): 5 instead of 9 fp32 contractions per 3 positions; F(2,3): 4
         # instead of 6 per 2), so the hardware fraction is priced on executed MFMA work and stays <= 1
         "achieved": round(executed, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "forward_traffic": forward_traffic,
         # the same launch priced on ALGORITHMIC work (direct-form 2 * MAC, SURVEY.md 8d: 10.152 MFLOP per read)
         "algorithmic_achieved": round(algorithmic, 3), "algorithmic_frac": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
         "formulas": {"frac": "2 * executed MAC per read * reads per launch / launch_ms / 157.3 TFLOP/s",
@@ -358,7 +433,8 @@ def main():
         "launch_ms": round(dom_ms, 4), "launches_timed": int(n_fw), "kernel_launches_per_forward": 2 if dom_op.kind == 8 else 1,
         "reads_per_launch": round(reads_per_launch, 1),
         "flop_per_launch": float(dom_flops), "executed_flop_per_launch": float(dom_exec),
-        "arithmetic": "fp32; k3/s1 convolutions in Winograd form (residual trunk and allele stage F(3,3), stem F(2,3))" if eng.program.winograd else "fp32, direct form",
+        "arithmetic": eng.program.arithmetic,          # the engine's own record, never a literal
+        "form": "k3/s1 convolutions in Winograd form (residual trunk and allele stage F(3,3), stem F(2,3))" if eng.program.winograd else "direct form",
         "whole_launch_algorithmic_frac": round(flops_launch / launch_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
         "hbm_algorithmic_gbs": round((900.0 * reads_per_launch) / launch_s / 1e9, 3),
         "pcie_h2d_gbs": round(float(np.mean([b.reads0.numel() for b in piece_batches])) / launch_s / 1e9, 3),
@@ -438,19 +514,19 @@ def main():
         # which would blur the per-kernel roofline above.
         two_engines = None
         try:
-            pinned = [whole[k] if k in whole else pin_batch(pool[k]) for k in range(len(pool))]
+            pinned2 = [pinned(k, 0, pool[k].n_sites) for k in range(len(pool))]
             eng2 = Engine(spec, state, device=dev_index)
             pipe2 = HostPipeline(engines=[eng, eng2], posteriors=True)
             done = 0
             for i in range(6):
-                done += len(pipe2.submit(pinned[i % len(pinned)], tag=i))
+                done += len(pipe2.submit(pinned2[i % len(pinned2)], tag=i))
             done += len(pipe2.flush())
             torch.cuda.synchronize(dev)
             n_two = 60
             t1 = time.perf_counter()
             got = 0
             for i in range(n_two):
-                got += len(pipe2.submit(pinned[i % len(pinned)], tag=i))
+                got += len(pipe2.submit(pinned2[i % len(pinned2)], tag=i))
             got += len(pipe2.flush())
             torch.cuda.synchronize(dev)
             dt_two = time.perf_counter() - t1
@@ -606,12 +682,41 @@ def main():
                       "tolerance": 1e-4, "sites": int(check.n_sites), "alleles": int(check.n_alleles),
                       "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
 
+    # ---- who ran where (after the timed region): every rank's own report, one all_gather_object -----------------------
+    reports = shard.summarize_ranks(shard.collect_rank_reports(run["report"]))
+    strong = None
+    if args.scaling == "both":
+        if world > 1:
+            # a second timed region of the same K steps: the N = 1 stream cut N ways (total work fixed)
+            run2 = timed_region("strong", profile=False)
+            rep2 = shard.summarize_ranks(shard.collect_rank_reports(run2["report"]))
+            strong = {"value": round(run2["value"], 1), "unit": "sites/s", "scaling": "strong",
+                      "ms_per_step": round(1e3 * run2["dt"] / max(args.steps, 1), 4), "sites_total": int(run2["sites_total"]),
+                      "timed_region_s": round(run2["dt"], 3), "gather_ms": run2["gather_ms"], "gather_host_ms": run2["gather_host_ms"],
+                      "slowest_rank": rep2["slowest_rank"], "balance": rep2["balance"], "distinct_devices": rep2["distinct_devices"],
+                      "ranks": rep2["ranks"]}
+            del run2
+        else:
+            strong = {"value": round(value, 1), "unit": "sites/s", "scaling": "strong",
+                      "note": "N = 1: the strong and the weak workload are the same stream; one timed region"}
+    cpu_reason = None
+    if cpu is None:
+        cpu_reason = ("not run at N > 1: the CPU baseline is timed on rank 0 of the N = 1 run only (it forks one worker per host core, "
+                      "which would compete with the other ranks' feeder threads)" if world > 1 else
+                      "skipped: --no-cpu-baseline" if args.no_cpu_baseline else
+                      "skipped: running under a profiler whose preloaded library has initialised the GPU (the baseline forks)" if profiled else
+                      "not run on this rank")
+
     if rank == 0:
         b0 = pool[0]
+        scaling_label = headline_mode
+        print(f"bench: N = {world} ({backend if dist is not None else 'no process group'}), `value` = {scaling_label.upper()} scaling"
+              + (f", strong scaling beside it: {strong['value']:.0f} sites/s" if strong and world > 1 else "")
+              + f"; {reports['distinct_devices']} distinct device(s) over {reports['ranks_seen']} rank(s)", file=sys.stderr)
         line = {
             "metric": "candidate sites/sec (whole node)", "value": round(value, 1), "unit": "sites/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / max(args.steps, 1), 4), "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": round(1e3 * dt / max(args.steps, 1), 4), "higher_is_better": True, "scaling": scaling_label,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Illumina 30x single-tech model (moe_attention single_tech weight_norm), synthetic "
                                    f"pileups cov 30, seeded synthetic weights; host-resident uint8 pileups + counts -> "
@@ -625,14 +730,19 @@ def main():
                        "reads_per_site": round(b0.reads0.shape[0] / b0.n_sites, 2),
                        "alleles_per_site": round(b0.n_alleles / b0.n_sites, 3),
                        "window": 150, "channels": 6, "parallelism": f"site-sharded dp{world}, one gather at the end",
+                       "arithmetic": eng.program.arithmetic,
                        "fused_read_convolver": bool(fused), "outputs": "logits + genotype-pair posteriors (host)",
                        "host_cpus_of_rank0": len(cpus), "pinned_input_bytes_of_rank0": pinned_bytes,
                        "repeat_passes_bit_identical": drift == 0, "outputs_finite": bool(finite)},
             "roofline": roofline,
-            "cpu_baseline": cpu if (cpu is not None or world == 1) else {
-                "value": None, "unit": "sites/s", "cores": 0, "kind": "port",
-                "sample": "not run at N > 1: the CPU baseline is timed on rank 0 of the N = 1 run only (it forks one worker per "
-                          "host core, which would compete with the other ranks' feeder threads)"},
+            "cpu_baseline": cpu, "cpu_baseline_reason": cpu_reason,
+            # audit of the run: one entry per rank (device PCI address / UUID, sites, reads, own seconds, launches, pinned bytes,
+            # CPUs), collected with one all_gather_object after the closing fence
+            "backend": (backend if dist is not None else None), "ranks_seen": reports["ranks_seen"],
+            "distinct_devices": reports["distinct_devices"], "slowest_rank": reports["slowest_rank"],
+            "rank_seconds_min_max": reports["rank_seconds_min_max"], "balance": reports["balance"],
+            "gather_ms": run["gather_ms"], "gather_host_ms": run["gather_host_ms"], "ranks": reports["ranks"],
+            "strong_scaling": strong,
             "device_resident": device_resident,
             "two_engines": two_engines,
             "bf16x3": bf16x3,

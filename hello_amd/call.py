@@ -233,7 +233,7 @@ def parser() -> argparse.ArgumentParser:
                     help="processes / GPUs of this node: > 1 re-launches this command under torch.distributed.run "
                          "(a launch that is already under it reads RANK / WORLD_SIZE instead)")
     ap.add_argument("--sites_per_launch", type=int, default=8192, help="shards are coalesced into GPU launches of about this many sites")
-    ap.add_argument("--arithmetic", choices=["fp32", "bf16x3", "bf16x3+32", "bf16x3+allele", "bf16x3+32+allele"], default="fp32",
+    ap.add_argument("--arithmetic", choices=["fp32", "bf16x3", "bf16x3+32"], default="fp32",
                     help="fp32: exact fp32 everywhere (default).  bf16x3: the read convolver's 64-channel trunk on the bf16 matrix "
                          "cores as 3-term splits (~1.3x faster; posteriors move by ~1e-6)")
     return ap

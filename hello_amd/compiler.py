@@ -211,23 +211,7 @@ def _is_canonical_read_convolver(nodes, cin) -> bool:
     return _canonical_read_convolver_extras(nodes, cin) == 0
 
 
-ARITHMETICS = ("fp32", "bf16x3", "bf16x3+32", "bf16x3+allele", "bf16x3+32+allele")
-
-
-def pack_conv_bf16x3(w: np.ndarray, b: np.ndarray):
-    """[cout, cin, k] -> the split weights of conv_bf16x3.hip: dense [cout padded to 128][k * cin] with K index = tap * cin
-    + c, as two bf16 planes hi = bf16(w), lo = bf16(w - hi) ([hi | lo][cout_pad][kpad] uint16, returned as float32 words),
-    and the bias padded likewise."""
-    from .readconv_pack import to_bf16_bits
-    cout, cin, k = w.shape
-    cout_pad = -(-cout // 128) * 128
-    dense = np.zeros((cout_pad, k * cin), np.float32)
-    dense[:cout] = np.transpose(w.astype(np.float32), (0, 2, 1)).reshape(cout, k * cin)
-    hi = to_bf16_bits(dense)
-    lo = to_bf16_bits(dense - (hi.astype(np.uint32) << np.uint32(16)).view(np.float32))
-    bias = np.zeros(cout_pad, np.float32)
-    bias[:cout] = b
-    return np.concatenate([hi.ravel(), lo.ravel()]).view(np.float32).copy(), bias
+ARITHMETICS = ("fp32", "bf16x3", "bf16x3+32")
 
 
 class _Lowering:
@@ -236,7 +220,6 @@ class _Lowering:
             raise ValueError(f"arithmetic must be one of {ARITHMETICS}, not {arithmetic!r}")
         self.arithmetic = arithmetic
         self.used_bf16x3 = False
-        self.used_bf16x3_allele = False
         self.used_xattn_front = False
         self.spec = spec
         self.state = state
@@ -276,17 +259,9 @@ class _Lowering:
             raise NotImplementedError("dilated convs are not implemented by the HIP engine")
         assert x.channels == node.cin, (node.key, x.channels, node.cin)
         w, b = self.folded[node.key]
-        # arithmetic "...+allele": the allele- / site-level convolutions on the bf16 matrix cores as 3-term splits
-        # (conv_bf16x3.hip, direct form)
-        split = ("allele" in self.arithmetic and x.domain in (ROWS_ALLELES, ROWS_SITES) and not x.u8 and node.groups == 1
-                 and node.cin % 32 == 0 and node.cout % 4 == 0 and node.norm != "ln")
-        wino = self.winograd and self._winograd_ok(node, x) and not split
-        if split:
-            packed, bias = pack_conv_bf16x3(w, b)
-            self.used_bf16x3_allele = True
-        else:
-            native = grouped_native(node) and not x.u8        # w is [cout, cin / groups, k]: each row its own group's inputs
-            packed, bias = (pack_conv_winograd(w, b, x.length) if wino else pack_conv(w, b, node.groups, expand=not native))
+        wino = self.winograd and self._winograd_ok(node, x)
+        native = grouped_native(node) and not x.u8        # w is [cout, cin / groups, k]: each row its own group's inputs
+        packed, bias = (pack_conv_winograd(w, b, x.length) if wino else pack_conv(w, b, node.groups, expand=not native))
         lout = ns.out_length([node], x.length)
         m = winograd_outputs_per_tile(lout)
         y = self.new(x.domain, lout, node.cout)
@@ -296,9 +271,8 @@ class _Lowering:
             OP_CONV1D, x.domain, src0=x.vid, dst=y.vid, res=res.vid if (res is not None and not layer_norm) else BUF_NONE,
             cin=node.cin, cout=node.cout, k=node.k, stride=node.stride, pad=node.pad,
             lin=x.length, lout=lout,
-            flags=((0 if layer_norm else act_flag) | (FLAG_SRC_U8 if x.u8 else 0) | (FLAG_WINOGRAD if wino else 0)
-                   | (FLAG_BF16X3 if split else 0)),
-            c1=node.groups if (not split and grouped_native(node) and not x.u8) else 0,
+            flags=(0 if layer_norm else act_flag) | (FLAG_SRC_U8 if x.u8 else 0) | (FLAG_WINOGRAD if wino else 0),
+            c1=node.groups if native else 0,
             w_off=self.blob.add(packed), b_off=self.blob.add(bias), name=node.key,
             macs_per_row=lout * node.cout * (node.cin // node.groups) * node.k,
             exec_macs_per_row=float(-(-lout // m) * (m + 2) * node.cout * (node.cin // node.groups)) if wino else 0.0))
@@ -324,8 +298,7 @@ class _Lowering:
                                macs_per_row=ns.macs(nodes, 36), exec_macs_per_row=readconv_pack.compressor_executed_macs(blocks)))
             self.used_fused_compressor = True
             return y
-        front = readconv_pack.xattn_front_match(nodes) if (self.fused is True and self.winograd and isinstance(x, tuple)
-                                                           and "allele" not in self.arithmetic) else None
+        front = readconv_pack.xattn_front_match(nodes) if (self.fused is True and self.winograd and isinstance(x, tuple)) else None
         if front is not None:
             allele, sites = x
             site = sites[front[0].pick]
@@ -523,7 +496,7 @@ class _Lowering:
             from . import readconv_pack
             nodes = spec.nets[f"expert{idx}"]
             front = (readconv_pack.xattn_front_match(nodes, mixed_ahead=True)
-                     if (additive and self.fused is True and self.winograd and "allele" not in self.arithmetic
+                     if (additive and self.fused is True and self.winograd
                          and (allele.length, allele.channels) == (18, 128)) else None)
             if front is not None:
                 # the same fused front as MoEAttention's experts (xattn_front_kernel), with x = a - (s - a) formed in that order

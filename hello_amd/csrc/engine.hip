@@ -206,6 +206,9 @@ int validate_model(const hello_model_desc* d) {
                                              "and cout / groups a multiple of 128 (a workgroup's channel block lies inside one group)", i, o.c1);
             if ((o.lin + 2 * o.pad - o.k) / o.stride + 1 != o.lout)
                 return fail(HELLO_ERR_MODEL, "op %d: lout inconsistent", i);
+            if (o.flags & (HELLO_FLAG_BF16X3 | HELLO_FLAG_BF16X3_32))
+                return fail(HELLO_ERR_MODEL, "op %d: the bf16x3 arithmetic modes exist for the fused read convolver only (ABI 2 "
+                                             "dropped the split-operand CONV1D)", i);
         }
         if (o.kind == HELLO_OP_COMPRESSOR_FUSED &&
             !(o.cin == 64 && o.cout == 128 && o.lin == 36 && o.lout == 18 && hello::compressor_supports_blocks(o.k) &&
@@ -313,11 +316,6 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
                                      : (size_t)((o.k * cing + 31) / 32) * 32;
             w_end = (size_t)o.w_off + cpad * kpad;
             b_end = (size_t)o.b_off + cpad;
-            if (o.flags & HELLO_FLAG_BF16X3) {       // split weights: [hi | lo][cout padded to 128][k * cin] bf16
-                const size_t c128 = (size_t)((o.cout + 127) / 128) * 128;
-                w_end = (size_t)o.w_off + c128 * (size_t)(o.k * o.cin);
-                b_end = (size_t)o.b_off + c128;
-            }
         } else if (o.kind == HELLO_OP_HEAD) {
             w_end = (size_t)o.w_off + (size_t)o.cout * o.cin;
             b_end = (size_t)o.b_off + o.cout;
@@ -783,17 +781,6 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 a.src_u8 = (o.flags & HELLO_FLAG_SRC_U8) ? 1 : 0;
                 a.wino = (o.flags & HELLO_FLAG_WINOGRAD) ? 1 : 0;
                 if (!a.src) return fail(HELLO_ERR_ARG, "op %d reads an input the caller did not supply", op_index);
-                if (o.flags & HELLO_FLAG_BF16X3) {
-                    a.kpad = o.k * o.cin;
-                    a.cout_pad = ((o.cout + 127) / 128) * 128;
-                    if (a.wino || !hello::conv1d_bf16x3_supported(a))
-                        return fail(HELLO_ERR_MODEL, "op %d: this convolution has no bf16x3 form (float input, cin %% 32 == 0, "
-                                                     "cout %% 4 == 0, not Winograd-packed)", op_index);
-                    if ((size_t)o.w_off + (size_t)a.cout_pad * a.kpad > e->n_weight_floats)
-                        return fail(HELLO_ERR_MODEL, "op %d: split weight block truncated", op_index);
-                    HIP_TRY(hello::launch_conv1d_bf16x3(a, stream));
-                    break;
-                }
                 if (a.wino) {
                     a.kpad = (hello::conv1d_wino_outputs_per_tile(o.lin) + 2) * a.cin;
                     a.cout_pad = o.cout;

@@ -38,11 +38,6 @@ bool conv1d_wino_supported(const ConvArgs& a);
 int conv1d_wino_outputs_per_tile(int length);      // 3 when the row length is a multiple of 3, else 2
 hipError_t launch_conv1d_wino(const ConvArgs& a, hipStream_t stream);
 
-// conv_bf16x3.hip: the same convolution with 3-term split bf16 operands (arithmetic mode "...+allele"); `w` points at the
-// split weights [hi | lo][cout_pad][kpad] bf16, kpad = k * cin, cout_pad a multiple of 128
-bool conv1d_bf16x3_supported(const ConvArgs& a);
-hipError_t launch_conv1d_bf16x3(const ConvArgs& a, hipStream_t stream);
-
 hipError_t launch_maxpool(const float* src, float* dst, long long rows, int lin, int lout, int c,
                           int k, int stride, int pad, hipStream_t stream);
 

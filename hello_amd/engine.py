@@ -23,6 +23,7 @@ _log = logging.getLogger(__name__)
 _LIB_PATH = os.environ.get("HELLO_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                         "libhello_mi355x.so")
 HELLO_IN_DEVICE, HELLO_OUT_DEVICE, HELLO_LAYOUT_RCL = 1, 2, 4
+ABI_VERSION = 2          # HELLO_ABI_VERSION of include/hello_mi355x.h
 
 
 class HelloOp(C.Structure):
@@ -63,6 +64,11 @@ def load_library():
     vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
     lib.hello_last_error.restype = C.c_char_p
     lib.hello_abi_version.restype = C.c_int
+    # a stale library (HELLO_LIB override, a cached build) would read this layer's programs with another meaning of the
+    # hello_op fields: refuse it here, before any program reaches it
+    if lib.hello_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{_LIB_PATH} implements ABI version {lib.hello_abi_version()}, this Python layer speaks {ABI_VERSION}: "
+                           f"rebuild it (`make -C hello_amd/csrc`)")
     lib.hello_engine_create.argtypes = [C.POINTER(HelloModelDesc), vp, C.c_size_t, C.c_int, C.POINTER(vp)]
     lib.hello_engine_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, f32p, f32p, f32p, i32, vp]
     lib.hello_engine_posteriors.argtypes = [vp, f32p, f32p, vp, i32, i32, i64, f32p, i32, vp]
@@ -115,7 +121,7 @@ def model_desc(program: "compiler.Program"):
     bufs = (HelloBuffer * len(program.buffers))()
     for dst, (dom, fpr) in zip(bufs, program.buffers):
         dst.domain, dst.floats_per_row = dom, fpr
-    desc = HelloModelDesc(1, program.window, program.channels0, program.channels1, program.n_experts, int(program.has_meta),
+    desc = HelloModelDesc(ABI_VERSION, program.window, program.channels0, program.channels1, program.n_experts, int(program.has_meta),
                           int(program.uses_ref), len(program.buffers), bufs, len(program.ops), ops)
     return desc, (ops, bufs)
 
@@ -130,22 +136,13 @@ class Engine:
         convolutions on the bf16 matrix cores as 3-term splits (x w ~= xh wh + xh wl + xl wh; ~2^-17 per product, the
         residual stream kept in fp32) -- or "bf16x3+32" -- its six 32 -> 32 convolutions too; DESIGN.md section 3.2 gives
         their measured accuracy and speed.  An explicit "bf16x3"
-        raises where the mode does not exist (other read-convolver geometries, layer-by-layer paths); the environment
-        variable HELLO_ARITHMETIC=bf16x3 (or bf16x3+32) only changes the default of callers that pass nothing, and only where the mode
-        exists (it is how the whole parity suite is run in this mode)."""
+        raises where the mode does not exist (other read-convolver geometries, layer-by-layer paths).  Nothing in the
+        environment changes the arithmetic: ``self.program.arithmetic`` is what was asked for here (the test suite runs
+        itself in a split mode through a fixture of tests/conftest.py, not through this constructor)."""
         self.lib = load_library()
         self.spec = spec
         if program is None:
-            if arithmetic is None and os.environ.get("HELLO_ARITHMETIC", "fp32") != "fp32":
-                try:
-                    program = compiler.compile_model(spec, state, fused=fused, winograd=winograd,
-                                                     arithmetic=os.environ["HELLO_ARITHMETIC"])
-                    _log.warning("HELLO_ARITHMETIC=%s: engine for %s created in that arithmetic (not the exact-fp32 default)",
-                                 os.environ["HELLO_ARITHMETIC"], spec.name)
-                except ValueError:
-                    program = None
-            if program is None:
-                program = compiler.compile_model(spec, state, fused=fused, winograd=winograd, arithmetic=arithmetic or "fp32")
+            program = compiler.compile_model(spec, state, fused=fused, winograd=winograd, arithmetic=arithmetic or "fp32")
         self.program = program
         p = self.program
         desc, self._desc_arrays = model_desc(p)

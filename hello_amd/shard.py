@@ -190,3 +190,55 @@ def pin_rank(local_rank: int, local_world: int, device_index: Optional[int] = No
     except OSError:
         pass
     return cpus
+
+
+# ------------------------------------------------------------------------------------------------
+# evidence of a multi-rank run: who ran where, on what, for how long (collected AFTER the timed region)
+# ------------------------------------------------------------------------------------------------
+def device_identity(device_index: int) -> dict:
+    """What distinguishes one GPU of the node from another, from the runtime's own properties: PCI address, UUID, name."""
+    out = {"device_index": int(device_index), "pci_bus_id": None, "uuid": None, "name": None}
+    try:
+        import torch
+        prop = torch.cuda.get_device_properties(device_index)
+        out["name"] = prop.name
+        out["pci_bus_id"] = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
+        uuid = getattr(prop, "uuid", None)
+        out["uuid"] = None if uuid is None else str(uuid)
+    except Exception:
+        pass
+    return out
+
+
+def collect_rank_reports(report: dict, group=None) -> List[dict]:
+    """Every rank's ``report`` on every rank, in rank order (one ``all_gather_object``; a plain list of the one report when no
+    process group is up).  Evidence, not data path: called after the timed region's closing fence."""
+    try:
+        import torch.distributed as dist
+        up = dist.is_available() and dist.is_initialized()
+    except Exception:
+        up = False
+    if not up:
+        return [dict(report)]
+    bucket = [None] * dist.get_world_size(group)
+    dist.all_gather_object(bucket, dict(report), group=group)
+    return bucket
+
+
+def summarize_ranks(reports: Sequence[dict]) -> dict:
+    """The audit fields of a multi-rank bench line from the ranks' own reports: the list itself, how many DISTINCT
+    devices the ranks drove (by PCI address / UUID, falling back to (host, device index)), which rank was slowest, and how even
+    the read-balanced partition came out (min / max reads over the ranks that had any)."""
+    reports = sorted((dict(r) for r in reports), key=lambda r: r.get("rank", 0))
+
+    def key(r):
+        return (r.get("host"), r.get("uuid") or r.get("pci_bus_id") or r.get("device_index"))
+    seconds = [float(r.get("timed_seconds", 0.0)) for r in reports]
+    reads = [int(r.get("reads", 0)) for r in reports]
+    busy = [x for x in reads if x > 0]
+    return {
+        "ranks": reports, "ranks_seen": len(reports), "distinct_devices": len({key(r) for r in reports}),
+        "slowest_rank": int(reports[int(np.argmax(seconds))].get("rank", 0)) if reports else None,
+        "rank_seconds_min_max": [round(min(seconds), 6), round(max(seconds), 6)] if seconds else None,
+        "balance": round(min(busy) / max(busy), 4) if busy else None,
+    }

@@ -24,6 +24,7 @@ still read and written.
 from __future__ import annotations
 
 import json
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -136,22 +137,56 @@ def write_flat(path: str, arrays: dict) -> str:
     return path
 
 
+def _header_entry(path: str, name: str, entry, room: int):
+    """One checked entry of a ``.hshard`` header -> (dtype, shape, offset, bytes).  The header is the file's own claim
+    about itself: a negative offset or dimension would make NumPy slice from the END of the buffer and hand back a wrong
+    view without an error, so everything is refused here by name."""
+    try:
+        dtype, shape, at = entry
+        dt = np.dtype(dtype)
+        shape = [int(d) for d in shape]
+        at = int(at)
+    except (TypeError, ValueError) as e:
+        raise ValueError(f"malformed shard {path}: header entry of array {name}: {e}") from None
+    if dt.kind not in "iuf" or dt.itemsize not in (1, 2, 4, 8) or dt.hasobject:
+        raise ValueError(f"malformed shard {path}: array {name} has dtype {dtype!r} (integer or float arrays only)")
+    if at < 0 or any(d < 0 for d in shape):
+        raise ValueError(f"malformed shard {path}: array {name} has a negative offset or dimension ({at}, {shape})")
+    count = 1
+    for d in shape:
+        count *= d
+    nbytes = count * dt.itemsize
+    if at + nbytes > room:
+        raise ValueError(f"malformed shard {path}: array {name} runs past the end of the file")
+    return dt, tuple(shape), at, nbytes
+
+
+def _header(path: str, raw: bytes, n: int) -> dict:
+    if len(raw) != n:
+        raise ValueError(f"malformed shard {path}: the header is cut short ({len(raw)} of {n} bytes)")
+    try:
+        header = json.loads(raw)
+    except ValueError as e:
+        raise ValueError(f"malformed shard {path}: the header is not JSON ({e})") from None
+    if not isinstance(header, dict):
+        raise ValueError(f"malformed shard {path}: the header is not a table of arrays")
+    return header
+
+
 def read_flat(path: str) -> dict:
     """One read; every array is a view of the file's buffer."""
     buf = np.fromfile(path, dtype=np.uint8)
     if buf.shape[0] < 16 or buf[:8].tobytes() != MAGIC:
         raise ValueError(f"{path} is not a shard file (no {MAGIC.decode()} magic)")
     n = int(buf[8:16].view(np.uint64)[0])
-    header = json.loads(buf[16:16 + n].tobytes())
+    if n > buf.shape[0] - 16:
+        raise ValueError(f"malformed shard {path}: the header is cut short ({buf.shape[0] - 16} of {n} bytes)")
+    header = _header(path, buf[16:16 + n].tobytes(), n)
     base = 16 + n
     out = {}
-    for name, (dtype, shape, at) in header.items():
-        dt = np.dtype(dtype)
-        count = int(np.prod(shape)) if shape else 1
-        end = base + at + count * dt.itemsize
-        if end > buf.shape[0]:
-            raise ValueError(f"malformed shard {path}: array {name} runs past the end of the file")
-        out[name] = buf[base + at:end].view(dt).reshape(tuple(shape))
+    for name, entry in header.items():
+        dt, shape, at, nbytes = _header_entry(path, name, entry, buf.shape[0] - base)
+        out[name] = buf[base + at:base + at + nbytes].view(dt).reshape(shape)
     return out
 
 
@@ -162,14 +197,19 @@ def read_flat_arrays(path: str, names: Sequence[str]) -> dict:
         if len(head) < 16 or head[:8] != MAGIC:
             raise ValueError(f"{path} is not a shard file (no {MAGIC.decode()} magic)")
         n = int(np.frombuffer(head[8:], np.uint64)[0])
-        header = json.loads(fh.read(n))
+        size = os.fstat(fh.fileno()).st_size
+        if n > size - 16:
+            raise ValueError(f"malformed shard {path}: the header is cut short ({size - 16} of {n} bytes)")
+        header = _header(path, fh.read(n), n)
         out = {}
         for name in names:
             if name in header:
-                dtype, shape, at = header[name]
-                dt = np.dtype(dtype)
+                dt, shape, at, nbytes = _header_entry(path, name, header[name], size - 16 - n)
                 fh.seek(16 + n + at)
-                out[name] = np.frombuffer(fh.read(int(np.prod(shape)) * dt.itemsize if shape else dt.itemsize), dt).reshape(tuple(shape))
+                raw = fh.read(nbytes)
+                if len(raw) != nbytes:
+                    raise ValueError(f"malformed shard {path}: array {name} runs past the end of the file")
+                out[name] = np.frombuffer(raw, dt).reshape(shape)
     return out
 
 
@@ -207,6 +247,7 @@ def write_shard(path: str, sites: Sequence[CandidateSite], compressed: bool = Fa
     return path
 
 
+READ_ARRAYS = ("reads_per_allele", "bases", "quals", "read_off", "cigars", "cigar_off", "ref_start", "mapq", "orientation", "hp")
 QUERY_OPS = np.zeros(16, np.int64)
 QUERY_OPS[[0, 1, 4, 7, 8]] = 1                    # BAM operations that consume read bases: M, I, S, =, X
 
@@ -295,7 +336,9 @@ class PackedShard:
         return self._ref_text[int(self.ref_off[s]):int(self.ref_off[s + 1])]
 
     def has_reads(self, tech: int) -> bool:
-        return f"reads_per_allele{tech}" in self.z
+        """Technology ``tech`` is part of this shard: technology 0 always, technology 1 exactly when ``has_second`` says so
+        (``validate`` refuses a file whose arrays disagree with the flag, so what is consumed is what was checked)."""
+        return f"reads_per_allele{tech}" in self.z and (tech == 0 or self.hybrid)
 
     def n_reads(self, tech: int = 0) -> int:
         """Reads the featurizer will write for technology ``tech`` (dummy reads of unsupported alleles included)."""
@@ -344,9 +387,14 @@ class PackedShard:
                 s = int(np.argmax(short))
                 bad(f"the reference window [{int(self.window_start[s])}, {int(window_end[s])}) does not cover the feature window "
                     f"[{int(lo[s])}, {int(lo[s]) + feature_length}) and the allele span", s)
+        if not self.hybrid:
+            stray = sorted(k for k in self.z if k.endswith("1") and k[:-1] in READ_ARRAYS)
+            if stray:
+                bad(f"has_second is 0 but the file carries arrays of a second technology ({', '.join(stray)})")
         for tech in (0, 1) if self.hybrid else (0,):
-            if not self.has_reads(tech):
-                bad(f"has_second is set but the arrays of technology {tech} are missing")
+            missing = sorted(k for k in READ_ARRAYS if f"{k}{tech}" not in self.z)
+            if missing:
+                bad(("has_second is set but " if tech else "") + f"the arrays of technology {tech} are missing ({', '.join(missing)})")
             g = lambda k: np.asarray(self.z[f"{k}{tech}"])                            # noqa: E731
             counts, read_off, cigar_off = g("reads_per_allele").astype(np.int64), g("read_off").astype(np.int64), g("cigar_off").astype(np.int64)
             if counts.shape[0] != A:

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define HELLO_ABI_VERSION 1
+#define HELLO_ABI_VERSION 2      /* 2: CONV1D groups in c1, two-source CONV1D (src1 / seg), XATTN_FRONT, flags 64 / 128 on
+                                    READCONV_FUSED only (a CONV1D carrying them is refused), hello_site_records */
 
 typedef enum hello_status {
     HELLO_OK = 0,
@@ -116,8 +117,6 @@ typedef enum hello_op_kind {
                                         splits x w ~= xh wh + xh wl + xl wh of pre-split operands; their split weights
                                         (hello_amd/readconv_pack.py pack_bf16x3) follow the op's fp32 weight block.  Never
                                         the default: results differ from exact fp32 at the 1e-6 level of the activations */
-                                     /* CONV1D with HELLO_FLAG_BF16X3 ("...+allele"): float input, cin % 32 == 0, direct form on split
-                                        operands (csrc/conv_bf16x3.hip); weights [hi | lo][cout padded to 128][k * cin] bf16 */
 #define HELLO_FLAG_BF16X3_32 128     /* with HELLO_FLAG_BF16X3 ("bf16x3+32"): the six 32 -> 32 convolutions of the ResidualBlock(32)s too */
 #define HELLO_FLAG_MIX_REST 8        /* MIX: dst[a] = src0[a] - (src1[site(a)] - src0[a])  (:372-383)  */
 

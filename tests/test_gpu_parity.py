@@ -657,7 +657,7 @@ def test_bf16x3_mode_is_refused_where_it_does_not_exist():
 _ORACLE_LOGITS = {}
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3+32", "bf16x3+32+allele"])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3+32"])
 @pytest.mark.parametrize("cfg,kw", [("single_tech", dict(coverage=30)), ("hybrid_full", dict(coverage=20, hybrid_coverage=10)),
                                     ("single_tech_hp", dict(coverage=(20, 80), channels=7, tech="pacbio"))])
 def test_bf16x3_mode_frames_and_posteriors(cfg, kw, mode):
@@ -686,9 +686,6 @@ def test_bf16x3_mode_frames_and_posteriors(cfg, kw, mode):
         dev = float(np.abs(frames[1] - frames[0]).max()) / scale
         print(f"{mode} {cfg} op {i}: frames max |d| / scale = {dev:.2e} (scale {scale:.3g})")
         assert 0 < dev < 1e-4
-    if "allele" in mode:        # the allele stage's convolutions on split operands too: every one of them carries the flag
-        convs = [o for o in split.program.ops if o.kind == 1 and o.domain in (2, 3)]
-        assert convs and all(o.flags & 64 for o in convs) and not any(o.flags & 32 for o in convs)
     logits, meta, post = split.forward_batch(batch, posteriors=True)
     again, _, post2 = split.forward_batch(batch, posteriors=True)
     assert np.array_equal(logits, again) and np.array_equal(post, post2)

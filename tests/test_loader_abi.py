@@ -271,7 +271,7 @@ def test_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} is declared in include/hello_mi355x.h but not exported"
     lib.hello_abi_version.restype = ctypes.c_int
-    assert lib.hello_abi_version() == 1
+    assert lib.hello_abi_version() == 2
 
 
 def test_engine_fails_loudly_without_a_gpu():
@@ -287,7 +287,7 @@ def test_engine_fails_loudly_without_a_gpu():
 def test_expert_front_is_one_fused_op_with_two_outputs_and_the_kernels_weight_layout():
     """The allele-level expert's front (MIX, 1x1, strided convolution, shortcut: xattn_subtract.py:9-60) lowers to ONE op whose
     `res` buffer is its second OUTPUT (the shortcut), read as the residual of the block's second convolution; unfused lowerings
-    (fused="trunk", the +allele arithmetic) keep the four launches; other expert shapes (MoEMergedAdvanced's) are not matched."""
+    (fused="trunk") keep the four launches; other expert shapes (MoEMergedAdvanced's) are not matched."""
     from hello_amd import readconv_pack as rp
     spec = ns.build("hybrid_full")
     state = weights.synth_state(spec, seed=1)
@@ -328,9 +328,8 @@ def test_arithmetic_modes_lower_to_flags_and_split_weight_blocks():
         sizes[mode] = prog.weights.size - base.weights.size
         assert [o.kind for o in prog.ops] == [o.kind for o in base.ops]          # only the read convolver changes
     assert sizes["bf16x3"] == sizes["bf16x3+32"] == 7 * 12288 + 6 * 3072          # one split block serves both levels
-    allele = compiler.compile_model(spec, state, arithmetic="bf16x3+32+allele")
-    convs = [o for o in allele.ops if o.kind == compiler.OP_CONV1D]
-    assert len(convs) == 8 and all(o.flags & compiler.FLAG_BF16X3 and not o.flags & compiler.FLAG_WINOGRAD for o in convs)
+    with pytest.raises(ValueError, match="arithmetic"):      # the layer-by-layer split-operand allele stage was removed (ABI 2)
+        compiler.compile_model(spec, state, arithmetic="bf16x3+32+allele")
     # hi + lo reproduce a weight to 2^-17 of its magnitude
     w = np.float32([0.3337, -1.25e-3, 7.0, 1e-20])
     hi = rp.to_bf16_bits(w)

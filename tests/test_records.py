@@ -260,6 +260,51 @@ def test_malformed_shards_are_refused(tmp_path):
             shards.PackedShard(arrays)
     with pytest.raises(ValueError, match=r"site 5, chr\d:\d+"):             # the site is named
         shards.PackedShard(cases["does not cover the feature window"])
+    # a file that says has_second = 0 but carries arrays of a second technology used to pass validation (only the
+    # technologies the flag names were checked) while has_reads(1) still said yes to a hybrid model -- unvalidated offsets on the GPU
+    bogus = broken(has_second=np.array(0), read_off1=np.array([0, 10 ** 9, 2 * 10 ** 9], np.int64))
+    with pytest.raises(ValueError, match="has_second is 0 but the file carries arrays of a second technology"):
+        shards.PackedShard(bogus)
+    single = shards.PackedShard(shards._payload(random_sites(rng, 5)))
+    assert single.has_reads(0) and not single.has_reads(1) and single.n_reads(1) == 0
+    with pytest.raises(ValueError, match=r"arrays of technology 1 are missing \(cigars"):
+        shards.PackedShard({k: v for k, v in good.items() if k != "cigars1"})
+
+    # the header of a .hshard file is the file's own claim -- negative offsets / dimensions, foreign dtypes and
+    # truncated arrays are refused by name, in the whole-file reader and in the count-arrays-only reader alike
+    import json as _json
+    path = shards.write_shard(str(tmp_path / "h.hshard"), sites)
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw[8:16], np.uint64)[0])
+    header = _json.loads(raw[16:16 + n])
+
+    def rewritten(name, **patch):
+        h = {k: list(v) for k, v in header.items()}
+        for k, (field, value) in patch.items():
+            h[k][field] = value
+        head = _json.dumps(h).encode("ascii")           # array offsets count from the end of the header: its length is free
+        out = str(tmp_path / name)
+        open(out, "wb").write(raw[:8] + np.uint64(len(head)).tobytes() + head + raw[16 + n:])
+        return out
+    attacks = {
+        "negative offset or dimension": rewritten("neg_at.hshard", start=(2, -8)),
+        "negative offset or dimension.": rewritten("neg_dim.hshard", reads_per_allele0=(1, [-3])),
+        "integer or float arrays only": rewritten("obj.hshard", start=(0, "|O")),
+        "runs past the end of the file": rewritten("long.hshard", reads_per_allele0=(1, [10 ** 9])),
+    }
+    for message, bad_path in attacks.items():
+        with pytest.raises(ValueError, match=message.rstrip(".")):
+            shards.read_flat(bad_path)
+        if "start" not in message and bad_path.endswith(("neg_dim.hshard", "long.hshard")):
+            with pytest.raises(ValueError, match=message.rstrip(".")):
+                shards.read_flat_arrays(bad_path, ["reads_per_allele0"])
+    with pytest.raises(ValueError, match="negative offset"):
+        shards.read_flat_arrays(attacks["negative offset or dimension"], ["start"])
+    open(tmp_path / "cut.hshard", "wb").write(raw[:16 + n // 2])
+    for reader in (shards.read_flat, lambda p: shards.read_flat_arrays(p, ["start"])):
+        with pytest.raises(ValueError, match="header is cut short"):
+            reader(str(tmp_path / "cut.hshard"))
+    assert np.array_equal(shards.read_flat_arrays(path, ["start", "nothing"])["start"], good["start"])
 
 
 def test_run_keeps_a_bounded_number_of_shards_in_memory(tmp_path):

@@ -133,3 +133,47 @@ def test_bench_rank_pieces_cover_the_global_stream_exactly():
         reads = [sum(int(counts[k]["reads_per_site"][lo:hi].sum()) for k, lo, hi in bench.rank_pieces(counts, launches, r, world)[0])
                  for r in range(world)]
         assert max(reads) - min(reads) <= 2 * max(int(c["reads_per_site"].max()) for c in counts)     # balanced by reads
+
+
+def _report_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import json
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # what bench.py's timed_region hands over: this rank's identity and clocks (two ranks rehearsing on ONE card share its address)
+    mine = dict(rank=rank, local_rank=rank, host="box", pid=os.getpid(), device_index=0, pci_bus_id="0000:05:00.0", uuid="GPU-abc",
+                name="MI355X", sites=100 + rank, reads=3000 + 30 * rank, alleles=210, launches=4, timed_seconds=1.0 + 0.25 * rank,
+                pinned_input_bytes=900 * (3000 + 30 * rank), cpus_pinned=4, cpu_list="0-3")
+    got = shard.summarize_ranks(shard.collect_rank_reports(mine))
+    if rank == 0:
+        json.dump(got, open(out_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_reports_make_a_multi_rank_bench_line_auditable(tmp_path):
+    """after the timed region every rank's report travels with one all_gather_object; the summary names the
+    ranks seen, the DISTINCT devices they drove, the slowest rank and the balance of the read-balanced partition."""
+    import json
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "reports.json")
+    mp.spawn(_report_worker, args=(2, 29700 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    z = json.load(open(out))
+    assert z["ranks_seen"] == 2 and [r["rank"] for r in z["ranks"]] == [0, 1]
+    assert z["distinct_devices"] == 1                       # both ranks reported the same PCI address / UUID
+    assert z["slowest_rank"] == 1 and z["rank_seconds_min_max"] == [1.0, 1.25]
+    assert z["balance"] == round(3000 / 3030, 4)
+    for r in z["ranks"]:
+        assert {"rank", "device_index", "pci_bus_id", "uuid", "sites", "reads", "timed_seconds", "launches", "pinned_input_bytes",
+                "cpus_pinned"} <= set(r)
+    # eight ranks on eight cards of one host, one of them idle (an empty range): distinct by address, balance over the busy ones
+    eight = [dict(rank=r, host="node", device_index=r, pci_bus_id=f"0000:{r:02x}:00.0", uuid=None, reads=0 if r == 7 else 1000 + r,
+                  timed_seconds=2.0 - 0.1 * r) for r in range(8)]
+    s = shard.summarize_ranks(reversed(eight))
+    assert s["distinct_devices"] == 8 and s["slowest_rank"] == 0 and s["balance"] == round(1000 / 1006, 4)
+    # without a process group: the one report, as a list
+    assert shard.collect_rank_reports(dict(rank=0, reads=5)) == [dict(rank=0, reads=5)]
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.shard_cpu_ranges([0, 1, 2, 5, 7, 8]) == "0-2,5,7-8" and bench.shard_cpu_ranges([]) == ""
