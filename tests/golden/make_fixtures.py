@@ -342,6 +342,34 @@ def make_pickle_fixture():
           f"[{res['logits'].min():.3f},{res['logits'].max():.3f}]")
 
 
+def make_canonical_pickles():
+    """what users hold is a CANONICAL-size pickle (create_model_wrapper.py:7-10 torch.save's the whole
+    MoEMergedWrapperAdvanced of a shipped configuration); the mini pickles above cannot reach the fused kernels.  The
+    structure is what a pickle pins, so the parameters are zeroed (6 / 25 MB of zeros gzip to a few KB): tests load the
+    file without the reference's source, inject seeded weights and hold the result to the config-built fixtures."""
+    import gzip
+    import io
+    for cfg in ("single_tech", "hybrid_full"):
+        wrapper = reference_model(cfg, "wn")
+        with torch.no_grad():
+            for p_ in wrapper.parameters():
+                p_.zero_()
+            for b_ in wrapper.buffers():
+                b_.zero_()
+            # weight norm keeps the last computed weight as a plain tensor attribute beside weight_g / weight_v (half the file)
+            for m_ in wrapper.modules():
+                for k_, v_ in list(vars(m_).items()):
+                    if isinstance(v_, torch.Tensor):
+                        setattr(m_, k_, torch.zeros(v_.shape, dtype=v_.dtype))
+        buf = io.BytesIO()
+        torch.save(wrapper, buf)                          # the reference's own serialisation of its own module tree
+        path = os.path.join(HERE, f"canonical_{cfg}.wrapper.dnn.gz")
+        with open(path, "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as fh:
+            fh.write(buf.getvalue())
+        n_par = sum(p_.numel() for p_ in wrapper.parameters())
+        print(f"canonical_{cfg}: {n_par} parameters (zeroed), pickle {buf.tell() / 1e6:.1f} MB -> {os.path.getsize(path) / 1024:.0f} KB gzip")
+
+
 def make_compressor2_pickle_fixture():
     """A real reference pickle of a small hybrid MoEAttention that takes the ``compressor2`` branch of its forward
     (MixtureOfExpertsAdvanced.py:181-192: hybrid compressor on the summed read frames, xattn2 on its output, the
@@ -970,6 +998,10 @@ def main():
             return
     if not only or "mini_reference" in only:
         make_pickle_fixture()
+    if not only or "canonical" in only:
+        make_canonical_pickles()
+        if only == {"canonical"}:
+            return
     if not only or "mini_compressor2" in only:
         make_compressor2_pickle_fixture()
     if not only or "mini_merged" in only:

@@ -219,3 +219,33 @@ def test_the_ctypes_stub_of_integration_md_runs_as_written():
     want, _ = eng.forward_batch(batch)
     eng.close()
     assert names["logits"].shape == want.shape and np.array_equal(names["logits"], want)
+
+
+@pytest.mark.parametrize("cfg,fixture", [("single_tech", "single_tech_batched"), ("hybrid_full", "hybrid_full")])
+def test_canonical_size_reference_pickle_reaches_the_fused_kernels(cfg, fixture, tmp_path):
+    """a canonical-architecture pickle written by the reference's torch.save (parameters zeroed in the
+    committed file: the structure is what it pins) loads without the reference's source, and -- with the fixture's seeded weights
+    injected -- the engine built from the PICKLE's spec runs the fused read convolver / compressor / expert front and reproduces
+    what the reference returned for the configuration-built model: logits, meta and the wrapper's per-site 5-tuple."""
+    from hello_amd import compiler
+    from hello_amd.wrapper import ScoringNetwork
+    from tests.util import canonical_pickle
+    spec, zeroed = loader.load_spec(canonical_pickle(cfg, tmp_path))
+    _, state, batch, exp = load_fixture(fixture)
+    assert set(zeroed) == set(state)
+    net = ScoringNetwork(spec, state)
+    prog = net.engine.program
+    kinds = [o.kind for o in prog.ops]
+    assert prog.fused_read_convolver and prog.fused_compressor and compiler.OP_XATTN_FRONT in kinds and prog.arithmetic == "fp32"
+    logits, meta = net.engine.forward_batch(batch)
+    np.testing.assert_allclose(logits, exp["logits"], rtol=2e-5, atol=2e-4)
+    if "meta" in exp:
+        np.testing.assert_allclose(meta, exp["meta"], **PROB)
+    net.providePredictions = True
+    for s, (fd, seg) in enumerate(site_dicts(batch)):
+        if f"site{s}_mix" not in exp:
+            break
+        mix, e0, e1, e2, m = net(fd, seg)
+        np.testing.assert_allclose(np.array([float(v) for v in mix.values()]), exp[f"site{s}_mix"], **PROB)
+        np.testing.assert_allclose(m.numpy(), exp[f"site{s}_meta"], **PROB)
+    net.close()

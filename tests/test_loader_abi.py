@@ -42,6 +42,33 @@ def test_reference_pickle_loads_without_reference_source():
     assert all(o.kind in compiler.OP_NAMES for o in prog.ops)
 
 
+@pytest.mark.parametrize("cfg", ["single_tech", "hybrid_full"])
+def test_canonical_size_reference_pickle_lowers_to_the_fused_program(cfg, tmp_path):
+    """what a user holds is a CANONICAL-architecture pickle (create_model_wrapper.py:7-10); the mini pickles
+    cannot reach the fused kernels.  canonical_<cfg>.wrapper.dnn.gz is such a pickle written by the reference's torch.save with
+    its parameters zeroed (the structure is what a pickle pins): loaded without the reference's source, its spec must lower --
+    with seeded weights injected -- to the very program the configuration-built spec lowers to, fused kernels included."""
+    from tests.util import canonical_pickle
+    assert "NNTools" not in sys.modules and "MixtureOfExpertsAdvanced" not in sys.modules
+    spec, state = loader.load_spec(canonical_pickle(cfg, tmp_path))
+    assert "NNTools" not in sys.modules
+    built = ns.build(cfg)
+    seeded = weights.synth_state(built, seed=3)
+    assert set(state) == set(seeded) and all(state[k].shape == seeded[k].shape for k in state)       # the reference's own keys
+    assert all(not np.any(v) for v in state.values())                                                 # zeroed, as committed
+    assert set(spec.nets) == set(built.nets) and spec.channels == built.channels and spec.window == built.window
+    got, want = compiler.compile_model(spec, seeded), compiler.compile_model(built, seeded)
+    fields = ("kind", "domain", "src0", "src1", "dst", "res", "cin", "cout", "k", "stride", "pad", "lin", "lout", "flags", "seg", "c1",
+              "a0", "a1", "w_off", "b_off")
+    assert [[getattr(o, f) for f in fields] for o in got.ops] == [[getattr(o, f) for f in fields] for o in want.ops]
+    assert got.buffers == want.buffers and np.array_equal(got.weights, want.weights)
+    assert (got.n_experts, got.has_meta, got.uses_ref) == (want.n_experts, want.has_meta, want.uses_ref)
+    kinds = [o.kind for o in got.ops]
+    assert got.fused_read_convolver and got.fused_compressor
+    assert kinds.count(compiler.OP_READCONV_FUSED) == (2 if cfg == "hybrid_full" else 1)
+    assert kinds.count(compiler.OP_XATTN_FRONT) == (3 if cfg == "hybrid_full" else 1) and compiler.OP_COMPRESSOR_FUSED in kinds
+
+
 def test_merged_family_pickle_loads_and_matches_reference():
     """The older MoEMergedAdvanced family (hybrid, additive, BatchNorm combiners + meta)."""
     spec, state = loader.load_spec(os.path.join(GOLDEN, "mini_merged.wrapper.dnn"))

@@ -99,3 +99,13 @@ def reference_segment_onehot(genome, start, stop, span=150):
     out = np.zeros((1, len(seg), 5), np.uint8)
     out[0, np.arange(len(seg)), ["ACGT".find(b) if b in "ACGT" else 4 for b in seg]] = 1
     return out
+
+
+def canonical_pickle(name, tmp_dir):
+    """tests/golden/canonical_<name>.wrapper.dnn.gz (a canonical-size reference pickle with zeroed parameters, written by the
+    reference's own torch.save in make_fixtures.py) unpacked into ``tmp_dir`` -> path of the .wrapper.dnn file."""
+    import gzip
+    out = os.path.join(str(tmp_dir), f"canonical_{name}.wrapper.dnn")
+    with gzip.open(os.path.join(GOLDEN, f"canonical_{name}.wrapper.dnn.gz"), "rb") as src, open(out, "wb") as dst:
+        dst.write(src.read())
+    return out
