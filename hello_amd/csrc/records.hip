@@ -529,17 +529,20 @@ int hello_site_records(const hello_site_table* t, const float* posteriors, int64
         size_t total = 0;
         for (int32_t k = 0; k < n_shards; ++k) {
             total += preamble.size() + 1;
-            for (auto* piece : per_shard[k]) total += piece->bytes.size() + 2;
+            for (auto* piece : per_shard[k]) total += piece->bytes.size();
+            total += 2;
         }
         rec->features.reserve(total);
         for (int32_t k = 0; k < n_shards; ++k) {
             rec->features += preamble;
+            // ONE MARK ... APPENDS group per shard around all of its records, whichever worker chunks they came from: the
+            // stream's bytes do not depend on the thread count or on where the chunk boundaries fell
+            if (!per_shard[k].empty()) rec->features.push_back('(');       // MARK
             for (auto* piece : per_shard[k]) {
-                rec->features.push_back('(');                  // MARK
                 rec->features += piece->bytes;
-                rec->features.push_back('e');                  // APPENDS
                 rec->n_records[k] += piece->records;
             }
+            if (!per_shard[k].empty()) rec->features.push_back('e');       // APPENDS
             rec->features.push_back('.');                      // STOP
             rec->features_off[k + 1] = (int64_t)rec->features.size();
         }

@@ -101,6 +101,32 @@ def test_record_stage_equals_the_python_rules(threads, with_meta):
             assert [list(d) for d in g["expertPredictions"]] == [list(d) for d in w["expertPredictions"]]       # pair order
 
 
+def test_features_stream_bytes_do_not_depend_on_the_worker_count():
+    """a shard's ``.features`` stream is ONE MARK ... APPENDS group whatever worker chunks its records came from, so
+    the file is byte-reproducible across --num_threads and hosts (the VCF texts always were)."""
+    rng = np.random.default_rng(5)
+    S = 1300
+    genome = "".join(rng.choice(list("ACGT"), size=S * 50 + 1000))
+    names = ["chr1", "chrX"]
+    aps, alleles, starts, stops, post, meta, chrom = random_table(rng, S, genome)
+    text, off = R.text_table(np.array(alleles))
+    table = R.SiteTable(aps, text, off, names, chrom, starts, stops, genomes={n: genome for n in names})
+    cuts = [0, 3, 3, 700, 1290, S]
+    streams = {}
+    for threads in (1, 2, 4, 8):
+        with R.site_records(table, post, meta, shard_site_off=cuts, threads=threads) as rec:
+            streams[threads] = (bytes(rec.features), rec.features_off.copy(), bytes(rec.shard_vcf), bytes(rec.mean_vcf), rec.n_records.copy())
+    for threads in (2, 4, 8):
+        for a, b in zip(streams[1], streams[threads]):
+            assert (a == b) if isinstance(a, bytes) else np.array_equal(a, b), threads
+    feats, foff = streams[1][0], streams[1][1]
+    for k in range(len(cuts) - 1):
+        stream = feats[foff[k]:foff[k + 1]]
+        ops = [op.name for op, _, _ in pickletools.genops(stream)]
+        assert ops.count("APPENDS") == (1 if cuts[k + 1] > cuts[k] and streams[1][4][k] else 0)
+        assert len(pickle.loads(stream)) == streams[1][4][k]
+
+
 def _single_site_table(chromosome, start, length, alleles, genome):
     text, off = R.text_table(np.array(alleles))
     return R.SiteTable([len(alleles)], text, off, [chromosome], [0], [start], [start + length], genomes={chromosome: genome})
