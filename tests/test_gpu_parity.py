@@ -613,7 +613,7 @@ def test_stress_against_oracle(label, cfg, kw, gain):
     spec = ns.build(cfg)
     state = weights.synth_state(spec, seed=77, gain=gain)
     hybrid = "hybrid_coverage" in kw
-    batch = _with_extremes(synth.make_sites(24, seed=int(1000 * gain) + len(cfg), **kw), 4000 + int(10 * gain), hybrid,
+    batch = _with_extremes(synth.make_sites(16, seed=int(1000 * gain) + len(cfg), **kw), 4000 + int(10 * gain), hybrid,
                            kw.get("channels", 6))
     eng = Engine(spec, state, device=0)
     logits, meta, post = eng.forward_batch(batch, posteriors=True)
@@ -677,7 +677,7 @@ def test_bf16x3_mode_frames_and_posteriors(cfg, kw, mode):
     spec = ns.build(cfg)
     state = weights.synth_state(spec, seed=21)
     hybrid = "hybrid_coverage" in kw
-    batch = _with_extremes(synth.make_sites(64, seed=5 + len(cfg), **kw), 77, hybrid, kw.get("channels", 6))
+    batch = _with_extremes(synth.make_sites(40, seed=5 + len(cfg), **kw), 77, hybrid, kw.get("channels", 6))
     exact, split = Engine(spec, state, device=0, arithmetic="fp32"), Engine(spec, state, device=0, arithmetic=mode)
     assert split.program.arithmetic == mode and exact.program.arithmetic == "fp32"
     fused = [[i for i, o in enumerate(e.program.ops) if o.kind == 8] for e in (exact, split)]

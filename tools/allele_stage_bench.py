@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--config", default="single_tech")
     ap.add_argument("--sites", type=int, default=8192)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--arithmetic", default="fp32")
     ap.add_argument("--save")
     ap.add_argument("--check")
     ap.add_argument("--label", default=os.environ.get("HELLO_LIB", "in-tree library"))
@@ -28,7 +29,7 @@ def main():
     from hello_amd import netspec as ns, synth, weights
     from hello_amd.engine import Engine
     spec = ns.build(args.config)
-    eng = Engine(spec, weights.synth_state(spec, seed=1), device=0, arithmetic="fp32")
+    eng = Engine(spec, weights.synth_state(spec, seed=1), device=0, arithmetic=args.arithmetic)
     kw = dict(coverage=30)
     if spec.hybrid_inputs:
         kw["hybrid_coverage"] = 15
@@ -56,7 +57,7 @@ def main():
     torch.cuda.synchronize(dev)
     rows, n = eng.op_times_ms()
     eng.set_profiling(0)
-    print(f"== {args.label}: {args.config}, {args.sites} sites ({b.reads0.shape[0]} reads, {b.n_alleles} alleles): {ms:.3f} ms per forward "
+    print(f"== {args.label} [{args.arithmetic}]: {args.config}, {args.sites} sites ({b.reads0.shape[0]} reads, {b.n_alleles} alleles): {ms:.3f} ms per forward "
           f"= {args.sites / ms:.1f} k sites/s device-resident")
     behind = 0.0
     for (kind, name, t), op in zip(rows, eng.program.ops):
