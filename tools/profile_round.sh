@@ -2,10 +2,10 @@
 # Profiles of one round on the GPU box: rocprofv3 kernel statistics of the driver's bench command, then PMC passes
 # (one counter group per pass: FETCH_SIZE and WRITE_SIZE do not fit together, MI355X_MICROARCH.md "rocprofv3 PMC slots";
 # --pmc only with --kernel-trace, never with system / runtime tracing).  Run from the repository root:
-#     bash tools/profile_round.sh r03
+#     bash tools/profile_round.sh r04
 # Writes raw output under gpurun_out/prof_<tag>/ and the summaries to copy into profiles/ under gpurun_out/profiles_<tag>/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG

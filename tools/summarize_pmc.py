@@ -83,7 +83,19 @@ def traffic(d):
     write = per_forward("WRITE_SIZE", "WRITE_SIZE")
     sq = load(d, "SQ_VALU_MFMA_BUSY_CYCLES")["readconv_kernel"]
     g = lambda c: sq[c]["sum"]                                                                                                # noqa: E731
+    # the WHOLE forward: every kernel of the pass (the engine's own and torch's copy kernels), per forward
+    ft, wt = load(d, "FETCH_SIZE"), load(d, "WRITE_SIZE")
+    forwards = ft["readconv_finalize_kernel"]["FETCH_SIZE"]["dispatches"]
+    by_kernel = {}
+    for k in sorted(set(ft) | set(wt)):
+        f_kb = ft.get(k, {}).get("FETCH_SIZE", {}).get("sum", 0.0) / forwards
+        w_kb = wt.get(k, {}).get("WRITE_SIZE", {}).get("sum", 0.0) / wt["readconv_finalize_kernel"]["WRITE_SIZE"]["dispatches"]
+        by_kernel[k] = round((2 * f_kb + w_kb) * 1024)
     return {
+        "bytes_per_forward": sum(by_kernel.values()),
+        "algorithmic_bytes_per_forward": 246002 * 900 + 4 * (17646 + 8193) + 4 * 17646 + 16 * 26400,
+        "algorithmic_bytes_per_forward_note": "8 192-site launch: 900 B per read + CSR counts in, 4 B per allele (logits) + 16 B per pair (posteriors) out",
+        "bytes_per_forward_by_kernel": dict(sorted(by_kernel.items(), key=lambda kv: -kv[1])),
         "kernel": "hello::readconv_kernel (bench.py headline loop, 8 192 sites / 246 k reads per forward; two launches per "
                   "forward: 7 680 workgroups of 8 groups, then 60 of one group)",
         "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,

@@ -115,6 +115,75 @@ __global__ __launch_bounds__(256, 3) void dma_kernel(const float* __restrict__ s
     out[(size_t)blockIdx.x * 256 + t] = s;
 }
 
+// pre-transformed activations (the producing layer wrote V), weights straight to registers, 64 tiles x 128 channels per workgroup:
+// a wave = 2 tile blocks x 32 channels (10 accumulators = 160 VGPRs, two workgroups per CU): per chunk 10 ds_read_b128 (V of both tile
+// blocks), 5 weight loads, 40 MFMAs, and only the 64 tiles' V chunk staged (2.5 loads + 2.5 ds_write_b128 per thread)
+template <bool BARRIER>
+__global__ __launch_bounds__(256, 2) void vdirect_kernel(const float* __restrict__ src, float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) float s_a[2][ROWS * LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lj = lane & 31, lh = lane >> 5;
+    for (int i = t; i < 2 * ROWS * LD; i += 256) (&s_a[0][0])[i] = 1.0f + 1e-3f * i;
+    __syncthreads();
+    f32x16 acc[2][5];
+    for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 5; ++c)
+            for (int e = 0; e < 16; ++e) acc[b][c][e] = 0.f;
+    const float* g = src + (size_t)blockIdx.x * 4096 + t * 4;
+    const float* gw = src + (size_t)wave * 65536 + lane * 4;
+    f32x4 r[3], wa[2][5];
+    for (int j = 0; j < 3; ++j) r[j] = *(const f32x4*)(g + j * 1024);
+    for (int c = 0; c < 5; ++c) wa[0][c] = *(const f32x4*)(gw + c * 256);
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 rn[3];
+            for (int j = 0; j < 3; ++j) rn[j] = *(const f32x4*)(g + ((it + h + 1) & 7) * 8192 + j * 1024);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) wa[h ^ 1][c] = *(const f32x4*)(gw + ((it + h + 1) & 31) * 1280 + c * 256);
+            f32x4 v[2][5];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) v[b][c] = *(const f32x4*)&s_a[h][(b * 32 + lj) * LD + lh * 4 + c * 8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) acc[b][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[h][c][e], v[b][c][e], acc[b][c], 0, 0, 0);
+            *(f32x4*)&s_a[h ^ 1][(t % (ROWS * LD / 4)) * 4] = r[0];
+            *(f32x4*)&s_a[h ^ 1][((t + 256) % (ROWS * LD / 4)) * 4] = r[1];
+            if (t < 128) *(f32x4*)&s_a[h ^ 1][((t + 512) % (ROWS * LD / 4)) * 4] = r[2];
+            for (int j = 0; j < 3; ++j) r[j] = rn[j];
+            if constexpr (BARRIER) __syncthreads();
+        }
+    }
+    float s = 0;
+    for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 5; ++c)
+            for (int e = 0; e < 16; ++e) s += acc[b][c][e];
+    out[(size_t)blockIdx.x * 256 + t] = s + r[0][0];
+}
+
+void run_vdirect(int cus, const float* src, float* out) {
+    printf("%-64s", "V from the producer + weights to registers, 64 x 128 per workgroup");
+    for (int wpc = 1; wpc <= 2; ++wpc) {
+        const int wgs = cus * wpc, iters = 2000;
+        const size_t dyn = wpc == 2 ? 40000 : 90000;
+        hipFuncSetAttribute((const void*)vdirect_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        hipLaunchKernelGGL((vdirect_kernel<true>), dim3(wgs), dim3(256), dyn, 0, src, out, 50);
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((vdirect_kernel<true>), dim3(wgs), dim3(256), dyn, 0, src, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double per = ms * 1e6 / ((double)iters * 40 * wpc);
+        printf("  %d wg/cu: %6.2f ns/MFMA (%4.1f %%)", wpc, per, 100.0 * 26.67 / per);
+    }
+    printf("\n");
+}
+
 template <int DMAS>
 void run_dma(const char* what, int cus, const float* src, float* out) {
     printf("%-64s", what);
@@ -173,6 +242,7 @@ int main() {
     run<10, 1, true, 6, 6>("+ reads + transform + barrier + 6 loads + 6 ds_write_b128 (the kernel's loop)", cus, src, out);
     run<10, 0, true, 6, 6>("the kernel's loop without the transform", cus, src, out);
     run<5, 1, true, 7, 2>("weights straight to registers: 5 reads, 7 loads, 2 writes", cus, src, out);
+    run_vdirect(cus, src, out);
     run_dma<5>("LDS-DMA staging: reads + transform + barrier + 5 buffer_load ... lds", cus, src, out);
     run_dma<4>("LDS-DMA staging with 4 pieces per wave", cus, src, out);
     return 0;
