@@ -325,8 +325,9 @@ def test_device_pointers_and_determinism(engines):
 
 
 def test_site_independence(engines):
-    """Scores of a site must not depend on what else is in the batch (sites are independent,
-    SURVEY.md 8e): score sites alone and inside a batch, bit for bit."""
+    """Scores of a site must not depend on what else is in the batch (sites are independent): sites scored alone
+    and inside a batch agree to rounding (1e-5: a launch's size selects the kernel family and cuts the per-allele sums at other
+    workgroup seams, so the last bits may differ; test_a_site_scored_alone_and_inside_a_large_launch... bounds that at 2e-6)."""
     spec = ns.build("single_tech")
     state = weights.synth_state(spec, seed=21)
     batch = synth.make_sites(12, seed=9, coverage=30)
