@@ -108,3 +108,24 @@ def test_full_size_batches_of_the_other_baseline_configs(label, cfg, kw):
     back = np.concatenate([logits[:, aoff[s]:aoff[s + 1]] for s in order], axis=1)
     np.testing.assert_allclose(lg_rev, back, rtol=1e-5, atol=1e-5)
     eng.close()
+
+
+def test_read_order_inside_an_allele_only_reassociates_its_sum():
+    """reduceSlots (MixtureOfExpertsAdvanced.py:23-34) SUMS an allele's reads: shuffling the reads inside every allele of a full
+    8 192-site launch (so that they fall into other read groups, workgroups and partial slots of the fused kernel) moves no logit
+    beyond float re-association, and shuffling whole alleles' read blocks with their counts permutes the logits exactly that way."""
+    from hello_amd.engine import Engine
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=35)
+    eng = Engine(spec, state, device=0)
+    batch = synth.make_sites(SITES_PER_BATCH, seed=811, coverage=30)
+    logits, _, post = eng.forward_batch(batch, posteriors=True)
+    rng = np.random.default_rng(4)
+    allele_of_read = np.repeat(np.arange(batch.n_alleles), batch.reads_per_allele0)
+    order = np.lexsort((rng.random(allele_of_read.shape[0]), allele_of_read))          # reads stay in their allele, in random order
+    assert not np.array_equal(order, np.arange(order.shape[0]))
+    shuffled = synth.SiteBatch(batch.reads0[order], batch.reads_per_allele0, batch.alleles_per_site, batch.ref_onehot)
+    lg2, _, post2 = eng.forward_batch(shuffled, posteriors=True)
+    scale = max(1.0, float(np.abs(logits).max()))
+    assert np.abs(lg2 - logits).max() <= 1e-5 * scale and np.abs(post2 - post).max() < 1e-5
+    eng.close()

@@ -728,3 +728,51 @@ def test_a_site_scored_alone_and_inside_a_large_launch_agree_to_rounding():
     print(f"one site per call vs inside a 2 048-site launch: max |d logit| / scale = {worst:.2e}")
     assert worst < 2e-6
     eng.close()
+
+
+@pytest.mark.parametrize("cfg", ["single_tech", "hybrid_full"])
+def test_sites_with_many_alleles(cfg):
+    """Sites of 9, 12 and 17 alleles between ordinary ones: the posteriors kernel's literal path (more than 8 alleles: 45 / 78 / 153
+    pairs per site), site sums over more alleles than a workgroup of the fused expert front holds (8 items: a 12-allele site spans
+    two of them, a 17-allele site three), the compressor's partly filled last workgroup.  Logits, meta and all four posterior rows
+    against the oracle in the reference's deployment form (one site per call)."""
+    from hello_amd.engine import Engine
+    from oracle import moe_oracle as mo
+    spec = ns.build(cfg)
+    state = weights.synth_state(spec, seed=31)
+    hybrid = spec.hybrid_inputs
+    rng = np.random.default_rng(17)
+    aps = np.array([2, 9, 1, 12, 3, 17, 2], np.int32)
+    A = int(aps.sum())
+    rpa0 = rng.integers(1, 5, size=A).astype(np.int32)
+    rpa1 = rng.integers(1, 4, size=A).astype(np.int32) if hybrid else None
+    pool = synth.make_sites(40, seed=5, coverage=30, **(dict(hybrid_coverage=15) if hybrid else {}))
+    reads0 = pool.reads0[:int(rpa0.sum())].copy()
+    reads1 = pool.reads1[:int(rpa1.sum())].copy() if hybrid else None
+    reads0[int(rpa0[:5].sum())] = 0                                      # an unsupported allele's dummy read inside the 9-allele site
+    batch = synth.SiteBatch(reads0, rpa0, aps, pool.ref_onehot[:aps.shape[0]].copy(), reads1, rpa1)
+    eng = Engine(spec, state, device=0)
+    logits, meta, post = eng.forward_batch(batch, posteriors=True)
+    want, want_meta = mo.forward_batch(mo.Oracle(spec, state, backend="torch"), batch, chunk_sites=1)
+    np.testing.assert_allclose(logits, want, **LOGIT_TOL)
+    if want_meta is not None:
+        assert np.abs(meta - want_meta).max() < PROB_ATOL
+    aoff = np.concatenate([[0], np.cumsum(aps)])
+    col = 0
+    for s in range(aps.shape[0]):
+        probs = [mo.sigmoid(want[e, aoff[s]:aoff[s + 1]]) for e in range(want.shape[0])]
+        if len(probs) == 1:
+            probs += [np.zeros_like(probs[0])] * 2
+        m = want_meta[s] if want_meta is not None else np.array([1, 0, 0], np.float32)
+        rows = mo.posteriors(probs, m)
+        n = rows[0].shape[0]
+        assert n == aps[s] * (aps[s] + 1) // 2
+        for r in range(4):
+            assert np.abs(post[r, col:col + n] - rows[r]).max() < PROB_ATOL, (s, r)
+        col += n
+    assert col == post.shape[1] == 45 + 78 + 153 + 3 + 1 + 6 + 3
+    # the same sites one per call through the small-launch kernels
+    for s in (1, 3, 5):
+        one, _, p1 = eng.forward_batch(batch.site_slice(s, s + 1), posteriors=True)
+        np.testing.assert_allclose(one, want[:, aoff[s]:aoff[s + 1]], **LOGIT_TOL)
+    eng.close()

@@ -222,7 +222,7 @@ def test_the_ctypes_stub_of_integration_md_runs_as_written():
 
 
 @pytest.mark.parametrize("cfg,fixture", [("single_tech", "single_tech_batched"), ("hybrid_full", "hybrid_full")])
-def test_canonical_size_reference_pickle_reaches_the_fused_kernels(cfg, fixture, tmp_path):
+def test_canonical_size_reference_pickle_reaches_the_fused_kernels(cfg, fixture, tmp_path, suite_arithmetic):
     """a canonical-architecture pickle written by the reference's torch.save (parameters zeroed in the
     committed file: the structure is what it pins) loads without the reference's source, and -- with the fixture's seeded weights
     injected -- the engine built from the PICKLE's spec runs the fused read convolver / compressor / expert front and reproduces
@@ -236,7 +236,7 @@ def test_canonical_size_reference_pickle_reaches_the_fused_kernels(cfg, fixture,
     net = ScoringNetwork(spec, state)
     prog = net.engine.program
     kinds = [o.kind for o in prog.ops]
-    assert prog.fused_read_convolver and prog.fused_compressor and compiler.OP_XATTN_FRONT in kinds and prog.arithmetic == "fp32"
+    assert prog.fused_read_convolver and prog.fused_compressor and compiler.OP_XATTN_FRONT in kinds and prog.arithmetic == suite_arithmetic
     logits, meta = net.engine.forward_batch(batch)
     np.testing.assert_allclose(logits, exp["logits"], rtol=2e-5, atol=2e-4)
     if "meta" in exp:
