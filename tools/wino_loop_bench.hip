@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 3) void dma_kernel(const float* __restrict__ s
 // pre-transformed activations (the producing layer wrote V), weights straight to registers, 64 tiles x 128 channels per workgroup:
 // a wave = 2 tile blocks x 32 channels (10 accumulators = 160 VGPRs, two workgroups per CU): per chunk 10 ds_read_b128 (V of both tile
 // blocks), 5 weight loads, 40 MFMAs, and only the 64 tiles' V chunk staged (2.5 loads + 2.5 ds_write_b128 per thread)
-template <bool BARRIER>
+template <bool BARRIER, bool TRANSFORM = false>
 __global__ __launch_bounds__(256, 2) void vdirect_kernel(const float* __restrict__ src, float* out, int iters) {
     __shared__ __attribute__((aligned(16))) float s_a[2][ROWS * LD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lj = lane & 31, lh = lane >> 5;
@@ -145,6 +145,18 @@ __global__ __launch_bounds__(256, 2) void vdirect_kernel(const float* __restrict
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int c = 0; c < 5; ++c) v[b][c] = *(const f32x4*)&s_a[h][(b * 32 + lj) * LD + lh * 4 + c * 8];
+            if constexpr (TRANSFORM) {                    // natural rows staged: the F(3,3) input transform stays in the loop
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const f32x4 d0 = v[b][0], d1 = v[b][1], d2 = v[b][2], d3 = v[b][3], d4 = v[b][4];
+                    const f32x4 s31 = d3 - d1;
+                    v[b][0] = 2.f * (d0 - d2) + s31;
+                    v[b][1] = s31 - (d1 + d2);
+                    v[b][2] = 3.f * (d1 - d2) + s31;
+                    v[b][3] = s31;
+                    v[b][4] = (d4 - d2) - 2.f * s31;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -165,17 +177,18 @@ __global__ __launch_bounds__(256, 2) void vdirect_kernel(const float* __restrict
     out[(size_t)blockIdx.x * 256 + t] = s + r[0][0];
 }
 
+template <bool TRANSFORM>
 void run_vdirect(int cus, const float* src, float* out) {
-    printf("%-64s", "V from the producer + weights to registers, 64 x 128 per workgroup");
+    printf("%-64s", TRANSFORM ? "natural rows + weights to registers, 64 x 128 per workgroup" : "V from the producer + weights to registers, 64 x 128 per workgroup");
     for (int wpc = 1; wpc <= 2; ++wpc) {
         const int wgs = cus * wpc, iters = 2000;
         const size_t dyn = wpc == 2 ? 40000 : 90000;
-        hipFuncSetAttribute((const void*)vdirect_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-        hipLaunchKernelGGL((vdirect_kernel<true>), dim3(wgs), dim3(256), dyn, 0, src, out, 50);
+        hipFuncSetAttribute((const void*)vdirect_kernel<true, TRANSFORM>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        hipLaunchKernelGGL((vdirect_kernel<true, TRANSFORM>), dim3(wgs), dim3(256), dyn, 0, src, out, 50);
         hipDeviceSynchronize();
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL((vdirect_kernel<true>), dim3(wgs), dim3(256), dyn, 0, src, out, iters);
+        hipLaunchKernelGGL((vdirect_kernel<true, TRANSFORM>), dim3(wgs), dim3(256), dyn, 0, src, out, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double per = ms * 1e6 / ((double)iters * 40 * wpc);
@@ -242,7 +255,8 @@ int main() {
     run<10, 1, true, 6, 6>("+ reads + transform + barrier + 6 loads + 6 ds_write_b128 (the kernel's loop)", cus, src, out);
     run<10, 0, true, 6, 6>("the kernel's loop without the transform", cus, src, out);
     run<5, 1, true, 7, 2>("weights straight to registers: 5 reads, 7 loads, 2 writes", cus, src, out);
-    run_vdirect(cus, src, out);
+    run_vdirect<false>(cus, src, out);
+    run_vdirect<true>(cus, src, out);
     run_dma<5>("LDS-DMA staging: reads + transform + barrier + 5 buffer_load ... lds", cus, src, out);
     run_dma<4>("LDS-DMA staging with 4 pieces per wave", cus, src, out);
     return 0;
