@@ -180,6 +180,68 @@ def rank_pieces(pool_counts, launches_total, rank, world):
     return pieces, sizes
 
 
+def launch_ranks(gpus, argv):
+    """``python bench.py --gpus N`` from a plain command line: start the N ranks as ONE CHILD process tree under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and wait for it.  Called before this process has
+    imported torch or touched a GPU; it never replaces itself (no exec), it only relays: the child inherits stdout, so rank
+    0's one JSON line is this command's one line, and the child's exit code is this command's.  The same pattern as
+    hello_amd/call.py's ``_launch_ranks`` (the reference's counterpart is its worker pool, call.py:111,215-221)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    rest, skip = [], False
+    for a in argv:                                   # the child's own --gpus is appended below
+        if skip:
+            skip = False
+        elif a == "--gpus":
+            skip = True
+        elif not a.startswith("--gpus="):
+            rest.append(a)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(gpus)] + rest
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), HELLO_BENCH_SELF_LAUNCHED="1")
+    print(f"bench: starting {gpus} ranks as a child: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def lib_sha256():
+    """sha256 of the HIP library this run loads (the file hello_amd.engine opens): ties `roofline.traffic` to the binary the
+    committed PMC passes profiled (profiles/hbm_traffic.json records the same hash, tools/profile_round.sh)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(os.path.join(ROOT, "hello_amd", "libhello_mi355x.so"), "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def committed_traffic(path, loaded_sha):
+    """-> (traffic, forward_traffic, provenance).  The HBM bytes of profiles/hbm_traffic.json are reported only when that
+    file says which library it profiled AND it is the library this run loaded; otherwise both are None and
+    ``provenance["traffic_stale"]`` is True (a changed kernel must not carry the previous build's bytes)."""
+    prov = {"lib_sha256": loaded_sha, "profiled_lib_sha256": None, "profiled_commit": None, "traffic_stale": None,
+            "source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950-corrected: "
+                      "2 x FETCH + WRITE; tools/profile_round.sh)"}
+    if not os.path.exists(path):
+        return None, None, prov
+    try:
+        tjson = json.load(open(path))
+    except Exception:
+        return None, None, prov
+    prov["profiled_lib_sha256"] = tjson.get("lib_sha256")
+    prov["profiled_commit"] = tjson.get("commit")
+    prov["traffic_stale"] = not (loaded_sha is not None and tjson.get("lib_sha256") == loaded_sha)
+    if prov["traffic_stale"]:
+        return None, None, prov
+    forward = None
+    if tjson.get("bytes_per_forward") is not None:
+        forward = {"bytes": tjson["bytes_per_forward"], "algorithmic_bytes": tjson.get("algorithmic_bytes_per_forward"),
+                   "by_kernel": tjson.get("bytes_per_forward_by_kernel"), "source": prov["source"]}
+    return tjson.get("bytes_per_launch"), forward, prov
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +253,7 @@ def main():
                          "20 steps stream 1.64 M sites in ~3.4 s)")
     ap.add_argument("--pool", type=int, default=3, help="distinct pinned synthetic batches the launches cycle through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of the CPU baseline's per-site leg (its batched leg takes half)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the device-resident, latency, small-batch and parity legs (headline only)")
     ap.add_argument("--fused", choices=["full", "trunk", "none"], default="full",
@@ -205,17 +268,25 @@ def main():
     ap.add_argument("--op-times", action="store_true", help="print per-op device times to stderr")
     args = ap.parse_args()
 
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        # a plain command line asking for N GPUs: the ranks are a child process tree, this process only waits for it
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    # CPU baseline first: it forks worker processes, which must happen before this process touches the GPU
-    # (and is skipped under a profiler, whose preloaded library has initialised the GPU already)
+    # CPU baseline first, on rank 0 at every N: it forks worker processes, which must happen before this process touches the
+    # GPU (and is skipped under a profiler, whose preloaded library has initialised the GPU already).  At N > 1 the other
+    # ranks are blocked in the rendezvous below while it runs (no engine, no feeder threads yet), so it has the host to
+    # itself exactly as at N = 1 and is over before any timed region starts.
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not profiled:
+    if rank == 0 and not args.no_cpu_baseline and not profiled:
         try:
-            cpu = cpu_baseline(args.seed)
+            cpu = cpu_baseline(args.seed, budget_s=args.cpu_budget)
+            if world > 1:
+                cpu["when"] = f"on rank 0 before the {world}-rank rendezvous (the other ranks wait idle in it)"
         except Exception as exc:           # the GPU measurement must not be lost to a host-side hiccup (fork limits ...)
             print(f"cpu baseline failed: {exc!r}", file=sys.stderr)
             cpu = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}
@@ -226,8 +297,7 @@ def main():
     from hello_amd.pipeline import HostPipeline, pin_batch
 
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        print(f"bench: --gpus {args.gpus} under a launcher of {world} rank(s): the launcher's world size is what runs", file=sys.stderr)
         args.gpus = world
     # HELLO_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
     backend = os.environ.get("HELLO_BENCH_BACKEND", "nccl")
@@ -386,33 +456,28 @@ def main():
     dom_exec = 2.0 * (dom_op.exec_macs_per_row or dom_op.macs_per_row) * rows_dom
     algorithmic = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     executed = dom_exec / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    # every pass over a pool batch must reproduce its first result bit for bit (checked outside the timed region)
-    first, drift = {}, 0
-    for (s, p), logits, meta, post in results:
-        if p not in first:
-            first[p] = (logits, post)
-        elif not (np.array_equal(logits, first[p][0]) and np.array_equal(post, first[p][1])):
-            drift += 1
-    if gathered is not None:
-        mine = np.concatenate([lg for _, lg, _, _ in results], axis=1)
-        drift += 0 if np.array_equal(gathered[:, :mine.shape[1]].numpy(), mine) else 1
-    finite = all(np.isfinite(lg).all() and np.isfinite(po).all() for _, lg, _, po in results[:len(piece_batches)])
-    del results
+    def check_run(r):
+        """Every pass over a pool batch must reproduce its first result bit for bit, and rank 0's own columns of the gathered
+        logits must be its own results (checked outside the timed region).  Drops the run's host results.  -> (drift, finite)."""
+        res, got = r.pop("results"), r.pop("gathered")
+        first, bad = {}, 0
+        for (s_, p), logits, meta, post in res:
+            if p not in first:
+                first[p] = (logits, post)
+            elif not (np.array_equal(logits, first[p][0]) and np.array_equal(post, first[p][1])):
+                bad += 1
+        if got is not None:
+            mine = np.concatenate([lg for _, lg, _, _ in res], axis=1) if res else np.zeros((eng.n_experts, 0), np.float32)
+            bad += 0 if np.array_equal(got[:, :mine.shape[1]].numpy(), mine) else 1
+        ok = all(np.isfinite(lg).all() and np.isfinite(po).all() for _, lg, _, po in res[:len(r["piece_batches"])])
+        return bad, ok
+    del results, gathered
+    drift, finite = check_run(run)
 
     # HBM bytes from the committed PMC passes of the same command (profiles/hbm_traffic.json, tools/profile_round.sh): the
-    # dominant kernel per launch (`traffic`, the contract's field) and EVERY kernel of the forward (`forward_traffic`)
-    traffic = forward_traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tjson = json.load(open(tpath))
-            traffic = tjson.get("bytes_per_launch")
-            if tjson.get("bytes_per_forward") is not None:
-                forward_traffic = {"bytes": tjson["bytes_per_forward"], "algorithmic_bytes": tjson.get("algorithmic_bytes_per_forward"),
-                                   "by_kernel": tjson.get("bytes_per_forward_by_kernel"), "source": "profiles/hbm_traffic.json "
-                                   "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950-corrected: 2 x FETCH + WRITE)"}
-        except Exception:
-            traffic = forward_traffic = None
+    # dominant kernel per launch (`traffic`, the contract's field) and EVERY kernel of the forward (`forward_traffic`) --
+    # reported only when that file was measured on THIS library (sha256 of the .so this process loaded), else null + stale
+    traffic, forward_traffic, traffic_prov = committed_traffic(os.path.join(ROOT, "profiles", "hbm_traffic.json"), lib_sha256())
     flops_launch = float(np.mean([site_flops(spec, pool[k].site_slice(lo, hi))[0] for k, lo, hi in pieces]))
     launch_s = dt / n_launches
     roofline = {
@@ -422,6 +487,7 @@ def main():
         # instead of 6 per 2), so the hardware fraction is priced on executed MFMA work and stays <= 1
         "achieved": round(executed, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "forward_traffic": forward_traffic,
+        "traffic_stale": traffic_prov["traffic_stale"], "traffic_provenance": traffic_prov,
         # the same launch priced on ALGORITHMIC work (direct-form 2 * MAC, SURVEY.md 8d: 10.152 MFLOP per read)
         "algorithmic_achieved": round(algorithmic, 3), "algorithmic_frac": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
         "formulas": {"frac": "2 * executed MAC per read * reads per launch / launch_ms / 157.3 TFLOP/s",
@@ -689,11 +755,15 @@ def main():
         if world > 1:
             # a second timed region of the same K steps: the N = 1 stream cut N ways (total work fixed)
             run2 = timed_region("strong", profile=False)
+            drift2, finite2 = check_run(run2)
+            drift += drift2
+            finite = finite and finite2
             rep2 = shard.summarize_ranks(shard.collect_rank_reports(run2["report"]))
             strong = {"value": round(run2["value"], 1), "unit": "sites/s", "scaling": "strong",
                       "ms_per_step": round(1e3 * run2["dt"] / max(args.steps, 1), 4), "sites_total": int(run2["sites_total"]),
                       "timed_region_s": round(run2["dt"], 3), "gather_ms": run2["gather_ms"], "gather_host_ms": run2["gather_host_ms"],
                       "slowest_rank": rep2["slowest_rank"], "balance": rep2["balance"], "distinct_devices": rep2["distinct_devices"],
+                      "repeat_passes_bit_identical": drift2 == 0, "outputs_finite": bool(finite2),
                       "ranks": rep2["ranks"]}
             del run2
         else:
@@ -701,9 +771,7 @@ def main():
                       "note": "N = 1: the strong and the weak workload are the same stream; one timed region"}
     cpu_reason = None
     if cpu is None:
-        cpu_reason = ("not run at N > 1: the CPU baseline is timed on rank 0 of the N = 1 run only (it forks one worker per host core, "
-                      "which would compete with the other ranks' feeder threads)" if world > 1 else
-                      "skipped: --no-cpu-baseline" if args.no_cpu_baseline else
+        cpu_reason = ("skipped: --no-cpu-baseline" if args.no_cpu_baseline else
                       "skipped: running under a profiler whose preloaded library has initialised the GPU (the baseline forks)" if profiled else
                       "not run on this rank")
 

@@ -196,17 +196,36 @@ def pin_rank(local_rank: int, local_world: int, device_index: Optional[int] = No
 # evidence of a multi-rank run: who ran where, on what, for how long (collected AFTER the timed region)
 # ------------------------------------------------------------------------------------------------
 def device_identity(device_index: int) -> dict:
-    """What distinguishes one GPU of the node from another, from the runtime's own properties: PCI address, UUID, name."""
-    out = {"device_index": int(device_index), "pci_bus_id": None, "uuid": None, "name": None}
+    """What distinguishes one GPU of the node from another, from the runtime's own properties: PCI address, UUID, name.
+    ``identity_source`` says which of them the runtime really provided ("pci_bus_id+uuid", "pci_bus_id", "uuid") or
+    "device_index" when neither could be read -- with ``identity_error`` naming why; nothing is swallowed silently."""
+    out = {"device_index": int(device_index), "pci_bus_id": None, "uuid": None, "name": None,
+           "identity_source": "device_index", "identity_error": None}
     try:
         import torch
         prop = torch.cuda.get_device_properties(device_index)
-        out["name"] = prop.name
+    except Exception as exc:
+        out["identity_error"] = f"get_device_properties: {exc!r}"
+        return out
+    out["name"] = getattr(prop, "name", None)
+    errors = []
+    try:
         out["pci_bus_id"] = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
-        uuid = getattr(prop, "uuid", None)
-        out["uuid"] = None if uuid is None else str(uuid)
-    except Exception:
-        pass
+    except Exception as exc:
+        errors.append(f"pci: {exc!r}")
+    try:
+        uuid = str(prop.uuid)
+        # a real UUID is 32 hex digits (with or without dashes / a "GPU-" prefix); anything else is not an identity
+        digits = uuid.lower().replace("gpu-", "").replace("-", "")
+        if len(digits) >= 16 and all(c in "0123456789abcdef" for c in digits) and set(digits) != {"0"}:
+            out["uuid"] = uuid
+        else:
+            errors.append(f"uuid: not a UUID: {uuid!r}")
+    except Exception as exc:
+        errors.append(f"uuid: {exc!r}")
+    src = [k for k in ("pci_bus_id", "uuid") if out[k]]
+    out["identity_source"] = "+".join(src) if src else "device_index"
+    out["identity_error"] = "; ".join(errors) or None
     return out
 
 
@@ -226,18 +245,24 @@ def collect_rank_reports(report: dict, group=None) -> List[dict]:
 
 
 def summarize_ranks(reports: Sequence[dict]) -> dict:
-    """The audit fields of a multi-rank bench line from the ranks' own reports: the list itself, how many DISTINCT
-    devices the ranks drove (by PCI address / UUID, falling back to (host, device index)), which rank was slowest, and how even
-    the read-balanced partition came out (min / max reads over the ranks that had any)."""
+    """The audit fields of a multi-rank bench line from the ranks' own reports: the list itself, how many DISTINCT devices the
+    ranks drove, which rank was slowest, and how even the read-balanced partition came out (min / max reads over the ranks that
+    had any).  A device is keyed on (host, PCI address, UUID) TOGETHER.  When any rank could name neither (its
+    ``identity_source`` is "device_index": ranks isolated by HIP_VISIBLE_DEVICES all see index 0, ranks sharing a card see
+    different ones), a count would prove nothing: ``distinct_devices`` is then None and ``identity_warning`` says why."""
     reports = sorted((dict(r) for r in reports), key=lambda r: r.get("rank", 0))
-
-    def key(r):
-        return (r.get("host"), r.get("uuid") or r.get("pci_bus_id") or r.get("device_index"))
+    for r in reports:
+        r.setdefault("identity_source", "+".join(k for k in ("pci_bus_id", "uuid") if r.get(k)) or "device_index")
+    unnamed = [int(r.get("rank", 0)) for r in reports if r["identity_source"] == "device_index"]
     seconds = [float(r.get("timed_seconds", 0.0)) for r in reports]
     reads = [int(r.get("reads", 0)) for r in reports]
     busy = [x for x in reads if x > 0]
     return {
-        "ranks": reports, "ranks_seen": len(reports), "distinct_devices": len({key(r) for r in reports}),
+        "ranks": reports, "ranks_seen": len(reports),
+        "distinct_devices": None if unnamed else len({(r.get("host"), r.get("pci_bus_id"), r.get("uuid")) for r in reports}),
+        "identity_sources": sorted({r["identity_source"] for r in reports}),
+        "identity_warning": (f"rank(s) {unnamed} could name their device only by its index: distinct devices cannot be counted"
+                             if unnamed else None),
         "slowest_rank": int(reports[int(np.argmax(seconds))].get("rank", 0)) if reports else None,
         "rank_seconds_min_max": [round(min(seconds), 6), round(max(seconds), 6)] if seconds else None,
         "balance": round(min(busy) / max(busy), 4) if busy else None,

@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "bench: a timing comparison (wide band), kept apart from the functional assertions")
+    config.addinivalue_line("markers", "slow: the full parity matrix behind the trimmed one (deselect with -m 'gpu and not slow')")
 
 
 @pytest.fixture(scope="session")

@@ -77,54 +77,120 @@ def test_pipeline_sink_keeps_logits_resident():
     eng.close()
 
 
-def test_bench_under_torchrun_is_auditable_and_equals_the_plain_run(tmp_path):
+def _bench_env():
+    import os
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HELLO_BENCH_BACKEND"):
+        env.pop(k, None)
+    return env
+
+
+def _json_lines(text):
+    return [ln for ln in text.splitlines() if ln.startswith("{")]
+
+
+SMALL = ["--steps", "3", "--warmup", "1", "--sites", "512", "--launches-per-step", "2", "--no-secondary"]
+
+
+def test_bench_under_torchrun_is_auditable():
     """bench.py as the driver launches it for N > 1 (python -m torch.distributed.run, one process per GPU), here with one rank on
-    this box's one GPU: a fresh child process (the launcher runs before anything touches the GPU), RCCL communicator up, the
-    product's partitioner + pipeline + the one gather on the measured path, ONE JSON line -- which carries the run's audit trail
-    (VERDICT r03 item 2): the ranks seen with their device's PCI address / UUID, sites, reads, own seconds, launches, pinned bytes
-    and CPUs; distinct_devices == 1; the event-timed gather; the strong-scaling value beside the weak one (--scaling both, the
-    default).  And the N = 1 point of a scaling curve agrees with the headline bench: the same workload, its value inside the
-    band of two plain runs taken before and after it on the same box (+- 5 %: clock drift between processes)."""
+    this box's one GPU and a small workload: a fresh child process (the launcher runs before anything touches the GPU), RCCL
+    communicator up, the product's partitioner + pipeline + the one gather on the measured path, ONE JSON line -- which carries the
+    run's audit trail: the ranks seen with their device's PCI address / UUID and the identity source, sites, reads, own seconds,
+    launches, pinned bytes and CPUs; distinct_devices == 1; the event-timed gather; the strong-scaling entry (--scaling both, the
+    default); the sha256 of the library it loaded.  The same workload run plainly scores the same number of sites."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    common = ["--gpus", "1", "--steps", "10", "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]
-    def run_plain():
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, cwd=root, env=env, capture_output=True,
-                             text=True, timeout=900)
-        assert out.returncode == 0, out.stderr[-2000:]
-        return out
-    plain = run_plain()
+    env = _bench_env()
+    common = ["--gpus", "1"] + SMALL + ["--no-cpu-baseline"]
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
     under = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                             "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py")] + common,
-                           cwd=root, env=env, capture_output=True, text=True, timeout=900)
+                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert under.returncode == 0, under.stderr[-2000:]
-    plain2 = run_plain()             # the card's clocks drift by a few per cent between processes: the launcher's run sits between two plain ones
-    lines = [ln for ln in under.stdout.splitlines() if ln.startswith("{")]
+    lines = _json_lines(under.stdout)
     assert len(lines) == 1, under.stdout[-2000:]
-    a = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])
-    b = json.loads(lines[0])
-    assert a["scaling"] == "weak" and b["scaling"] == "weak" and b["n_gpus"] == 1 and b["steps"] == 10
-    assert a["config"]["sites_total"] == b["config"]["sites_total"] == 10 * 10 * 8192 and b["config"]["repeat_passes_bit_identical"]
+    a, b = json.loads(_json_lines(plain.stdout)[-1]), json.loads(lines[0])
+    assert a["scaling"] == "weak" and b["scaling"] == "weak" and b["n_gpus"] == 1 and b["steps"] == 3
+    assert a["config"]["sites_total"] == b["config"]["sites_total"] == 3 * 2 * 512 and b["config"]["repeat_passes_bit_identical"]
     assert b["value"] > 0 and 0 < b["roofline"]["frac"] <= 1.0 and b["roofline"]["kernel"] == "readconv_kernel"
-    a2 = json.loads([ln for ln in plain2.stdout.splitlines() if ln.startswith("{")][-1])
-    lo, hi = min(a["value"], a2["value"]), max(a["value"], a2["value"])
-    # (steady card: the three agree within 0.3 %; right after the suite's other tests single runs have read 3 - 4 % apart)
-    assert 0.95 * lo <= b["value"] <= 1.05 * hi, (a["value"], b["value"], a2["value"])
     # the headline's arithmetic comes from the engine's own record
     assert a["dtype"] == b["dtype"] == "f32" and a["roofline"]["arithmetic"] == b["config"]["arithmetic"] == "fp32"
     # audit trail
     assert b["backend"] == "nccl" and b["ranks_seen"] == 1 and b["distinct_devices"] == 1 and b["slowest_rank"] == 0 and b["balance"] == 1.0
     (r,) = b["ranks"]
-    assert r["rank"] == 0 and r["device_index"] == 0 and r["pci_bus_id"] and r["sites"] == 10 * 10 * 8192 and r["launches"] == 100
+    assert r["rank"] == 0 and r["device_index"] == 0 and r["pci_bus_id"] and r["sites"] == 3 * 2 * 512 and r["launches"] == 6
+    assert "pci_bus_id" in r["identity_source"] and b["identity_warning"] is None
     assert r["reads"] > 25 * r["sites"] and r["pinned_input_bytes"] > 0 and r["pinned_input_bytes"] % 900 == 0 and r["cpus_pinned"] >= 1
     assert 0 < r["timed_seconds"] <= b["config"]["timed_region_s"] + 1e-3 and b["gather_ms"] is not None and b["gather_ms"] >= 0
     assert b["strong_scaling"]["value"] == b["value"] and "N = 1" in b["strong_scaling"]["note"]
     assert a["backend"] is None and a["ranks_seen"] == 1 and a["distinct_devices"] == 1 and a["gather_ms"] is None
-    # the CPU baseline was switched off here: null with its reason (at N > 1 it carries the "N = 1 only" reason)
+    # the CPU baseline was switched off here: null with its reason
     assert a["cpu_baseline"] is None and "--no-cpu-baseline" in a["cpu_baseline_reason"] and b["cpu_baseline"] is None
+    # roofline.traffic is tied to the binary: the hash of the library this run loaded is on the line, and bytes appear only when
+    # profiles/hbm_traffic.json was measured on it
+    prov = b["roofline"]["traffic_provenance"]
+    assert len(prov["lib_sha256"]) == 64 and (b["roofline"]["traffic"] is None) == bool(b["roofline"]["traffic_stale"] in (True, None))
+
+
+def test_bench_gpus_2_from_a_plain_shell_starts_its_own_ranks():
+    """`python bench.py --gpus 2` typed into a plain shell (no launcher, no RANK in the environment) starts its two
+    ranks itself as a child torch.distributed.run, and prints rank 0's ONE JSON line -- here with HELLO_BENCH_BACKEND=gloo so that
+    both ranks can share this box's one GPU.  The line carries what the contract asks of every line, at N > 1 too: `roofline` and
+    `cpu_baseline` (timed on rank 0 before the rendezvous), plus the audit of both ranks and the strong-scaling second region
+    (exercised here at world 2, with its own repeat / gather checks)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(_bench_env(), HELLO_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-budget", "2"] + SMALL, cwd=root, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1, out.stdout[-2000:]
+    z = json.loads(lines[0])
+    assert z["n_gpus"] == 2 and z["backend"] == "gloo" and z["ranks_seen"] == 2 and [r["rank"] for r in z["ranks"]] == [0, 1]
+    assert z["distinct_devices"] == 1                                        # the rehearsal's two ranks share the one card, and say so
+    assert z["scaling"] == "weak" and z["config"]["sites_total"] == 2 * 3 * 2 * 512 and z["config"]["repeat_passes_bit_identical"]
+    assert sum(r["sites"] for r in z["ranks"]) == z["config"]["sites_total"] and 0.9 < z["balance"] <= 1.0
+    assert z["roofline"]["kernel"] == "readconv_kernel" and 0 < z["roofline"]["frac"] <= 1.0 and z["roofline"]["launch_ms"] > 0
+    cpu = z["cpu_baseline"]
+    assert cpu is not None and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["kind"] == "port" and "rendezvous" in cpu["when"]
+    assert z["cpu_baseline_reason"] is None
+    st = z["strong_scaling"]
+    assert st["scaling"] == "strong" and st["sites_total"] == 3 * 2 * 512 and [r["rank"] for r in st["ranks"]] == [0, 1]
+    assert st["repeat_passes_bit_identical"] and st["outputs_finite"] and st["value"] > 0
+    assert sum(r["sites"] for r in st["ranks"]) == st["sites_total"]
+    assert "starting 2 ranks as a child" in out.stderr
+
+
+@pytest.mark.bench
+def test_bench_under_torchrun_equals_the_plain_run():
+    """The N = 1 point of a scaling curve agrees with the headline bench: the default workload under the launcher, its value inside
+    the band of two plain runs taken before and after it on the same box (+- 10 %: a timing comparison on a shared card, kept out of
+    the functional assertions above -- ADVICE r04)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _bench_env()
+    common = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-secondary", "--no-cpu-baseline"]
+
+    def run(prefix):
+        out = subprocess.run(prefix + [os.path.join(root, "bench.py")] + common, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(_json_lines(out.stdout)[-1])
+    a = run([sys.executable])
+    b = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+             "--master-port", str(29300 + os.getpid() % 300)])
+    a2 = run([sys.executable])
+    assert a["config"]["sites_total"] == b["config"]["sites_total"] == a2["config"]["sites_total"] == 6 * 10 * 8192
+    lo, hi = min(a["value"], a2["value"]), max(a["value"], a2["value"])
+    assert 0.90 * lo <= b["value"] <= 1.10 * hi, (a["value"], b["value"], a2["value"])

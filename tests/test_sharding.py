@@ -177,3 +177,79 @@ def test_rank_reports_make_a_multi_rank_bench_line_auditable(tmp_path):
     sys.path.insert(0, ROOT)
     import bench
     assert bench.shard_cpu_ranges([0, 1, 2, 5, 7, 8]) == "0-2,5,7-8" and bench.shard_cpu_ranges([]) == ""
+
+
+def test_distinct_devices_is_not_counted_from_device_indices():
+    """a rank that can name its card only by its index (no PCI address, no usable UUID) makes the count meaningless --
+    ranks isolated by HIP_VISIBLE_DEVICES all see index 0, two ranks on one card see different ones.  The summary then reports
+    None with a warning and says which identity source every rank used; PCI address and UUID are keyed TOGETHER."""
+    named = [dict(rank=r, host="n", device_index=0, pci_bus_id=f"0000:{r:02x}:00.0", uuid=f"GPU-{r:032x}", reads=10, timed_seconds=1.0,
+                  identity_source="pci_bus_id+uuid") for r in range(4)]
+    s = shard.summarize_ranks(named)
+    assert s["distinct_devices"] == 4 and s["identity_warning"] is None and s["identity_sources"] == ["pci_bus_id+uuid"]
+    # same PCI address, different UUIDs (two partitions of one card): distinct -- and the reverse
+    twins = [dict(named[0], rank=0), dict(named[0], rank=1, uuid="GPU-" + "f" * 32)]
+    assert shard.summarize_ranks(twins)["distinct_devices"] == 2
+    blind = [dict(rank=r, host="n", device_index=0, pci_bus_id=None, uuid=None, reads=10, timed_seconds=1.0) for r in range(2)]
+    s = shard.summarize_ranks(blind + [dict(named[3], rank=2)])
+    assert s["distinct_devices"] is None and "[0, 1]" in s["identity_warning"] and s["identity_sources"] == ["device_index", "pci_bus_id+uuid"]
+    assert [r["identity_source"] for r in s["ranks"]] == ["device_index", "device_index", "pci_bus_id+uuid"]
+    # device_identity itself: no GPU here, so the property query fails -- reported, not swallowed
+    ident = shard.device_identity(0)
+    assert ident["device_index"] == 0 and ident["identity_source"] in ("device_index", "pci_bus_id", "uuid", "pci_bus_id+uuid")
+    if ident["identity_source"] == "device_index":
+        assert ident["identity_error"]
+
+
+def test_roofline_traffic_is_tied_to_the_profiled_library(tmp_path):
+    """profiles/hbm_traffic.json names the sha256 of the library its PMC passes profiled; bench.py reports
+    `roofline.traffic` only for the library it loaded itself, and nulls it with traffic_stale otherwise."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = "ab" * 32
+    good = dict(lib_sha256=sha, commit="abc1234", bytes_per_launch=5.0e8, bytes_per_forward=4.0e9, algorithmic_bytes_per_forward=2.2e8,
+                bytes_per_forward_by_kernel={"readconv_kernel": 5.0e8})
+    path = str(tmp_path / "hbm_traffic.json")
+    json.dump(good, open(path, "w"))
+    traffic, forward, prov = bench.committed_traffic(path, sha)
+    assert traffic == 5.0e8 and forward["bytes"] == 4.0e9 and prov["traffic_stale"] is False and prov["profiled_commit"] == "abc1234"
+    # a different library (the kernel changed, the passes were not re-run): no bytes, flagged
+    traffic, forward, prov = bench.committed_traffic(path, "cd" * 32)
+    assert traffic is None and forward is None and prov["traffic_stale"] is True and prov["profiled_lib_sha256"] == sha
+    # a traffic file from before the hash existed is stale by definition
+    json.dump({k: v for k, v in good.items() if k != "lib_sha256"}, open(path, "w"))
+    assert bench.committed_traffic(path, sha)[2]["traffic_stale"] is True
+    # no file: nothing to report, nothing to call stale
+    assert bench.committed_traffic(str(tmp_path / "absent.json"), sha) == (None, None, dict(prov, lib_sha256=sha, profiled_lib_sha256=None,
+                                                                                          profiled_commit=None, traffic_stale=None))
+    # the hash bench.py takes is the hash of the file the engine opens
+    import hashlib
+    lib = os.path.join(ROOT, "hello_amd", "libhello_mi355x.so")
+    if os.path.exists(lib):
+        assert bench.lib_sha256() == hashlib.sha256(open(lib, "rb").read()).hexdigest()
+
+
+def test_bench_launcher_rewrites_only_the_gpus_flag(monkeypatch):
+    """`python bench.py --gpus N` from a plain shell starts its ranks as a CHILD torch.distributed.run (never an
+    exec, before anything touches a GPU) and returns the child's exit code."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    rc = bench.launch_ranks(8, ["--steps", "5", "--gpus", "8", "--warmup", "2", "--gpus=8", "--no-secondary"])
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "5", "--warmup", "2", "--no-secondary"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    # and main() takes that road only from a plain shell: under a launcher (RANK / WORLD_SIZE set) it never re-launches
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src

@@ -2,10 +2,12 @@
 # Profiles of one round on the GPU box: rocprofv3 kernel statistics of the driver's bench command, then PMC passes
 # (one counter group per pass: FETCH_SIZE and WRITE_SIZE do not fit together, MI355X_MICROARCH.md "rocprofv3 PMC slots";
 # --pmc only with --kernel-trace, never with system / runtime tracing).  Run from the repository root:
-#     bash tools/profile_round.sh r04
+#     HELLO_PROFILE_COMMIT=<git rev-parse --short HEAD, expanded where .git exists> bash tools/profile_round.sh r05
+# hbm_traffic.json records the sha256 of the library that was profiled (+ that commit): bench.py reports roofline.traffic only
+# for the same library and flags traffic_stale otherwise.
 # Writes raw output under gpurun_out/prof_<tag>/ and the summaries to copy into profiles/ under gpurun_out/profiles_<tag>/.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG

@@ -73,6 +73,16 @@ def table(d, stats_csv, forwards):
     return "\n".join(out)
 
 
+def provenance():
+    """Which binary the passes profiled: sha256 of hello_amd/libhello_mi355x.so as it lies beside this tool (the file the profiled
+    bench.py loaded) and the commit the caller names ($HELLO_PROFILE_COMMIT: the GPU box's copy of the tree has no .git).
+    bench.py reports `roofline.traffic` only when this hash equals the hash of the library it loaded."""
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hello_amd", "libhello_mi355x.so")
+    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+    return {"lib_sha256": sha, "commit": os.environ.get("HELLO_PROFILE_COMMIT") or None}
+
+
 def traffic(d):
     # readconv_kernel is launched twice per forward (bulk + remainder, readconv_plan): per-forward figures are the
     # kernel's SUM over the pass divided by the number of forwards (= dispatches of its finalize kernel)
@@ -92,6 +102,7 @@ def traffic(d):
         w_kb = wt.get(k, {}).get("WRITE_SIZE", {}).get("sum", 0.0) / wt["readconv_finalize_kernel"]["WRITE_SIZE"]["dispatches"]
         by_kernel[k] = round((2 * f_kb + w_kb) * 1024)
     return {
+        **provenance(),
         "bytes_per_forward": sum(by_kernel.values()),
         "algorithmic_bytes_per_forward": 246002 * 900 + 4 * (17646 + 8193) + 4 * 17646 + 16 * 26400,
         "algorithmic_bytes_per_forward_note": "8 192-site launch: 900 B per read + CSR counts in, 4 B per allele (logits) + 16 B per pair (posteriors) out",
