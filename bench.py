@@ -807,7 +807,8 @@ def main():
             # audit of the run: one entry per rank (device PCI address / UUID, sites, reads, own seconds, launches, pinned bytes,
             # CPUs), collected with one all_gather_object after the closing fence
             "backend": (backend if dist is not None else None), "ranks_seen": reports["ranks_seen"],
-            "distinct_devices": reports["distinct_devices"], "slowest_rank": reports["slowest_rank"],
+            "distinct_devices": reports["distinct_devices"], "identity_sources": reports["identity_sources"],
+            "identity_warning": reports["identity_warning"], "slowest_rank": reports["slowest_rank"],
             "rank_seconds_min_max": reports["rank_seconds_min_max"], "balance": reports["balance"],
             "gather_ms": run["gather_ms"], "gather_host_ms": run["gather_host_ms"], "ranks": reports["ranks"],
             "strong_scaling": strong,

@@ -277,10 +277,16 @@ def shard_read_totals(paths: Sequence[str], threads: int = 4) -> np.ndarray:
     from concurrent.futures import ThreadPoolExecutor
 
     def total(path):
+        # the second technology's counts weigh in only when the shard says it has one (has_second; a file that carries
+        # reads_per_allele1 with has_second = 0 is refused later by PackedShard.validate -- it must not skew the deal first)
         if path.endswith(".npz"):
             with np.load(path, allow_pickle=False) as z:
-                return sum(int(np.maximum(z[k], 1).sum()) for k in ("reads_per_allele0", "reads_per_allele1") if k in z.files)
-        return sum(int(np.maximum(a, 1).sum()) for k, a in shard_io.read_flat_arrays(path, ("reads_per_allele0", "reads_per_allele1")).items())
+                got = {k: z[k] for k in ("reads_per_allele0", "reads_per_allele1", "has_second") if k in z.files}
+        else:
+            got = shard_io.read_flat_arrays(path, ("reads_per_allele0", "reads_per_allele1", "has_second"))
+        second = "has_second" in got and int(np.asarray(got["has_second"]).reshape(-1)[0]) != 0
+        return sum(int(np.maximum(got[k], 1).sum()) for k in (("reads_per_allele0", "reads_per_allele1") if second else ("reads_per_allele0",))
+                   if k in got)
     with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
         return np.array(list(pool.map(total, paths)), np.int64)
 

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import contextlib
 import json
+import os
 import sys
 import types
 import zipfile
@@ -53,6 +54,37 @@ def _is_native(path: str) -> bool:
             return _NATIVE_KEY + ".npy" in zf.namelist()
     except zipfile.BadZipFile:
         return False
+
+
+_LFS_MAGIC = b"version https://git-lfs"
+
+
+def sniff(path: str) -> str:
+    """What kind of file ``path`` is, from its first bytes -- before any unpickler sees it:
+    "native" (the build's .npz), "torch-zip" (torch.save since 1.6), "torch-legacy" (torch.save before 1.6 or with
+    _use_new_zipfile_serialization=False: a bare pickle stream, which torch.load still reads), "gzip", or -- raising a
+    ValueError that names the cause and the fix -- a git-LFS pointer (what a fresh clone of the reference holds in models/:
+    its .gitattributes tracks *.dnn with LFS, models/README.md:3-9), an empty file, or something that is not a model."""
+    with open(path, "rb") as fh:
+        head = fh.read(64)
+    if head.startswith(_LFS_MAGIC):
+        fields = dict(line.split(" ", 1) for line in open(path, "r", errors="replace").read().splitlines() if " " in line)
+        raise ValueError(
+            f"{path} is a git-LFS pointer ({os.path.getsize(path)} bytes of text, oid {fields.get('oid', '?')}, the real model is "
+            f"{fields.get('size', '?')} bytes), not the model itself: the clone was made without git-lfs.  Fetch the model with "
+            f"`git lfs install && git lfs pull --include '{path.rsplit('/', 1)[-1]}'` in the reference checkout (or download it "
+            f"from the release the pointer belongs to) and pass that file to --network")
+    if not head:
+        raise ValueError(f"{path} is empty (0 bytes): an interrupted download or copy; fetch the model file again")
+    if head.startswith(b"PK\x03\x04") or head.startswith(b"PK\x05\x06"):
+        return "native" if _is_native(path) else "torch-zip"
+    if head.startswith(b"\x1f\x8b"):
+        return "gzip"
+    if head[:1] == b"\x80" and 2 <= head[1] <= 5:
+        return "torch-legacy"
+    raise ValueError(f"{path} is neither a torch.save file (zip archive or legacy pickle stream) nor a native hello_amd .npz: it starts "
+                     f"with {head[:16]!r}.  Expected the reference's *.wrapper.dnn (python/create_model_wrapper.py) or a file written "
+                     f"by hello_amd.loader.save_native")
 
 
 # --------------------------------------------------------------------------------------------
@@ -111,12 +143,16 @@ def _conv_node(prefix, idx, layers, pos):
         nxt = _cls(layers[pos + used])
         if nxt == "BatchNorm1d" and norm != "bn" and act == "none":
             if wn:
-                raise NotImplementedError("BatchNorm after a weight-normed conv")
+                raise NotImplementedError(f"BatchNorm1d at {prefix}.{idx + used} (state-dict keys {prefix}.{idx + used}.weight / "
+                                          f".running_mean ...) follows the weight-normed convolution {key}: folding both into one "
+                                          f"weight is not implemented (no shipped configuration does this)")
             norm, bn_key = "bn", f"{prefix}.{idx + used}"
             bn_eps = float(layers[pos + used].eps)
         elif nxt == "LayerNormModule" and norm not in ("bn", "ln") and act == "none":
             if wn:
-                raise NotImplementedError("LayerNorm after a weight-normed conv")
+                raise NotImplementedError(f"LayerNormModule at {prefix}.{idx + used} follows the weight-normed convolution {key} "
+                                          f"(state-dict keys {key}.weight_g / .weight_v): not implemented (the reference's "
+                                          f"layer-norm configurations use plain convolutions, *_layer_norm.py)")
             norm, bn_key = "ln", f"{prefix}.{idx + used}"
             bn_eps = float(layers[pos + used]._modules["normer"].eps)
         elif nxt == "Noop" and act == "none":
@@ -131,6 +167,9 @@ def _conv_node(prefix, idx, layers, pos):
         if act != "none":
             break
     (k,), (s,), (p,), (d,) = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+    if getattr(conv, "padding_mode", "zeros") != "zeros":
+        raise NotImplementedError(f"convolution {key} (state-dict key {key}.{'weight_v' if wn else 'weight'}) pads with "
+                                  f"{conv.padding_mode!r}: only zero padding is implemented")
     return ns.Conv(key, conv.in_channels, conv.out_channels, k, s, p, d, conv.groups, norm, bn_key, act, bn_eps), used
 
 
@@ -166,7 +205,8 @@ def _convert(network, prefix: str) -> List[ns.Node]:
         elif name == "AdaptiveAvgPool1d":
             # terminus: AdaptiveAvgPool1d(1), Flatten, norm|Noop|Dropout, Linear
             if [_cls(x) for x in layers[pos:pos + 2]] != ["AdaptiveAvgPool1d", "Flatten"] or pos + 3 >= len(layers):
-                raise NotImplementedError("unsupported pooling head")
+                raise NotImplementedError(f"pooling head at {prefix}.{pos}: expected AdaptiveAvgPool1d, Flatten, (norm | Noop | Dropout), "
+                                          f"Linear (NNTools.py:517-566), found {[_cls(x) for x in layers[pos:pos + 4]]}")
             mid, lin = layers[pos + 2], layers[pos + 3]
             wn = _cls(lin) == "WeightNormedLinear"
             linear = lin._modules["linear"] if wn else lin
@@ -175,7 +215,8 @@ def _convert(network, prefix: str) -> List[ns.Node]:
             if _cls(mid) == "BatchNorm1d":
                 norm, bn_key, bn_eps = "bn", f"{prefix}.{pos + 2}", float(mid.eps)
                 if wn:
-                    raise NotImplementedError("BatchNorm before a weight-normed linear")
+                    raise NotImplementedError(f"BatchNorm1d at {prefix}.{pos + 2} before the weight-normed Linear {key} (state-dict keys "
+                                              f"{key}.weight_g / .weight_v): not implemented")
             else:
                 norm, bn_key = ("wn" if wn else "none"), None
             nodes.append(ns.Head(key, linear.in_features, linear.out_features, norm, bn_key, bn_eps))
@@ -185,7 +226,9 @@ def _convert(network, prefix: str) -> List[ns.Node]:
             nxt = layers[pos + 1] if pos + 1 < len(layers) else None
             sel = _children(nets[1]._modules["network"])[0] if len(nets) == 2 else None
             if nxt is None or _cls(nxt) != "LinearCombination" or sel is None or _cls(sel) != "SelectArgument":
-                raise NotImplementedError("only the xattn_subtract Fork/LinearCombination front-end is supported")
+                raise NotImplementedError(f"Fork at {prefix}.{pos} with {len(nets)} branch(es) followed by "
+                                          f"{_cls(nxt) if nxt is not None else 'nothing'}: only the xattn_subtract front end -- Fork(net0, "
+                                          f"net1 = SelectArgument) + LinearCombination (architectures/xattn_subtract.py:14-42) -- is implemented")
             nodes.append(ns.Mix(tuple(float(c) for c in nxt.coefficients), int(sel.select)))
             pos += 2
         elif name == "SelectArgument":
@@ -200,7 +243,12 @@ def _convert(network, prefix: str) -> List[ns.Node]:
         elif name in ("Noop", "Dropout"):
             pos += 1
         else:
-            raise NotImplementedError(f"layer type {name!r} at {prefix}.{pos} is not supported")
+            keys = [k for k, _ in getattr(layer, "named_parameters", lambda: [])()][:3]
+            raise NotImplementedError(f"layer type {name!r} at {prefix}.{pos} is not supported"
+                                      + (f" (state-dict keys {', '.join(f'{prefix}.{pos}.{k}' for k in keys)} ...)" if keys else "")
+                                      + "; supported: Conv1d / WeightNormedConv1d (+ BatchNorm1d | LayerNormModule, ReLU | Softplus), "
+                                        "MaxPool1d, ResidualBlock, the pooling head, Fork + LinearCombination, SelectArgument, Transposer, "
+                                        "ConcatenateChannels, Noop, Dropout")
     return nodes
 
 
@@ -226,7 +274,7 @@ def _spec_from_merged(moe) -> ns.ModelSpec:
         sub = moe._modules.get(name)
         if sub is not None:
             if _cls(sub) != "Network":
-                raise NotImplementedError(f"{name} is a {_cls(sub)}, expected NNTools.Network")
+                raise NotImplementedError(f"moeMerged.{name} is a {_cls(sub)}, expected NNTools.Network (state-dict keys moeMerged.{name}.*)")
             nets[name] = _convert(sub, f"moeMerged.{name}")
     for name in ("alleleConvCombiner", "siteConvCombiner"):
         sub = moe._modules.get(name)
@@ -245,7 +293,9 @@ def spec_from_module(wrapper) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:
         state = {k: v.detach().cpu().numpy() for k, v in wrapper.state_dict().items()}
         return _spec_from_merged(moe), state
     if moe is None or _cls(moe) != "MoEAttention":
-        raise NotImplementedError(f"unsupported model class {_cls(moe) if moe is not None else None}")
+        raise NotImplementedError(f"the pickled wrapper's .moeMerged is {_cls(moe) if moe is not None else 'missing'}: expected "
+                                  f"MoEAttention or MoEMergedAdvanced (MixtureOfExpertsAdvanced.py:71,255); the pickle's top level is a "
+                                  f"{_cls(wrapper)}")
     nets = {}
     for name in _MOE_ATTENTION_NETS:
         sub = moe._modules.get(name)
@@ -258,18 +308,35 @@ def spec_from_module(wrapper) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:
     return spec, state
 
 
-def _load_reference_pickle(path: str):
+def _load_reference_pickle(path: str, kind: str = "torch-zip"):
+    import pickle
     import torch
     import warnings
     with _stand_in_modules(), warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        obj = torch.load(path, map_location="cpu", weights_only=False)
+        try:
+            obj = torch.load(path, map_location="cpu", weights_only=False)
+        except (pickle.UnpicklingError, AttributeError, ModuleNotFoundError, EOFError, RuntimeError) as exc:
+            raise ValueError(f"{path} ({kind} stream) could not be unpickled as a reference model: {exc!r}.  The loader supplies stand-ins "
+                             f"for the classes of NNTools and MixtureOfExpertsAdvanced[XferLearning] only; a pickle naming other modules, "
+                             f"or a truncated file, cannot be read") from exc
+    if not hasattr(obj, "_modules"):
+        raise ValueError(f"{path} holds a {type(obj).__name__}, not a module: the reference caller loads a whole "
+                         f"MoEMergedWrapperAdvanced (python/create_model_wrapper.py:7-10), not a bare state dict -- wrap the weights "
+                         f"with that script, or save them with hello_amd.loader.save_native(path, config, state)")
     return spec_from_module(obj)
 
 
 def load_spec(path: str) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:
-    """(ModelSpec, state dict) of a native file or a reference ``.wrapper.dnn`` pickle."""
-    return _load_native(path) if _is_native(path) else _load_reference_pickle(path)
+    """(ModelSpec, state dict) of a native file or a reference ``.wrapper.dnn`` pickle (zip form or the legacy stream of
+    torch < 1.6).  A file that is neither -- most often the git-LFS pointer a plain clone of the reference leaves in models/ --
+    is refused with a ValueError that says what it is and how to get the model (``sniff``)."""
+    kind = sniff(path)
+    if kind == "native":
+        return _load_native(path)
+    if kind == "gzip":
+        raise ValueError(f"{path} is gzip-compressed: decompress it first (gunzip -k) and pass the .wrapper.dnn / .npz inside")
+    return _load_reference_pickle(path, kind)
 
 
 def load(path: str, device: int = 0, **kw):

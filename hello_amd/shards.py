@@ -144,10 +144,12 @@ def _header_entry(path: str, name: str, entry, room: int):
     try:
         dtype, shape, at = entry
         dt = np.dtype(dtype)
-        shape = [int(d) for d in shape]
-        at = int(at)
+        shape = list(shape)
     except (TypeError, ValueError) as e:
         raise ValueError(f"malformed shard {path}: header entry of array {name}: {e}") from None
+    # JSON numbers that are not integers (1.9, true) would be truncated to a plausible shape by int(): refused instead
+    if not all(isinstance(d, int) and not isinstance(d, bool) for d in shape + [at]):
+        raise ValueError(f"malformed shard {path}: array {name} has a non-integer offset or dimension ({at!r}, {shape!r})")
     if dt.kind not in "iuf" or dt.itemsize not in (1, 2, 4, 8) or dt.hasobject:
         raise ValueError(f"malformed shard {path}: array {name} has dtype {dtype!r} (integer or float arrays only)")
     if at < 0 or any(d < 0 for d in shape):
@@ -158,7 +160,19 @@ def _header_entry(path: str, name: str, entry, room: int):
     nbytes = count * dt.itemsize
     if at + nbytes > room:
         raise ValueError(f"malformed shard {path}: array {name} runs past the end of the file")
+    if at % dt.itemsize:
+        # the view is handed by pointer to C and to the GPU: it must be aligned to its element (the writer aligns to 64)
+        raise ValueError(f"malformed shard {path}: array {name} starts at byte {at}, not a multiple of its {dt.itemsize}-byte element")
     return dt, tuple(shape), at, nbytes
+
+
+def _refuse_overlaps(path: str, spans) -> None:
+    """``spans`` = (name, offset, bytes) of every array of a header: two arrays sharing bytes is a file lying about itself."""
+    end, last = 0, None
+    for name, at, nbytes in sorted((s for s in spans if s[2] > 0), key=lambda s: s[1]):
+        if at < end:
+            raise ValueError(f"malformed shard {path}: arrays {last} and {name} overlap")
+        end, last = at + nbytes, name
 
 
 def _header(path: str, raw: bytes, n: int) -> dict:
@@ -183,10 +197,12 @@ def read_flat(path: str) -> dict:
         raise ValueError(f"malformed shard {path}: the header is cut short ({buf.shape[0] - 16} of {n} bytes)")
     header = _header(path, buf[16:16 + n].tobytes(), n)
     base = 16 + n
-    out = {}
+    out, spans = {}, []
     for name, entry in header.items():
         dt, shape, at, nbytes = _header_entry(path, name, entry, buf.shape[0] - base)
+        spans.append((name, at, nbytes))
         out[name] = buf[base + at:base + at + nbytes].view(dt).reshape(shape)
+    _refuse_overlaps(path, spans)
     return out
 
 
@@ -201,6 +217,7 @@ def read_flat_arrays(path: str, names: Sequence[str]) -> dict:
         if n > size - 16:
             raise ValueError(f"malformed shard {path}: the header is cut short ({size - 16} of {n} bytes)")
         header = _header(path, fh.read(n), n)
+        _refuse_overlaps(path, [(k,) + _header_entry(path, k, e, size - 16 - n)[2:] for k, e in header.items()])
         out = {}
         for name in names:
             if name in header:

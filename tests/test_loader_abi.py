@@ -420,3 +420,140 @@ def test_combiner_concats_are_folded_into_two_source_convolutions():
     assert all(len({o.src0, o.src1, o.dst}) == 3 for o in two) and np.array_equal(folded.weights, kept.weights)
     m250 = compiler.compile_model(ns.build("merged_hybrid_250"), weights.synth_state(ns.build("merged_hybrid_250"), seed=2))
     assert sum(o.kind == compiler.OP_CONCAT for o in m250.ops) == 1                 # its reader is a grouped convolution
+
+
+def test_c99_consumer_sees_the_structs_the_ctypes_mirrors_describe(tmp_path):
+    """VERDICT r04 item 6 (SURVEY 8b "C-ABI beneath both"): tests/abi/abi_check.c includes include/hello_mi355x.h as strict C99
+    (-Wall -Wextra -pedantic -Werror), links the library, prints sizeof / offsetof of every field of every struct that crosses the
+    boundary, and calls the entry points that need no GPU.  The table must equal the hand-written ctypes mirrors in
+    hello_amd/engine.py and hello_amd/records.py field by field (name, offset, size, order): a header edit that the Python
+    side does not follow -- or the reverse -- fails here instead of corrupting an engine call."""
+    import shutil
+    import subprocess
+    from hello_amd import engine, records
+    cc = shutil.which("cc") or shutil.which("gcc")
+    assert cc, "no C compiler on this box"
+    lib_dir = os.path.join(ROOT, "hello_amd")
+    exe = str(tmp_path / "abi_check")
+    build = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "abi", "abi_check.c"), "-o", exe, "-L", lib_dir, "-lhello_mi355x",
+                            f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    structs, fields, consts, calls = {}, {}, {}, {}
+    for line in run.stdout.splitlines():
+        kind, name, *rest = line.split(" ", 2)
+        if kind == "struct":
+            structs[name] = int(rest[0])
+        elif kind == "field":
+            off, size = rest[0].split()
+            fields.setdefault(name.split(".")[0], []).append((name.split(".")[1], int(off), int(size)))
+        elif kind == "const":
+            consts[name] = int(rest[0])
+        elif kind == "call":
+            calls[name] = rest[0]
+    mirrors = {"hello_op": engine.HelloOp, "hello_buffer": engine.HelloBuffer, "hello_model_desc": engine.HelloModelDesc,
+               "hello_site_table": records._SiteTable, "hello_features_format": records._FeaturesFormat, "hello_records_view": records._View}
+    assert set(structs) == set(mirrors) == set(fields)
+    for name, mirror in mirrors.items():
+        assert ctypes.sizeof(mirror) == structs[name], name
+        want = [(f, getattr(mirror, f).offset, getattr(mirror, f).size) for f, _ in mirror._fields_]
+        assert fields[name] == want, (name, fields[name], want)
+    # every field the header declares is in the C program's table (no field skipped when the header grows)
+    header = open(os.path.join(ROOT, "include", "hello_mi355x.h")).read()
+    for name in mirrors:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        declared = []
+        for stmt in body.split(";"):
+            stmt = stmt.strip()
+            if stmt:
+                first, *more = stmt.split(",")
+                declared += [re.findall(r"(\w+)\s*$", first)[0]] + [m.strip().lstrip("*") for m in more]
+        assert declared == [f for f, _, _ in fields[name]], (name, declared)
+    assert consts["HELLO_ABI_VERSION"] == engine.ABI_VERSION
+    assert (consts["HELLO_IN_DEVICE"], consts["HELLO_OUT_DEVICE"], consts["HELLO_LAYOUT_RCL"]) == (
+        engine.HELLO_IN_DEVICE, engine.HELLO_OUT_DEVICE, engine.HELLO_LAYOUT_RCL)
+    assert consts["HELLO_OP_READCONV_FUSED"] == 8 and consts["HELLO_OP_XATTN_FRONT"] == 11 and consts["HELLO_BUF_FIRST_SCRATCH"] == 3
+    assert calls["hello_abi_version"] == str(engine.ABI_VERSION)
+    assert calls["hello_engine_create(NULL)"].startswith("-1 engine_reset 1 message ") and "NULL" in calls["hello_engine_create(NULL)"]
+    assert calls["hello_engine_create(out=NULL)"].startswith("-1 message ")
+
+
+def test_loader_names_what_a_fresh_clone_of_the_reference_really_holds(tmp_path):
+    """VERDICT r04 item 7 (caller_calling.py:863, models/README.md:3-9): the one model file of a plain clone is a 133-byte git-LFS
+    pointer; the loader says so and how to fetch the model, instead of a bare UnpicklingError.  Same for an empty file, a gzip, a file
+    that is not a model, and a pickle of something that is not a module."""
+    import gzip
+    import glob
+    import pickle
+    pointer = tmp_path / "illumina.wrapper.dnn"
+    pointer.write_text("version https://git-lfs.github.com/spec/v1\noid sha256:" + "ab" * 32 + "\nsize 12341951\n")
+    with pytest.raises(ValueError, match=r"git-LFS pointer.*12341951 bytes.*git lfs pull") as err:
+        loader.load_spec(str(pointer))
+    assert "sha256:" + "ab" * 32 in str(err.value) and "illumina.wrapper.dnn" in str(err.value)
+    with pytest.raises(ValueError, match="git-LFS pointer"):
+        loader.load(str(pointer))                              # the drop-in entry fails before any engine exists
+    # the reference's own pointer file(s), where the reference tree is present (build container only, read-only)
+    for path in glob.glob("/root/reference/models/*.dnn"):
+        if os.path.getsize(path) < 1024:
+            with pytest.raises(ValueError, match="git-LFS pointer"):
+                loader.load_spec(path)
+    empty = tmp_path / "empty.dnn"
+    empty.write_bytes(b"")
+    with pytest.raises(ValueError, match="empty"):
+        loader.load_spec(str(empty))
+    junk = tmp_path / "junk.dnn"
+    junk.write_bytes(b"<!DOCTYPE html><html>404")
+    with pytest.raises(ValueError, match="neither a torch.save file"):
+        loader.load_spec(str(junk))
+    gz = tmp_path / "model.dnn.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(open(os.path.join(GOLDEN, "mini_reference.wrapper.dnn"), "rb").read())
+    with pytest.raises(ValueError, match="gzip-compressed"):
+        loader.load_spec(str(gz))
+    bare = tmp_path / "state_dict.dnn"
+    with open(bare, "wb") as fh:
+        pickle.dump({"moeMerged.x": 1}, fh, protocol=2)
+    with pytest.raises(ValueError, match="(not a module|could not be unpickled)"):
+        loader.load_spec(str(bare))
+    with pytest.raises(FileNotFoundError):
+        loader.load_spec(str(tmp_path / "absent.dnn"))
+    assert loader.sniff(os.path.join(GOLDEN, "mini_reference.wrapper.dnn")) == "torch-zip"
+
+
+def test_legacy_torch_save_stream_loads_like_the_zip_form(tmp_path):
+    """A 2021 model may be a pre-1.6 torch.save stream (a bare pickle, no zip): `mini_reference` re-saved with
+    _use_new_zipfile_serialization=False loads without the reference's source to the same architecture and weights."""
+    import torch
+    import warnings
+    src = os.path.join(GOLDEN, "mini_reference.wrapper.dnn")
+    legacy = str(tmp_path / "mini_reference_legacy.wrapper.dnn")
+    with loader._stand_in_modules(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.save(torch.load(src, map_location="cpu", weights_only=False), legacy, _use_new_zipfile_serialization=False)
+    assert loader.sniff(legacy) == "torch-legacy"
+    spec_a, state_a = loader.load_spec(src)
+    spec_b, state_b = loader.load_spec(legacy)
+    assert sorted(state_a) == sorted(state_b) and all(np.array_equal(state_a[k], state_b[k]) for k in state_a)
+    assert repr(spec_a.nets) == repr(spec_b.nets) and spec_a.channels == spec_b.channels
+    for name in ("NNTools", "MixtureOfExpertsAdvanced"):
+        assert name not in sys.modules                          # the stand-ins are gone again
+
+
+def test_unsupported_layers_are_named_with_their_state_dict_key():
+    """Every NotImplementedError of the loader says WHICH layer (path in the module tree = prefix of its state-dict keys)."""
+    import torch
+    with loader._stand_in_modules():
+        nn_tools = sys.modules["NNTools"]
+        net = nn_tools.Network()
+        net.network = torch.nn.Sequential(torch.nn.Conv1d(6, 8, 3), torch.nn.ReLU(), torch.nn.GRU(8, 8))
+        with pytest.raises(NotImplementedError, match=r"'GRU' at moeMerged\.read_convolver0\.network\.2.*weight_ih_l0"):
+            loader._convert(net, "moeMerged.read_convolver0")
+        net.network = torch.nn.Sequential(torch.nn.Conv1d(6, 8, 3, padding=1, padding_mode="circular"))
+        with pytest.raises(NotImplementedError, match=r"moeMerged\.x\.network\.0\.weight.*'circular'"):
+            loader._convert(net, "moeMerged.x")
+        net.network = torch.nn.Sequential(torch.nn.AdaptiveAvgPool1d(1), torch.nn.ReLU(), torch.nn.Linear(4, 1), torch.nn.ReLU())
+        with pytest.raises(NotImplementedError, match=r"pooling head at moeMerged\.x\.network\.0.*AdaptiveAvgPool1d"):
+            loader._convert(net, "moeMerged.x")

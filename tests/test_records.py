@@ -331,6 +331,29 @@ def test_malformed_shards_are_refused(tmp_path):
         with pytest.raises(ValueError, match="header is cut short"):
             reader(str(tmp_path / "cut.hshard"))
     assert np.array_equal(shards.read_flat_arrays(path, ["start", "nothing"])["start"], good["start"])
+    # JSON numbers that are not integers (int() would truncate 1.9 to a plausible 1, True to 1), offsets that are not
+    # aligned to the element (the view goes by pointer to C and the GPU), arrays that share bytes
+    more = {
+        "non-integer offset or dimension": rewritten("frac_dim.hshard", reads_per_allele0=(1, [1.9])),
+        "non-integer offset or dimension.": rewritten("bool_dim.hshard", reads_per_allele0=(1, [True])),
+        "non-integer offset or dimension..": rewritten("frac_at.hshard", start=(2, 64.0)),
+        "not a multiple of its 8-byte element": rewritten("odd_at.hshard", start=(2, header["start"][2] + 4)),
+        "overlap": rewritten("overlap.hshard", stop=(2, header["start"][2])),
+    }
+    for message, bad_path in more.items():
+        with pytest.raises(ValueError, match=message.rstrip(".")):
+            shards.read_flat(bad_path)
+    for bad in ("frac_dim.hshard", "bool_dim.hshard", "overlap.hshard"):
+        with pytest.raises(ValueError, match="non-integer|overlap"):
+            shards.read_flat_arrays(str(tmp_path / bad), ["reads_per_allele0"])
+    # the load balancer's read totals honour has_second: stray second-technology counts of a single-technology shard weigh nothing
+    from hello_amd import call as driver
+    flat = shards.read_flat(path)
+    assert int(np.asarray(flat["has_second"]).reshape(-1)[0]) == 1
+    both = int(np.maximum(flat["reads_per_allele0"], 1).sum() + np.maximum(flat["reads_per_allele1"], 1).sum())
+    first = int(np.maximum(flat["reads_per_allele0"], 1).sum())
+    stray = shards.write_flat(str(tmp_path / "stray.hshard"), dict({k: np.array(v) for k, v in flat.items()}, has_second=np.array(0)))
+    assert list(driver.shard_read_totals([path, stray], threads=1)) == [both, first]
 
 
 def test_run_keeps_a_bounded_number_of_shards_in_memory(tmp_path):

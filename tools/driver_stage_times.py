@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--threads", type=int, default=min(16, len(os.sched_getaffinity(0))))
     ap.add_argument("--config", default="single_tech")
     ap.add_argument("--arithmetic", default="fp32")
+    ap.add_argument("--no-record-alone", action="store_true", help="skip the record stage's stand-alone timing at the end")
+    ap.add_argument("--only-all", action="store_true", help="skip the quarter-of-the-shards run (the memory-flatness check)")
     args = ap.parse_args()
     logging.basicConfig(level=logging.WARNING)
     rng = np.random.default_rng(7)
@@ -98,7 +100,7 @@ def main():
         for shard_sites in [int(x) for x in args.shard_sites.split(",")]:
             payload, n_reads = template_payload(rng, shard_sites, args.coverage)
             n_files = max(4, args.sites // shard_sites)
-            for label, count in (("quarter", max(1, n_files // 4)), ("all", n_files)):
+            for label, count in ((("all", n_files),) if args.only_all else (("quarter", max(1, n_files // 4)), ("all", n_files))):
                 sdir, work = os.path.join(base, f"shards_{shard_sites}_{label}"), os.path.join(base, f"work_{shard_sites}_{label}")
                 os.makedirs(sdir)
                 write_shards(sdir, payload, count, 700 * shard_sites + 10_000)
@@ -124,6 +126,8 @@ def main():
                         print("      " + m)
                 shutil.rmtree(sdir)
                 shutil.rmtree(work)
+        if args.no_record_alone:
+            return
         # the record stage alone (host only): one launch of 8 192 sites
         payload, _ = template_payload(rng, 8192, args.coverage)
         shard = shards.PackedShard(dict(payload))
