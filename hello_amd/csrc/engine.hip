@@ -138,6 +138,9 @@ struct hello_engine {
     int debug_op = -1;               // op whose dst is snapshotted after it ran (-1: none)
     DevBuf d_debug;
     size_t debug_floats = 0;         // size of the last snapshot
+    int stamp_mode = 0;              // hello_engine_debug_stamps: bit 0 record, bit 1 one workgroup per CU
+    DevBuf d_stamps;
+    int32_t stamp_layout[5] = {0, 0, 0, 0, 0};   // workgroups, waves, groups recorded per workgroup, slots, bulk workgroups
 
     // device views into d_csr for the current batch
     int32_t *roff0 = nullptr, *roff1 = nullptr, *aoff = nullptr, *site_of_allele = nullptr;
@@ -374,6 +377,7 @@ void hello_engine_destroy(hello_engine* e) {
     e->d_feat_in.release();
     e->d_feat_out.release();
     e->d_debug.release();
+    e->d_stamps.release();
     if (e->d_weights) (void)hipFree(e->d_weights);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     if (e->ev_staged) (void)hipEventDestroy(e->ev_staged);
@@ -455,6 +459,33 @@ int hello_engine_debug_capture(hello_engine* e, int32_t op_index) try {
     return HELLO_OK;
 } catch (...) {
     return hello::exception_status("hello_engine_debug_capture");
+}
+
+int hello_engine_debug_stamps(hello_engine* e, int32_t mode) try {
+    if (!e) return fail(HELLO_ERR_ARG, "engine is NULL");
+    if (mode < 0 || mode > 3 || mode == 2) return fail(HELLO_ERR_ARG, "mode %d: 0 = off, 1 = record, 3 = record with one workgroup per CU", mode);
+    e->stamp_mode = mode;
+    e->stamp_layout[0] = 0;
+    return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_engine_debug_stamps");
+}
+
+int hello_engine_debug_read_stamps(hello_engine* e, uint64_t* out, int64_t capacity, int64_t* n_words, int32_t* layout) try {
+    if (!e || !n_words || !layout) return fail(HELLO_ERR_ARG, "NULL argument");
+    const int32_t* L = e->stamp_layout;
+    const int64_t n = (int64_t)L[0] * L[1] * L[2] * L[3];
+    *n_words = n;
+    for (int i = 0; i < 5; ++i) layout[i] = L[i];
+    if (!out) return HELLO_OK;
+    if (n == 0) return fail(HELLO_ERR_ARG, "no stamped forward has run since hello_engine_debug_stamps");
+    if (capacity < n) return fail(HELLO_ERR_ARG, "capacity %lld < %lld words", (long long)capacity, (long long)n);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->last_stream ? e->last_stream : e->own_stream));
+    HIP_TRY(hipMemcpy(out, e->d_stamps.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return HELLO_OK;
+} catch (...) {
+    return hello::exception_status("hello_engine_debug_read_stamps");
 }
 
 int hello_engine_debug_read(hello_engine* e, float* out, int64_t capacity, int64_t* n_floats) try {
@@ -890,9 +921,28 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                     const long long bulk_reads = plan.rest_wgs ? plan.bulk_wgs * plan.groups_per_wg * G : total;
                     a.groups_per_wg = plan.groups_per_wg;
                     a.n_reads = bulk_reads;
+                    if ((e->stamp_mode & 1) && !t1) {
+                        // diagnostic forward: the stamped instantiation of the kernel (refused by the launch for any schedule but
+                        // the default fp32 Winograd one from the bytes)
+                        if (wide || !a.reads) return fail(HELLO_ERR_ARG, "stamps: the canonical fused read convolver from the bytes only");
+                        const long long wgs = plan.rest_wgs ? plan.bulk_wgs + plan.rest_wgs : (long long)((total + (long long)G * plan.groups_per_wg - 1) / ((long long)G * plan.groups_per_wg));
+                        const int slots = hello::readconv_stamp_slots();
+                        const size_t bytes = (size_t)wgs * 4 * plan.groups_per_wg * slots * sizeof(uint64_t);
+                        if (bytes > e->d_stamps.cap) {
+                            HIP_TRY(hipStreamSynchronize(stream));
+                            if (e->d_stamps.ensure(bytes)) return fail(HELLO_ERR_HIP, "device allocation of %zu bytes failed", bytes);
+                        }
+                        HIP_TRY(hipMemsetAsync(e->d_stamps.p, 0, bytes, stream));
+                        a.stamps = (unsigned long long*)e->d_stamps.p;
+                        a.stamp_groups = plan.groups_per_wg;
+                        a.stamp_mode = e->stamp_mode;
+                        const int32_t lay[5] = {(int32_t)wgs, 4, plan.groups_per_wg, slots, (int32_t)(plan.rest_wgs ? plan.bulk_wgs : wgs)};
+                        for (int i = 0; i < 5; ++i) e->stamp_layout[i] = lay[i];
+                    }
                     HIP_TRY(wide ? hello::launch_readconv_wide(a, stream) : hello::launch_readconv_fused(a, stream));
                     if (plan.rest_wgs) {
                         hello::ReadConvArgs b = a;
+                        if (b.stamps) b.stamps += (size_t)plan.bulk_wgs * 4 * plan.groups_per_wg * hello::readconv_stamp_slots();
                         if (b.reads) b.reads += bulk_reads * d.window * o.cin;
                         else b.pooled += bulk_reads * (long long)o.lin * o.cin;
                         b.allele_of_read += bulk_reads;

@@ -90,7 +90,12 @@ struct ReadConvArgs {
     int bf16x3;                // arithmetic mode bf16x3 (`reads` + Winograd form, 150 bp, ReLU, no extra blocks): 1 = the 64-channel
                                // trunk on the bf16 matrix cores as 3-term splits, 2 = the 32-channel blocks too ("bf16x3+32");
                                // the split weights follow the fp32 blob
+    unsigned long long* stamps;   // diagnostic launch (hello_engine_debug_stamps) or NULL: per-wave s_memtime stamps,
+                                  // [workgroups][4 waves][stamp_groups][readconv_stamp_slots()] -- see readconv_kernel
+    int stamp_groups;          // groups per workgroup that record (>= groups_per_wg records all)
+    int stamp_mode;            // bit 1: pad the LDS so that one workgroup is resident per CU
 };
+int readconv_stamp_slots();
 bool readconv_supports_window(int window);
 int readconv_reads_per_group(int window);
 int readconv_frame_rows(int window);       // positions per read after the read convolver: 36 | 61

@@ -81,6 +81,7 @@ struct Offs {
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int STAMP_SLOTS = 48;                           // uint64 words per (workgroup, wave, group) of a stamped launch: readconv_kernel
 
 // Geometry of a pileup window of WIN_ positions (150 in every shipped model, 250 in the feature-map variant):
 //   window -> 3 valid k=3 convs (WIN-6) -> MaxPool(3,2): L1 -> strided block: L2
@@ -149,6 +150,7 @@ bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0
 
 bool readconv_supports_window(int window) { return window == 150 || window == 250; }
 int readconv_reads_per_group(int window) { return window == 250 ? Geometry250::G : Geometry::G; }
+int readconv_stamp_slots() { return rc::STAMP_SLOTS; }
 int readconv_frame_rows(int window) { return window == 250 ? Geometry250::L2 : Geometry::L2; }
 // Groups a workgroup walks.  More groups per workgroup = fewer partial-sum slots and one prologue per several
 // groups (measured 1.2 %), but fewer, longer workgroups = a coarser tail when the last wave of workgroups does
@@ -1355,7 +1357,12 @@ __device__ __forceinline__ void stem_conv3_pool_wino(const float* __restrict__ i
     });
 }
 
-template <class CF, bool STEM, int NB64, bool WINO, bool BF16 = false, bool BF16_32 = false>
+// STAMP (diagnostic instantiation, hello_engine_debug_stamps; never the product launch): every wave records s_memtime at the
+// start of each group and on both sides of each of the group's 20 barriers into ReadConvArgs::stamps -- memory nothing else
+// reads; no output value is computed from a stamp.  Layout: [workgroup][wave][group < stamp_groups][STAMP_SLOTS] of uint64:
+// slot 0 = group start, 1 + 2 i = arrival at barrier i, 2 + 2 i = release from it, 41 = HW_ID | XCC_ID << 32, 42 / 43 =
+// s_memrealtime at the group's start / end (100 MHz: the in-kernel clock), 44 = after the workgroup's last flush.
+template <class CF, bool STEM, int NB64, bool WINO, bool BF16 = false, bool BF16_32 = false, bool STAMP = false>
 __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a) {
     using namespace rc;
     constexpr bool F33 = WINO && CF::F33;                     // 64-channel residual blocks in F(3,3) form
@@ -1378,8 +1385,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bufA = smem;
     float* bufB = smem + BUF_FLOATS;
-    int* s_allele = (int*)(smem + 2 * BUF_FLOATS);           // G ints
-    float* dump = smem + 2 * BUF_FLOATS + 12;                 // 16 spare bytes of the same 64-byte block
+    float* dump = smem + 2 * BUF_FLOATS + 12;                 // 16 spare bytes of a 64-byte block between the images and the staged bytes
     unsigned char* s_u8 = (unsigned char*)(smem + 2 * BUF_FLOATS + 16);
 
     const int tid0 = threadIdx.x;
@@ -1452,6 +1458,27 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     const int cb2 = wave % 2, cb4 = wave;
     const long long read0 = wg_read0 + (long long)grp * G;
     if (read0 >= a.n_reads) break;                            // uniform: the last workgroup may hold fewer groups
+    unsigned long long* const stamp_base = STAMP ? a.stamps + (((long long)blockIdx.x * CF::NW + wave) * a.stamp_groups + grp) * STAMP_SLOTS : nullptr;
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (grp < a.stamp_groups && lane == 0) stamp_base[slot] = t;
+        }
+    };
+    auto barrier = [&](int id) {                              // barrier `id` of the group (0 .. 19 in the fp32 Winograd schedule)
+        stamp(1 + 2 * id);
+        __syncthreads();
+        stamp(2 + 2 * id);
+    };
+    if constexpr (STAMP) {
+        stamp(0);
+        const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        if (grp < a.stamp_groups && lane == 0) {
+            stamp_base[41] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            stamp_base[42] = rt;
+        }
+    }
     const int n_here = (int)((a.n_reads - read0) < G ? (a.n_reads - read0) : G);
     // first trunk layer: requested before anything else waits
     if constexpr (F33) {
@@ -1461,7 +1488,6 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     } else {
         load_weights<NVA>(wA, W + OFF_B, cb2, lane);
     }
-    if (tid < G) s_allele[tid] = (tid < n_here) ? a.allele_of_read[read0 + tid] : -1;
     if (STEM) {
         // the stem, from the uint8 pileups: conv1 bytes -> bufB, conv2 bufB -> bufA, conv3 + max pool
         // bufA -> X (= bufB again, now as the 32-channel image)
@@ -1495,25 +1521,25 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         }
         f32x4 ws2[3];
         if constexpr (!WINO) load_weights<3>(ws2, W + OFF_S2, 0, lane);
-        __syncthreads();
+        barrier(0);
         stem_conv1<CF>(s_u8, bufB, W + OFF_S1, ch, dump, wave, lane);
-        __syncthreads();
+        barrier(1);
         if constexpr (WINO) stem_conv2_wino<CF>(bufB, bufA, W + OFF_S2, dump, wave, lane);
         else conv_layer<CF, 16, 16, 3, 1, 0, 1, 1, 0, CF::ST12, MODE_PLAIN, false, GEOM_STEM, 16, CF::SROWS>(
             bufB, bufA, ws2, nullptr, W + OFF_S2 + 3 * 256, sreg, 0u, dump, wave, lane);
-        __syncthreads();
+        barrier(2);
         if (tid < 8 * (G + 1)) {                      // the image's shared zero rows: 0, 72, 144, ...
             const int row = (tid >> 3) * RS1;
             *(f32x4*)(X + img_off<32, SWX>(row, tid & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};   // a whole row, chunk by chunk
         }
         if constexpr (WINO) stem_conv3_pool_wino<CF, SWX>(bufA, X, W + OFF_S3, dump, wave, lane, n_here);
         else stem_conv3_pool<CF, SWX>(bufA, X, W + OFF_S3, dump, wave, lane, n_here);
-        __syncthreads();
+        barrier(3);
         if (tid < 8) ((f32x4*)H)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};        // row 0 of the 32-channel image
     } else {
         for (int i = tid; i < BUF_FLOATS / 4; i += THREADS) ((f32x4*)bufA)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (tid < 16) ((f32x4*)bufB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
+        barrier(0);
         const f32x4* src = (const f32x4*)(a.pooled + read0 * (L1 * 32));
         const int n4 = n_here * L1 * 8;
         for (int f = tid; f < n4; f += THREADS) {
@@ -1528,7 +1554,14 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
     auto slice = [&](int off, int cb, int nv) { return W + off + cb * nv * 256 + lane * 4; };   // this wave's block, this lane
 
     // ---- 3 x ResidualBlock(32): x -> relu(conv) -> relu(conv) + x --------------------------------
-    __syncthreads();
+    // With the in-kernel stem nothing is pending here but wave 0's zeros for row 0 of H, which no wave reads before the next
+    // barrier (the first convolution reads X and writes rows >= 1 of H): no barrier.  Without the stem, X was just filled.
+    if constexpr (STEM && !BF16_32) {
+        stamp(1 + 2 * 4);
+        stamp(2 + 2 * 4);
+    } else {
+        barrier(4);
+    }
     // bf16x3: this wave's split weights of the 32-channel layers, [6 layers][2 blocks][3 taps][hi | lo][64 lanes][8] behind
     // the 64-channel layers' block
     const unsigned short* const WS32 = (const unsigned short*)(W + O::off_d(NB64)) + (1 + 2 * NB64) * 24576 + cb2 * 3072 + lane * 8;
@@ -1573,7 +1606,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             // this wave's block of a 32-channel F(3,3) layer, this lane: [2 input groups][5 components][64 lanes][4]
             auto slice32 = [&](int off) { return W + off + cb2 * (10 * 256) + lane * 4; };
             wino3_layer<CF, 32, MODE_PLAIN, false>(X, H, w3, slice32(off_a), slice32(off_b), W + off_a + O::W3232D, wave, lane);
-            __syncthreads();
+            barrier(5 + 2 * blk);
             if (blk < 2)
                 wino3_layer<CF, 32, MODE_RESID_INPLACE, false>(H, X, w3, slice32(off_b), slice32(off_b + (O::W3232D + 32)),
                                                                W + off_b + O::W3232D, wave, lane);
@@ -1581,16 +1614,16 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
                 wino3_layer<CF, 32, MODE_RESID_INPLACE, true>(H, X, w3, slice32(off_b), nullptr, W + off_b + O::W3232D, wave, lane);
         } else if constexpr (WINO) {
             wino_layer<CF, 32, MODE_PLAIN, true>(X, H, wA, slice(off_b, cb2, NVA), W + off_a + W3232, pad1, dump, wave, lane);
-            __syncthreads();
+            barrier(5 + 2 * blk);
             wino_layer<CF, 32, MODE_RESID_INPLACE, true, true>(H, X, wA, nxt, W + off_b + W3232, pad1f, dump, wave, lane);
         } else {
             conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_PLAIN, true>(
                 X, H, w6, slice(off_b, cb2, 6), W + off_a + W3232, sreg, pad1, dump, wave, lane);
-            __syncthreads();
+            barrier(5 + 2 * blk);
             conv_layer<CF, 32, 32, 3, 1, 1, RS1, RS1, L1, T1, MODE_RESID_INPLACE, true>(
                 H, X, w6, nxt, W + off_b + W3232, sreg, pad1, dump, wave, lane);
         }
-        __syncthreads();
+        barrier(6 + 2 * blk);
     }
 
     // ---- strided block 32 -> 64: relu(conv s2) -> relu(conv) + (1x1 s2 shortcut) ----------------
@@ -1632,7 +1665,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         conv_layer<CF, 32, 64, 1, 2, 0, RS1, RS2, L2, T2, MODE_TO_REGS, false, GEOM_TRUNK, 16, RS2 * CF::G, false, SWX, SWX>(
             X, nullptr, w2, nullptr, W + OFF_SC + W3264S, sreg, pad2, dump, wave, lane);
     }
-    __syncthreads();
+    barrier(11);
     if (tid < 32) ((f32x4*)X)[(tid & 15) + (tid >> 4) * (RS2 * G + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this wave's block of an F(3,3) layer, this lane: [4 input groups][5 components][64 lanes][4]
     auto slice3 = [&](int off) { return W + off + cb4 * (20 * 256) + lane * 4; };
@@ -1657,7 +1690,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_ADD_REGS, true, GEOM_TRUNK, 16, RS2 * CF::G, true, SWX, SWX>(
             H, X, w12, slice(O::off_d(0), cb4, NVB), W + OFF_C2 + W6464, sreg, pad2, dump, wave, lane);
     }
-    __syncthreads();
+    barrier(12);
 
     // ---- NB64 x ResidualBlock(64) (3 in the canonical read convolver) ------------------------------
 #pragma unroll
@@ -1675,7 +1708,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
                                                        W + off_b + O::W6464D, sreg, wave, lane);
         } else if constexpr (F33) {
             wino3_layer<CF, 64, MODE_PLAIN, false>(X, H, w3, slice3(off_a), slice3(off_b), W + off_a + O::W6464D, wave, lane);
-            __syncthreads();
+            barrier(13 + 2 * blk);
             if (blk < NB64 - 1)
                 wino3_layer<CF, 64, MODE_RESID_INPLACE, false>(H, X, w3, slice3(off_b), slice3(O::off_d(blk + 1)),
                                                            W + off_b + O::W6464D, wave, lane);
@@ -1683,7 +1716,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
                 wino3_layer<CF, 64, MODE_RESID_INPLACE, true>(H, X, w3, slice3(off_b), nullptr, W + off_b + O::W6464D, wave, lane);
         } else if constexpr (WINO) {
             wino_layer<CF, 64, MODE_PLAIN, true>(X, H, wB, slice(off_b, cb4, NVB), W + off_a + W6464, pad2w, dump, wave, lane);
-            __syncthreads();
+            barrier(13 + 2 * blk);
             if (blk < NB64 - 1)
                 wino_layer<CF, 64, MODE_RESID_INPLACE, true>(H, X, wB, slice(O::off_d(blk + 1), cb4, NVB), W + off_b + W6464,
                                                              pad2w, dump, wave, lane);
@@ -1692,7 +1725,7 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
         } else {
             conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_PLAIN, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
                 X, H, w12, slice(off_b, cb4, 12), W + off_a + W6464, sreg, pad2, dump, wave, lane);
-            __syncthreads();
+            barrier(13 + 2 * blk);
             if (blk < NB64 - 1)
                 conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, true, GEOM_TRUNK, 16, RS2 * CF::G, true>(
                     H, X, w12, slice(O::off_d(blk + 1), cb4, 12), W + off_b + W6464, sreg, pad2, dump, wave, lane);
@@ -1700,12 +1733,21 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
                 conv_layer<CF, 64, 64, 3, 1, 1, RS2, RS2, L2, T2, MODE_RESID_INPLACE, false, GEOM_TRUNK, 16, RS2 * CF::G, true>(
                     H, X, w12, nullptr, W + off_b + W6464, sreg, pad2, dump, wave, lane);
         }
-        __syncthreads();
+        barrier(14 + 2 * blk);
     }
 
     // ---- the group's reads join the running per-allele sum, in read order ---------------------------
+    static_assert(G <= 4, "the allele select below");
+    // the alleles of the group's reads, by scalar loads (the index is uniform), all requested at once
+    int allele_of[G];
+#pragma unroll
+    for (int rd = 0; rd < G; ++rd) {
+        const long long r = read0 + rd < a.n_reads ? read0 + rd : a.n_reads - 1;
+        allele_of[rd] = __builtin_amdgcn_readfirstlane(a.allele_of_read[r]);
+    }
+#pragma nounroll
     for (int rd = 0; rd < n_here; ++rd) {
-        const int al = s_allele[rd];
+        const int al = rd == 0 ? allele_of[0] : rd == 1 ? allele_of[1 % G] : rd == 2 ? allele_of[2 % G] : allele_of[3 % G];
         if (al != cur) {                                      // uniform
             flush();
             cur = al;
@@ -1720,9 +1762,18 @@ __global__ __launch_bounds__(CF::THREADS, 2) void readconv_kernel(ReadConvArgs a
             }
         }
     }
-    __syncthreads();                                          // the next group's stem overwrites the images
+    barrier(19);                                          // the next group's stem overwrites the images
+    if constexpr (STAMP) {
+        const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+        if (grp < a.stamp_groups && lane == 0) stamp_base[43] = rt;
+    }
     }   // groups of this workgroup
     flush();
+    if constexpr (STAMP) {
+        static_assert(!STAMP || (NB64 == 3 && STEM && WINO && !BF16), "stamps: the default fp32 Winograd schedule (20 barriers per group)");
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if ((tid0 & 63) == 0) a.stamps[(((long long)blockIdx.x * CF::NW + wave0) * a.stamp_groups) * STAMP_SLOTS + 44] = t;
+    }
 }
 
 template <class CF, int NB64, bool WINO, bool STEM_ONLY = false, bool BF16 = false, bool BF16_32 = false>
@@ -1747,6 +1798,25 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
     if (a.groups_per_wg < 1) return hipErrorInvalidValue;
     const long long per_wg = (long long)CF::G * a.groups_per_wg;
     const unsigned groups = (unsigned)((a.n_reads + per_wg - 1) / per_wg);       // workgroups
+    if (a.stamps) {
+        // the diagnostic instantiation (hello_engine_debug_stamps): the default schedule only; stamp_mode bit 1 pads the
+        // workgroup's LDS past half a CU's, so that ONE workgroup is resident per CU (one wave per SIMD)
+        if constexpr (std::is_same<CF, Geometry>::value && NB64 == 3 && WINO && !BF16 && !STEM_ONLY) {
+            if (!a.reads || (a.channels != 6 && a.channels != 7) || a.stamp_groups < 1) return hipErrorInvalidValue;
+            static bool stamped_on[64] = {};
+            if (!stamped_on[dev]) {
+                const hipError_t e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64, WINO, false, false, true>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+                if (e != hipSuccess) return e;
+                stamped_on[dev] = true;
+            }
+            const int lds = (a.stamp_mode & 2) ? 100 * 1024 : CF::LDS_BYTES;
+            hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO, false, false, true>), dim3(groups), dim3(CF::THREADS), lds, stream, a);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (a.reads) {
         if (a.channels != 6 && a.channels != 7) return hipErrorInvalidValue;
         hipLaunchKernelGGL((readconv_kernel<CF, true, NB64, WINO, BF16, BF16_32>), dim3(groups), dim3(CF::THREADS), CF::LDS_BYTES, stream, a);

@@ -79,6 +79,12 @@ def load_library():
     lib.hello_engine_set_profiling_filter.argtypes = [vp, i32]
     lib.hello_engine_debug_capture.argtypes = [vp, i32]
     lib.hello_engine_debug_read.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    # the kernel-timeline diagnostic is an addition within ABI version 2: a library built before it (HELLO_LIB pointing at an
+    # older build, e.g. the baseline of an A/B run) still loads; record_stamps then says what is missing
+    diagnostics = ("hello_engine_debug_stamps", "hello_engine_debug_read_stamps") if hasattr(lib, "hello_engine_debug_stamps") else ()
+    if diagnostics:
+        lib.hello_engine_debug_stamps.argtypes = [vp, i32]
+        lib.hello_engine_debug_read_stamps.argtypes = [vp, vp, i64, C.POINTER(i64), C.POINTER(i32)]
     lib.hello_engine_stream.argtypes = [vp]
     lib.hello_engine_stream.restype = C.c_void_p
     lib.hello_engine_destroy.argtypes = [vp]
@@ -86,7 +92,7 @@ def load_library():
     for fn in ("hello_engine_create", "hello_engine_forward", "hello_engine_posteriors",
                "hello_engine_synchronize", "hello_engine_last_forward_ms", "hello_engine_set_profiling",
                "hello_engine_op_times_ms", "hello_engine_set_profiling_filter", "hello_engine_debug_capture",
-               "hello_engine_debug_read"):
+               "hello_engine_debug_read") + diagnostics:
         getattr(lib, fn).restype = C.c_int
     _lib = lib
     return lib
@@ -371,6 +377,22 @@ class Engine:
         out = np.empty(int(n.value), dtype=np.float32)
         _check(self.lib.hello_engine_debug_read(self.handle, out.ctypes.data, out.size, C.byref(n)))
         return out
+
+    def record_stamps(self, mode: int):
+        """Diagnostic: 1 = following forwards launch the STAMPED instantiation of the fused read convolver (per-wave s_memtime
+        records around every barrier; same results, ~10 % slower), 3 = the same with one workgroup per CU, 0 = off."""
+        if not hasattr(self.lib, "hello_engine_debug_stamps"):
+            raise RuntimeError(f"{_LIB_PATH} was built before the kernel-timeline diagnostic (hello_engine_debug_stamps): rebuild it")
+        _check(self.lib.hello_engine_debug_stamps(self.handle, int(mode)))
+
+    def read_stamps(self):
+        """-> (uint64 [workgroups, waves, groups per workgroup, slots], number of workgroups of the bulk launch) of the last
+        stamped forward; slots as documented at hello_engine_debug_stamps in include/hello_mi355x.h."""
+        n, layout = C.c_int64(), (C.c_int32 * 5)()
+        _check(self.lib.hello_engine_debug_read_stamps(self.handle, None, 0, C.byref(n), layout))
+        out = np.empty(int(n.value), dtype=np.uint64)
+        _check(self.lib.hello_engine_debug_read_stamps(self.handle, out.ctypes.data, out.size, C.byref(n), layout))
+        return out.reshape(layout[0], layout[1], layout[2], layout[3]), int(layout[4])
 
     def op_times_ms(self):
         """-> (list of (op kind, layer name, mean ms per forward), number of forwards averaged)."""

@@ -253,6 +253,18 @@ int hello_engine_set_profiling_filter(hello_engine* engine, int32_t op_kind);
 int hello_engine_debug_capture(hello_engine* engine, int32_t op_index);
 int hello_engine_debug_read(hello_engine* engine, float* out, int64_t capacity, int64_t* n_floats);
 
+/* Diagnostic timeline of the fused read convolver (how its time splits over its barrier-delimited sections; the reference has
+ * no counterpart -- its profile is torch's).  debug_stamps(1) arms: following forwards launch a STAMPED instantiation of the kernel
+ * (same code, plus per-wave s_memtime records at the start of each group of reads and on both sides of each of its 20 barriers,
+ * written to an engine-owned buffer nothing else reads; results are unchanged, the launch is ~10 % slower);  3: the same with ONE
+ * workgroup resident per CU (LDS padding); 0 disarms.  Only the canonical fp32 Winograd read convolver from the bytes.
+ * debug_read_stamps copies the last stamped forward's records to the host: uint64 [layout[0] workgroups][layout[1] waves]
+ * [layout[2] groups per workgroup][layout[3] slots]; layout[4] = how many of the workgroups walk layout[2] groups (the rest, from
+ * the second launch, walk one).  Slots: 0 group start, 1 + 2 i / 2 + 2 i arrival at / release from barrier i, 41 HW_ID | XCC_ID << 32,
+ * 42 / 43 s_memrealtime (100 MHz) at the group's start / end, 44 (group 0 only) after the workgroup's last flush. */
+int hello_engine_debug_stamps(hello_engine* engine, int32_t mode);
+int hello_engine_debug_read_stamps(hello_engine* engine, uint64_t* out, int64_t capacity, int64_t* n_words, int32_t* layout);
+
 void hello_engine_destroy(hello_engine* engine);
 
 /* ---- record stage (host only: no engine, no GPU) ---------------------------------------------------------------------

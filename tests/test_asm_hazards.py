@@ -26,7 +26,7 @@ def test_executed_mfma_accounting_matches_the_instruction_stream():
     import check_asm_hazards
     from hello_amd import readconv_pack as rp
     path = os.path.join(ROOT, "hello_amd", "csrc", "readconv_fused.hip")
-    cfg150 = "_ZN5hello15readconv_kernelINS_2rc3CfgILi4ELi4ELi150ELi0EEELb1ELi%dELb%dELb%dELb%dEEEvNS_12ReadConvArgsE"
+    cfg150 = "_ZN5hello15readconv_kernelINS_2rc3CfgILi4ELi4ELi150ELi0EEELb1ELi%dELb%dELb%dELb%dELb0EEEvNS_12ReadConvArgsE"
     for extra, wino in ((0, True), (2, True), (0, False)):
         per_wave_and_group = rp.executed_macs_per_read(wino, extra) * 4 / 4 / 1024       # 4 reads, 4 waves
         assert check_asm_hazards.mfma_count(path, cfg150 % (3 + extra, wino, 0, 0)) == per_wave_and_group, (extra, wino)

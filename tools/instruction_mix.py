@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import check_asm_hazards as cah          # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT = "_ZN5hello15readconv_kernelINS_2rc3CfgILi4ELi4ELi150ELi0EEELb1ELi3ELb1ELb0ELb0EEEvNS_12ReadConvArgsE"
+DEFAULT = "_ZN5hello15readconv_kernelINS_2rc3CfgILi4ELi4ELi150ELi0EEELb1ELi3ELb1ELb0ELb0ELb0EEEvNS_12ReadConvArgsE"
 
 
 def sections(symbol):
