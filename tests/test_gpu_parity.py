@@ -40,11 +40,17 @@ def get_engine(cache, name, spec, state, fused):
 # configurations and one per kernel family (wide trunk, 250 bp geometry, Softplus, transfer-learning blocks) -- VERDICT r03 item 6
 CANONICAL = ("single_tech_batched", "single_tech_hp", "hybrid_no_ensemble", "hybrid_full", "hybrid_ensemble2",
              "hybrid_no_ensemble_wide", "merged_hybrid_250", "single_tech_softplus", "single_tech_addendum")
-GOLDEN_CASES = [(n, f) for n in FIXTURES for f in (False, "trunk", True, "direct") if f in (False, True) or n in CANONICAL]
+# (+ the layer-norm model in direct form: the only fixture that lowers to direct-form 64 / 128 / 256-channel k3 convolutions behind a
+# LAYERNORM op -- found by tests/test_parity_matrix.py)
+EXTRA = (("single_tech_layernorm", "direct"),)
+GOLDEN_CASES = [(n, f) for n in FIXTURES for f in (False, "trunk", True, "direct") if f in (False, True) or n in CANONICAL or (n, f) in EXTRA]
 
 
-@pytest.mark.parametrize("name,fused", GOLDEN_CASES)
-def test_golden_logits(engines, name, fused):
+# the rest of the (fixture x kernel path) matrix that round 4 trimmed for time: kept, behind --runslow
+GOLDEN_CASES_REST = [(n, f) for n in FIXTURES for f in ("trunk", "direct") if n not in CANONICAL and (n, f) not in EXTRA]
+
+
+def _golden_logits(engines, name, fused):
     spec, state, batch, exp = load_fixture(name)
     eng = get_engine(engines, name, spec, state, fused)
     logits, meta = eng.forward_batch(batch)
@@ -54,6 +60,19 @@ def test_golden_logits(engines, name, fused):
         np.testing.assert_allclose(meta, exp["meta"], rtol=1e-4, atol=PROB_ATOL)
     else:
         assert meta is None
+
+
+@pytest.mark.parametrize("name,fused", GOLDEN_CASES)
+def test_golden_logits(engines, name, fused):
+    _golden_logits(engines, name, fused)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name,fused", GOLDEN_CASES_REST)
+def test_golden_logits_rest_of_the_matrix(engines, name, fused):
+    """Every fixture outside CANONICAL through the two intermediate kernel paths too (layered stem + fused trunk; fused,
+    direct-form convolutions): a model whose shapes only these paths see stays covered."""
+    _golden_logits(engines, name, fused)
 
 
 def _frames_op(program, tech):
@@ -603,9 +622,22 @@ def _with_extremes(batch, seed, hybrid, channels):
                            cat(batch.ref_onehot, ref), cat(batch.reads1, reads1), cat(batch.reads_per_allele1, rpa1))
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("gain", [0.5, 1.0, 2.5])
+@pytest.mark.parametrize("label,cfg,kw", BASELINE_CONFIGS, ids=[c[1] + "-" + str(i) for i, c in enumerate(BASELINE_CONFIGS)])
+def test_stress_against_oracle_36_sites(label, cfg, kw, gain):
+    """The round-3 size of the stress batches (36 sites + extremes: more partial workgroups and read-group seams than the 16 of
+    the default run)."""
+    _stress_against_oracle(label, cfg, kw, gain, 36)
+
+
 @pytest.mark.parametrize("gain", [0.5, 1.0, 2.5])
 @pytest.mark.parametrize("label,cfg,kw", BASELINE_CONFIGS, ids=[c[1] + "-" + str(i) for i, c in enumerate(BASELINE_CONFIGS)])
 def test_stress_against_oracle(label, cfg, kw, gain):
+    _stress_against_oracle(label, cfg, kw, gain, 16)
+
+
+def _stress_against_oracle(label, cfg, kw, gain, n_sites):
     """The fused Winograd engine (F(3,3) on unnormalised 0..254 inputs, sums over up to 1000 reads) against the CPU
     oracle: pair posteriors within the north star's 1e-4, per-allele probabilities within 1e-4, logits within 2e-5 of
     their scale, at three weight scales (logits from O(0.1) to O(1e6))."""
@@ -614,7 +646,7 @@ def test_stress_against_oracle(label, cfg, kw, gain):
     spec = ns.build(cfg)
     state = weights.synth_state(spec, seed=77, gain=gain)
     hybrid = "hybrid_coverage" in kw
-    batch = _with_extremes(synth.make_sites(16, seed=int(1000 * gain) + len(cfg), **kw), 4000 + int(10 * gain), hybrid,
+    batch = _with_extremes(synth.make_sites(n_sites, seed=int(1000 * gain) + len(cfg), **kw), 4000 + int(10 * gain), hybrid,
                            kw.get("channels", 6))
     eng = Engine(spec, state, device=0)
     logits, meta, post = eng.forward_batch(batch, posteriors=True)
