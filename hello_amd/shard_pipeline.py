@@ -136,61 +136,51 @@ class ShardScorer:
 
     def _fill(self, shards, parts, block: np.ndarray, techs):
         """One pass over the launch's bytes: every shard's arrays land at their place in the pinned block, offsets and
-        site indices shifted to the coalesced numbering."""
+        site indices shifted to the coalesced numbering.  ONE NumPy call per field and launch (a concatenation straight into
+        the pinned view, then one vector add of the per-shard shifts), not one per field and shard: with reference-sized shards
+        (400 sites, ~20 per launch) the per-shard form spent more host time in Python call overhead than in copying."""
         def view(key):
             at, dtype, count = parts[key]
             return block[at:at + count * dtype.itemsize].view(dtype)
+
+        def cat(key, arrays, tail=None):
+            v = view(key)
+            n = sum(int(a.shape[0]) for a in arrays)
+            np.concatenate(arrays, out=v[:n], casting="same_kind")
+            if tail is not None:
+                v[n] = tail
+            return v, n
+
+        def shifted(v, counts, shifts):
+            """v[k-th run of counts[k] elements] += shifts[k] (runs in order; a zero shift everywhere is skipped)."""
+            if len(shifts) > 1 and any(shifts):
+                v += np.repeat(np.asarray(shifts, dtype=v.dtype), np.asarray(counts, dtype=np.int64))
+        n_sites = [sh.n_sites for sh in shards]
+        site_shift = np.concatenate([[0], np.cumsum(n_sites)[:-1]]).tolist()
         for t in techs:
             fa = [sh.featurizer_core(t) for sh in shards]
             for name in ("bases", "quals", "cigars"):
-                v, pos = view((name, t)), 0
-                for f in fa:
-                    n = int(f[name].shape[0])
-                    v[pos:pos + n] = f[name]
-                    pos += n
-                v[pos] = 0
+                cat((name, t), [f[name] for f in fa], tail=0)
             for name, data in (("read_off", "bases"), ("cigar_off", "cigars")):
-                v, pos, shift = view((name, t)), 0, 0
+                v = view((name, t))
                 v[0] = 0
-                for f in fa:
-                    n = int(f[name].shape[0]) - 1
-                    np.add(f[name][1:], shift, out=v[pos + 1:pos + 1 + n])
-                    pos += n
-                    shift += int(f[data].shape[0])
+                _, n = cat_into(v[1:], [f[name][1:] for f in fa])
+                sizes = [int(f[data].shape[0]) for f in fa]
+                shifted(v[1:1 + n], [int(f[name].shape[0]) - 1 for f in fa], np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist())
             for name in PER_READ:
-                v, pos, site = view((name, t)), 0, 0
-                for f, sh in zip(fa, shards):
-                    n = int(f[name].shape[0])
-                    if name == "site_of_read":
-                        np.add(f[name], site, out=v[pos:pos + n])
-                    else:
-                        v[pos:pos + n] = f[name]
-                    pos += n
-                    site += sh.n_sites
-        v, pos = view(("ref", None)), 0
-        for sh in shards:
-            n = int(sh.ref.shape[0])
-            v[pos:pos + n] = sh.ref
-            pos += n
-        v[pos] = 0
-        v, pos, shift = view(("ref_off", None)), 0, 0
+                v, n = cat((name, t), [f[name] for f in fa])
+                if name == "site_of_read":
+                    shifted(v[:n], [int(f[name].shape[0]) for f in fa], site_shift)
+        cat(("ref", None), [sh.ref for sh in shards], tail=0)
+        v = view(("ref_off", None))
         v[0] = 0
-        for sh in shards:
-            np.add(sh.ref_off[1:], shift, out=v[pos + 1:pos + 1 + sh.n_sites])
-            pos += sh.n_sites
-            shift += int(sh.ref.shape[0])
+        _, n = cat_into(v[1:], [sh.ref_off[1:] for sh in shards])
+        ref_sizes = [int(sh.ref.shape[0]) for sh in shards]
+        shifted(v[1:1 + n], n_sites, np.concatenate([[0], np.cumsum(ref_sizes)[:-1]]).tolist())
         for name, attr in (("window_start", "window_start"), ("asm_start", "start"), ("asm_stop", "stop")):
-            v, pos = view((name, None)), 0
-            for sh in shards:
-                v[pos:pos + sh.n_sites] = getattr(sh, attr)
-                pos += sh.n_sites
+            cat((name, None), [getattr(sh, attr) for sh in shards])
         if self.uses_ref:
-            v, pos = view(("onehot", None)), 0
-            for sh in shards:
-                n = sh.n_sites * self.L * 5
-                if n:
-                    v[pos:pos + n] = sh.onehot.reshape(-1)
-                pos += n
+            cat(("onehot", None), [sh.onehot.reshape(-1) for sh in shards if sh.n_sites])
 
     # -- pipeline ---------------------------------------------------------------------------------------------------
     def _harvest(self, slot: _Slot) -> Scored:
@@ -264,6 +254,13 @@ class ShardScorer:
         n = len(self.slots)
         order = [self.slots[(self.count + k) % n] for k in range(n)]      # oldest first
         return [self._harvest(s) for s in order if s.pending is not None]
+
+
+def cat_into(v: np.ndarray, arrays):
+    """Concatenate 1-D ``arrays`` into the head of ``v`` (one C call); -> (v, elements written)."""
+    n = sum(int(a.shape[0]) for a in arrays)
+    np.concatenate(arrays, out=v[:n], casting="same_kind")
+    return v, n
 
 
 # ---------------------------------------------------------------------------------------------------------------------

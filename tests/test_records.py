@@ -401,3 +401,57 @@ def test_run_keeps_a_bounded_number_of_shards_in_memory(tmp_path):
     assert all(sp.SENTINEL in open(tmp_path / f"features{k}.log").read() for k in (0, n - 1))
     total = sp.merge_final_vcf(stats.outputs, lambda names: "", str(tmp_path / "final.vcf"))
     assert total == sum(o.position.shape[0] for o in stats.outputs) > n
+
+
+@pytest.mark.parametrize("hybrid,uses_ref", [(False, False), (True, True)])
+def test_staging_block_of_a_coalesced_launch_equals_the_per_shard_walk(hybrid, uses_ref):
+    """ShardScorer._fill lays a launch's shards out in the pinned block with ONE NumPy call per field (round 5: reference-sized
+    shards spent more host time in per-shard call overhead than in copying).  Held here, without a GPU, to the plain per-shard
+    walk: every field of every shard at its place, offsets and site indices shifted to the coalesced numbering -- ragged shards
+    (one of a single site), one and two technologies, the one-hot reference segments."""
+    rng = np.random.default_rng(11)
+    payloads = [shards._payload(random_sites(rng, n, hybrid=hybrid)) for n in (5, 1, 9, 3)]
+    packed = [shards.PackedShard(dict(p)) for p in payloads]
+    if uses_ref:
+        for sh in packed:
+            sh.onehot = sh.segment_onehot()                            # what the reader threads attach (shard_pipeline.load_shard)
+    scorer = sp.ShardScorer.__new__(sp.ShardScorer)                    # layout + fill need no engine
+    scorer.hybrid, scorer.uses_ref, scorer.L = hybrid, uses_ref, 150
+    techs = (0, 1) if hybrid else (0,)
+    parts, nbytes, reads, S = scorer._layout(packed)
+    block = np.full(nbytes, 0xAB, np.uint8)
+    scorer._fill(packed, parts, block, techs)
+
+    def view(key):
+        at, dtype, count = parts[key]
+        return block[at:at + count * dtype.itemsize].view(dtype)
+    for t in techs:
+        fa = [sh.featurizer_core(t) for sh in packed]
+        for name in ("bases", "quals", "cigars"):
+            want = np.concatenate([f[name] for f in fa] + [np.zeros(1, fa[0][name].dtype)])
+            assert np.array_equal(view((name, t)), want), (name, t)
+        for name, data in (("read_off", "bases"), ("cigar_off", "cigars")):
+            want, shift = [np.zeros(1, np.int64)], 0
+            for f in fa:
+                want.append(f[name][1:] + shift)
+                shift += int(f[data].shape[0])
+            assert np.array_equal(view((name, t)), np.concatenate(want)), (name, t)
+        for name in sp.PER_READ:
+            want, site = [], 0
+            for f, sh in zip(fa, packed):
+                want.append(f[name] + site if name == "site_of_read" else f[name])
+                site += sh.n_sites
+            got = view((name, t))
+            assert np.array_equal(got, np.concatenate(want).astype(got.dtype)), (name, t)
+        assert reads[t] == sum(int(f["site_of_read"].shape[0]) for f in fa)
+    assert np.array_equal(view(("ref", None)), np.concatenate([sh.ref for sh in packed] + [np.zeros(1, np.uint8)]))
+    want, shift = [np.zeros(1, np.int64)], 0
+    for sh in packed:
+        want.append(sh.ref_off[1:] + shift)
+        shift += int(sh.ref.shape[0])
+    assert np.array_equal(view(("ref_off", None)), np.concatenate(want))
+    for name, attr in (("window_start", "window_start"), ("asm_start", "start"), ("asm_stop", "stop")):
+        assert np.array_equal(view((name, None)), np.concatenate([getattr(sh, attr) for sh in packed]))
+    if uses_ref:
+        assert np.array_equal(view(("onehot", None)), np.concatenate([sh.onehot.reshape(-1) for sh in packed]))
+    assert S == sum(sh.n_sites for sh in packed)
