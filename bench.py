@@ -15,6 +15,11 @@ every result harvested to host memory before the closing fence.  The device-resi
 HBM, outputs left there) is reported beside it as ``device_resident``: the pipeline hides the PCIe feed behind
 the kernels, so the two agree within a few percent.
 
+``python bench.py --gpus N`` from a plain shell starts its own N ranks (a CHILD ``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1``, before this process has touched a GPU; never an exec) and relays rank 0's one JSON line;
+under a launcher (RANK / WORLD_SIZE set: the driver's form) the process is a rank.  The CPU baseline is timed on rank 0 at every N,
+before the rendezvous (the other ranks wait idle in it), so the line carries ``cpu_baseline`` at N > 1 too.
+
 With N > 1 (one process per GPU under torch.distributed.run) the global step batch is N times as large
 (``--scaling weak``, the default) or the same ``--launches-per-step`` launches cut N ways (``--scaling strong``:
 the fixed 1.64 M-site stream of the N = 1 run); every rank computes the same read-balanced site partition from
