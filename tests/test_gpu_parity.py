@@ -808,3 +808,45 @@ def test_sites_with_many_alleles(cfg):
         one, _, p1 = eng.forward_batch(batch.site_slice(s, s + 1), posteriors=True)
         np.testing.assert_allclose(one, want[:, aoff[s]:aoff[s + 1]], **LOGIT_TOL)
     eng.close()
+
+
+def test_stamped_read_convolver_gives_the_same_bits_and_a_sane_timeline():
+    """hello_engine_debug_stamps (DESIGN 3.1's measured cost model rests on it): the stamped instantiation of the fused read convolver
+    computes the same bits as the product kernel, at two workgroups per CU and at one; every (workgroup, wave, group) record is
+    monotone -- start <= arrival <= release at each of the 20 barriers -- and the layout says how the launches covered the reads.
+    Models outside the canonical fp32 Winograd schedule refuse the diagnostic instead of recording nonsense."""
+    from hello_amd.engine import Engine
+    spec = ns.build("single_tech")
+    state = weights.synth_state(spec, seed=3)
+    batch = synth.make_sites(700, seed=17, coverage=30)              # a bulk launch of several groups per workgroup + a remainder launch
+    eng = Engine(spec, state, device=0, arithmetic="fp32")
+    want, _, want_post = eng.forward_batch(batch, posteriors=True)
+    for mode in (1, 3):
+        eng.record_stamps(mode)
+        got, _, got_post = eng.forward_batch(batch, posteriors=True)
+        assert np.array_equal(got, want) and np.array_equal(got_post, want_post)
+        stamps, bulk = eng.read_stamps()
+        wgs, waves, groups, slots = stamps.shape
+        assert waves == 4 and slots >= 45 and 0 < bulk <= wgs and groups >= 1
+        n_groups = (batch.reads0.shape[0] + 3) // 4
+        s = stamps.astype(np.int64)
+        live = s[..., 0] > 0
+        assert int(live.sum()) == 4 * n_groups                        # every group of 4 reads left one record per wave
+        assert live[bulk:, :, 1:].sum() == 0                          # the remainder launch's workgroups walk one group
+        seq = np.concatenate([s[..., 0:1], s[..., 1:41]], axis=-1)[live]
+        assert (np.diff(seq, axis=-1) >= 0).all()                     # start <= arrive 0 <= release 0 <= arrive 1 <= ...
+        assert (s[..., 43][live] > s[..., 42][live]).all()            # the 100 MHz clock moved inside every group
+        total = (s[..., 40] - s[..., 0])[live]
+        assert 5e4 < np.median(total) < 2e6                           # a group is ~1.5e5 (one wave per SIMD) to ~2.6e5 cycles
+    eng.record_stamps(0)
+    again, _, _ = eng.forward_batch(batch, posteriors=True)
+    assert np.array_equal(again, want)
+    with pytest.raises(RuntimeError, match="mode"):
+        eng.record_stamps(2)
+    eng.close()
+    wide = ns.build("hybrid_no_ensemble", w=2)
+    eng = Engine(wide, weights.synth_state(wide, seed=3), device=0)
+    eng.record_stamps(1)
+    with pytest.raises(RuntimeError, match="stamps"):
+        eng.forward_batch(synth.make_sites(5, seed=2, coverage=10, hybrid_coverage=6))
+    eng.close()
