@@ -39,6 +39,25 @@ def _to_u8(x, what: str) -> np.ndarray:
     return np.ascontiguousarray(u)
 
 
+class _Lazy:
+    """torch is imported on first use (the module itself needs NumPy only)."""
+    def __init__(self, make):
+        self._make, self._value = make, None
+
+    def clone(self):
+        if self._value is None:
+            self._value = self._make()
+        return self._value.clone()
+
+
+def _one_hot_meta():
+    import torch
+    return torch.tensor([1.0, 0.0, 0.0])
+
+
+_SINGLE_EXPERT_META = _Lazy(_one_hot_meta)      # a single-expert model's mixing weights (MixtureOfExpertsAdvanced.py:575-579)
+
+
 def pair_keys(alleles: Sequence) -> List[Tuple]:
     """Unordered allele pairs in first-seen itertools.product order (MixtureOfExpertsAdvanced.py:562-564)."""
     n = len(alleles)
@@ -95,35 +114,57 @@ class ScoringNetwork:
 
     # -- packing ---------------------------------------------------------------------------------
     @staticmethod
-    def _pack(sites: Sequence[Tuple[Dict, object]]):
-        """[(featureDict, segment)] -> contiguous channels-last uint8 batch + counts."""
-        r0, r1, rpa0, rpa1, aps, refs, names = [], [], [], [], [], [], []
-        any_second = None
+    def _as_array(x) -> np.ndarray:
+        if hasattr(x, "detach"):
+            x = x.detach().cpu().numpy()                     # a view for a CPU tensor
+        return np.asarray(x)
+
+    @staticmethod
+    def _bytes_of(arrays: List[np.ndarray], labels: List[str]) -> np.ndarray:
+        """The pileups of one technology as ONE contiguous uint8 [sum R, L, C] array.  The reference hands over float copies of
+        the featurizer's bytes (caller_calling.py:633-639): they are concatenated first and converted + validated in one pass
+        (one NumPy call per site instead of three per allele); only a failed check walks the alleles again to name the culprit."""
+        if all(a.dtype == np.uint8 for a in arrays):
+            return np.concatenate(arrays, axis=0)
+        whole = np.concatenate(arrays, axis=0)
+        if whole.dtype == np.uint8:                          # (mixed uint8 / float inputs were promoted by the concatenation)
+            return whole
+        u = whole.astype(np.uint8)
+        if not np.array_equal(u, whole):
+            for a, label in zip(arrays, labels):
+                _to_u8(a, label)                             # raises, naming the allele
+            raise ValueError("pileup values must be integers in 0..255 (the featurizer's uint8 alphabet)")
+        return u
+
+    @classmethod
+    def _pack(cls, sites: Sequence[Tuple[Dict, object]], need_ref: bool = True):
+        """[(featureDict, segment)] -> contiguous channels-last uint8 batch + counts.  ``need_ref`` False: the model does not
+        read the reference segment -- it is not converted."""
+        r0, r1, l0, l1, rpa0, rpa1, aps, refs, names = [], [], [], [], [], [], [], [], []
         for feature_dict, segment in sites:
             alleles = list(feature_dict.keys())
             names.append(alleles)
             aps.append(len(alleles))
             for a in alleles:
                 first, second = feature_dict[a]
-                f = _to_u8(first, f"allele {a!r}")
+                f = cls._as_array(first)
                 r0.append(f)
+                l0.append(a)
                 rpa0.append(f.shape[0])
-                has_second = second is not None
-                if any_second is None:
-                    any_second = has_second
-                if has_second:
-                    s = _to_u8(second, f"allele {a!r} (second technology)")
-                    r1.append(s)
-                    rpa1.append(s.shape[0])
-            if segment is not None:
+                if second is not None:
+                    sec = cls._as_array(second)
+                    r1.append(sec)
+                    l1.append(a)
+                    rpa1.append(sec.shape[0])
+            if need_ref and segment is not None:
                 seg = _to_u8(segment, "ref_segment")
                 refs.append(seg.reshape(-1, seg.shape[-2], seg.shape[-1])[0])
-        reads0 = np.concatenate(r0, axis=0)
+        reads0 = cls._bytes_of(r0, [f"allele {a!r}" for a in l0])
         # like the reference (MixtureOfExpertsAdvanced.py:511-516): a missing second tensor anywhere
         # means "no second technology"
         complete = len(r1) == len(r0)
-        reads1 = np.concatenate(r1, axis=0) if (r1 and complete) else None
-        ref = np.stack(refs, axis=0) if len(refs) == len(sites) else None
+        reads1 = cls._bytes_of(r1, [f"allele {a!r} (second technology)" for a in l1]) if (r1 and complete) else None
+        ref = np.stack(refs, axis=0) if (refs and len(refs) == len(sites)) else None
         return (reads0, np.asarray(rpa0, np.int32), reads1,
                 np.asarray(rpa1, np.int32) if reads1 is not None else None,
                 np.asarray(aps, np.int32), ref, names)
@@ -133,8 +174,8 @@ class ScoringNetwork:
         """Score many sites in ONE engine launch; returns one result per site, in order, each shaped
         exactly like the reference's per-site return value."""
         import torch
-        reads0, rpa0, reads1, rpa1, aps, ref, names = self._pack(sites)
         eng = self.engine
+        reads0, rpa0, reads1, rpa1, aps, ref, names = self._pack(sites, need_ref=bool(eng.program.uses_ref))
         if eng.program.channels1 and reads1 is None:
             raise ValueError("this model scores two read technologies: every allele needs both tensors")
         logits, meta, post = eng.forward(reads0, rpa0, aps, reads1 if eng.program.channels1 else None,
@@ -148,7 +189,7 @@ class ScoringNetwork:
             rows = [dict(zip(keys, scalars[r][col:col + n])) for r in range(4)]
             col += n
             if self.providePredictions:
-                m = torch.from_numpy(meta[s].copy()) if eng.has_meta else torch.tensor([1.0, 0.0, 0.0])
+                m = torch.from_numpy(meta[s].copy()) if eng.has_meta else _SINGLE_EXPERT_META.clone()
                 results.append((rows[0], rows[1], rows[2], rows[3], m))
             else:
                 results.append(rows[0])
