@@ -3,7 +3,10 @@
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): Illumina 30x single-tech model
 (moe_attention_config_single_tech_old_equivalent_weight_norm), >= 1 M synthetic candidate sites from the
-seeded generator, seeded synthetic weights.
+seeded generator, seeded synthetic weights.  ``--config {C2,C3,C4,C5,hybrid_full}`` makes any other BASELINE.json
+configuration the timed region (same path, any N); the default (C2) run also reports C3, C4, C5 and hybrid_full in a
+``configs`` block: host-to-host rate at ``--sites`` sites per launch over ``--config-launches`` launches, the read convolver's
+roofline fraction from the engine's HIP events, and max |delta| against the oracle's per-site answers on 96 check sites.
 
 ``value`` is SURVEY.md 8d metric (1): host-resident uint8 pileups + CSR counts -> host-resident allele logits
 AND genotype-pair posteriors, PCIe both ways included, through the product's own feed
@@ -24,15 +27,18 @@ With N > 1 (one process per GPU under torch.distributed.run) the global step bat
 (``--scaling weak``, the default) or the same ``--launches-per-step`` launches cut N ways (``--scaling strong``:
 the fixed 1.64 M-site stream of the N = 1 run); every rank computes the same read-balanced site partition from
 the shared counts, pins and feeds ONLY its range through its own pipeline (host threads on CPUs near its GPU) and
-keeps its logits resident; ONE RCCL gather at the end of the run brings every rank's logits to rank 0, inside the
-timed region.
+keeps its logits (and, for ensemble models, its per-site meta weights) resident; ONE RCCL gather at the end of the run
+brings every rank's results to rank 0, inside the timed region.
 
 At N > 1 the line also carries the run's audit trail, collected with one ``all_gather_object`` AFTER the closing fence:
-``ranks`` (per rank: device index, PCI address, UUID, sites, reads, own seconds, launches, pinned bytes, CPUs), ``distinct_devices``,
-``backend``, ``gather_ms`` (two events around the one gather), ``slowest_rank``, ``balance`` = min / max reads per rank; and with
-``--scaling both`` (the default) ``strong_scaling``: a second timed region of the same K steps over the N = 1 stream cut N ways.
+``ranks`` (per rank: device index, PCI address, UUID, sites, reads, own seconds, launches, pinned bytes, CPUs, ``own_checksum`` of the
+columns it produced), ``distinct_devices``, ``backend``, ``gather_ms`` (two events around the one gather), ``slowest_rank``,
+``balance`` = min / max reads per rank, ``gather_verified_ranks`` = the number of ranks whose own checksum equals the checksum of
+what rank 0 received for them (the gather proves itself; the run fails when it is not N); and with ``--scaling both`` (the
+default) ``strong_scaling``: a second timed region of the same K steps over the N = 1 stream cut N ways.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S] [--launches-per-step B] [--scaling weak|strong|both]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5|hybrid_full] [--sites S] [--launches-per-step B]
+                    [--scaling weak|strong|both]
 """
 import argparse
 import json
@@ -50,12 +56,139 @@ HBM_PEAK_GBS = 8000.0
 PARITY_SITES = 96
 
 
-def site_flops(spec, batch):
-    """Algorithmic FLOPs of one batch (2 * MAC; dead site-level compressor excluded)."""
-    from hello_amd import netspec as ns
-    per_read = 2 * ns.macs(spec.nets["read_convolver0"], spec.window)
-    per_allele = 2 * (ns.macs(spec.nets["compressor0"], 36) + ns.macs(spec.nets["xattn0"], 18))
-    return per_read * batch.reads0.shape[0] + per_allele * batch.n_alleles, per_read, per_allele
+# BASELINE.json's configurations (SURVEY.md 8d "Concrete configs"): the model + the synthetic generator's arguments, exactly as
+# tests/test_gpu_fullsize.py builds them.  C2 is the headline (BASELINE.json configs[1], the configuration `metric` is quoted on);
+# hybrid_full is not a BASELINE config: it is here because its `meta` mixing weights cross the gather (three experts + meta).
+BENCH_CONFIGS = {
+    "C2": dict(spec="single_tech", sites=dict(coverage=30),
+               label="Illumina 30x single-tech model (moe_attention single_tech weight_norm), synthetic pileups cov 30"),
+    "C3": dict(spec="single_tech", sites=dict(coverage=(8, 52), tech="pacbio", max_reads=128),
+               label="PacBio HiFi single-tech model, long-window pileups, coverage U{8..52}, <= 128 reads per site"),
+    "C4": dict(spec="hybrid_no_ensemble", sites=dict(coverage=30, hybrid_coverage=15),
+               label="hybrid Illumina 30x + PacBio 15x no-ensemble model (moe_attention full_hybrid weight_norm no_ensemble: two read "
+                     "convolvers, combiners, one expert)"),
+    "C5": dict(spec="single_tech_hp", sites=dict(coverage=(20, 80), channels=7, tech="pacbio"),
+               label="PacBio haplotagged model (7 channels: read_convolver_with_hp_channel), mixed coverage U{20..80}, ragged CSR packing"),
+    "hybrid_full": dict(spec="hybrid_full", sites=dict(coverage=30, hybrid_coverage=15),
+                        label="full hybrid Illumina 30x + PacBio 15x model (three experts + meta mixing weights)"),
+}
+SECONDARY_CONFIGS = ("C3", "C4", "C5", "hybrid_full")
+
+
+def make_config_sites(name, n_sites, seed):
+    from hello_amd import synth
+    return synth.make_sites(n_sites, seed=seed, **BENCH_CONFIGS[name]["sites"])
+
+
+def _rows_of(op, batch):
+    """Rows one op of a compiled program walks over, for a batch (reads of the op's technology / alleles / sites)."""
+    from hello_amd import compiler
+    if op.kind == compiler.OP_READCONV_FUSED:
+        return int(batch.reads0.shape[0]) if op.seg == compiler.SEG_R0A else (0 if batch.reads1 is None else int(batch.reads1.shape[0]))
+    return {compiler.ROWS_READS0: int(batch.reads0.shape[0]), compiler.ROWS_READS1: 0 if batch.reads1 is None else int(batch.reads1.shape[0]),
+            compiler.ROWS_ALLELES: batch.n_alleles, compiler.ROWS_SITES: batch.n_sites}[op.domain]
+
+
+def program_flops(program, batch):
+    """-> (algorithmic FLOPs of one batch: 2 * direct-form MAC of every op the engine runs -- SURVEY 8d's per-read / per-allele /
+    per-site figures, dead site-level compressor excluded --, FLOPs the matrix instructions execute: Winograd forms counted as run)."""
+    alg = sum(2.0 * op.macs_per_row * _rows_of(op, batch) for op in program.ops)
+    exe = sum(2.0 * (op.exec_macs_per_row or op.macs_per_row) * _rows_of(op, batch) for op in program.ops)
+    return alg, exe
+
+
+def batch_input_bytes(batch):
+    """Algorithmic input bytes of one batch: the uint8 pileups of both technologies (R * L * C)."""
+    n = int(np.prod(batch.reads0.shape))
+    return n + (0 if batch.reads1 is None else int(np.prod(batch.reads1.shape)))
+
+
+def feature_dicts(batch):
+    """A SiteBatch as the per-site call's arguments: [(featureDict {allele: (float [R, L, C], float [R', L, C] | None)}, segment)]
+    (caller_calling.py:631-649)."""
+    from hello_amd import synth
+    names = synth.allele_names(batch)
+    aoff = np.concatenate([[0], np.cumsum(batch.alleles_per_site)])
+    roff0 = np.concatenate([[0], np.cumsum(batch.reads_per_allele0)])
+    roff1 = None if batch.reads1 is None else np.concatenate([[0], np.cumsum(batch.reads_per_allele1)])
+    out = []
+    for s in range(batch.n_sites):
+        fd = {}
+        for k, a in enumerate(range(aoff[s], aoff[s + 1])):
+            second = None if roff1 is None else batch.reads1[roff1[a]:roff1[a + 1]].astype(np.float32)
+            fd[names[s][k]] = (batch.reads0[roff0[a]:roff0[a + 1]].astype(np.float32), second)
+        out.append((fd, batch.ref_onehot[s:s + 1].astype(np.float32)))
+    return out
+
+
+def _oracle_answers_worker(job):
+    """One worker of the reference-answer pool: sites [lo, hi) of a configuration's check batch through oracle/moe_oracle.py, ONE
+    SITE PER CALL (the reference's per-site form, MixtureOfExpertsAdvanced.py:520-589).  -> (lo, probabilities [E, A_part],
+    meta [S_part, 3] | None, posteriors [4, P_part])."""
+    name, seed, n_sites, lo, hi = job
+    import torch
+    torch.set_num_threads(1)
+    try:                                    # NumPy's BLAS threads too: one worker per core, not cores x cores threads
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    from hello_amd import netspec as ns, weights
+    from oracle import moe_oracle as mo
+    spec = ns.build(BENCH_CONFIGS[name]["spec"])
+    oracle = mo.Oracle(spec, weights.synth_state(spec, seed=seed))            # NumPy back end: the independent restatement
+    sub = make_config_sites(name, n_sites, seed + 4242).site_slice(lo, hi)
+    logits, meta = mo.forward_batch(oracle, sub, chunk_sites=1)
+    probs = mo.sigmoid(logits)
+    aoff = np.concatenate([[0], np.cumsum(sub.alleles_per_site)])
+    post = []
+    for s in range(sub.n_sites):
+        p = [probs[e, aoff[s]:aoff[s + 1]] for e in range(probs.shape[0])]
+        if len(p) == 1:                     # single-expert models: experts [e0, 0, 0], meta [1, 0, 0]  (:530-538)
+            p, m = p + [np.zeros_like(p[0])] * 2, np.array([1, 0, 0], np.float32)
+        else:
+            m = meta[s]
+        post.append(np.stack(mo.posteriors(p, m)))
+    return lo, probs, meta, np.concatenate(post, axis=1)
+
+
+def oracle_answers(names, seed, n_sites=96):
+    """What the CPU oracle answers on ``n_sites`` seeded check sites of each configuration (the other half of BASELINE.json's
+    metric: max |delta| vs the CPU reference).  A pool of single-threaded workers forked BEFORE this process touches the GPU.
+    -> {name: (check batch, probabilities [E, A], meta | None, posteriors [4, P])}."""
+    import multiprocessing as mp
+    cores = host_cores()
+    cut = max(1, min(cores, 8))
+    jobs = []
+    for name in names:
+        edges = np.linspace(0, n_sites, cut + 1).astype(int)
+        jobs += [(name, seed, n_sites, int(a), int(b)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+    with mp.get_context("fork").Pool(min(cores, len(jobs))) as workers:
+        parts = workers.map(_oracle_answers_worker, jobs)
+    out = {}
+    for name in names:
+        mine = sorted((p for j, p in zip(jobs, parts) if j[0] == name), key=lambda p: p[0])
+        meta = None if mine[0][2] is None else np.concatenate([p[2] for p in mine], axis=0)
+        out[name] = (make_config_sites(name, n_sites, seed + 4242), np.concatenate([p[1] for p in mine], axis=1), meta,
+                     np.concatenate([p[3] for p in mine], axis=1))
+    return out
+
+
+def parity_of(engine, answers):
+    """The engine's answers on a configuration's check sites against the oracle's: max |delta| of sigmoid(logit) over every expert,
+    of the meta weights, and of every genotype-pair posterior row the model produces (tolerance 1e-4, BASELINE.json north_star)."""
+    check, want_probs, want_meta, want_post = answers
+    got_logits, got_meta, got_post = engine.forward_batch(check, posteriors=True)
+    got_probs = 1.0 / (1.0 + np.exp(-got_logits.astype(np.float64)))
+    rows = 4 if engine.n_experts > 1 else 1          # single-expert models: the mixture row IS expert 0's
+    out = {"max_abs_delta_allele_probability": float(np.abs(got_probs - want_probs).max()),
+           "max_abs_delta_pair_posterior": float(np.abs(got_post[:rows] - want_post[:rows]).max()),
+           "tolerance": 1e-4, "sites": int(check.n_sites), "alleles": int(check.n_alleles), "experts": int(engine.n_experts),
+           "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
+    if want_meta is not None:
+        out["max_abs_delta_meta"] = float(np.abs(got_meta - want_meta).max())
+    out["within_tolerance"] = bool(max(v for k, v in out.items() if k.startswith("max_abs_delta")) <= 1e-4)
+    return out
 
 
 def host_cores():
@@ -79,68 +212,50 @@ def host_cores():
 def _per_site_worker(job):
     """One worker process of the reference's deployment form (call.py:26-30,111,215-221): torch on ONE
     thread, one site per call through the per-site wrapper.  -> (sites scored, seconds)."""
-    seed, worker, budget_s = job
+    config, seed, worker, budget_s = job
     import torch
     torch.set_num_threads(1)
-    from hello_amd import netspec as ns, synth, weights
+    from hello_amd import netspec as ns, weights
     from oracle import moe_oracle as mo
-    spec = ns.build("single_tech")
+    spec = ns.build(BENCH_CONFIGS[config]["spec"])
     wrapper = mo.WrapperOracle(spec, weights.synth_state(spec, seed=seed), backend="torch")
-    sample = synth.make_sites(48, seed=seed + 999 + worker, coverage=30)
-    names = synth.allele_names(sample)
-    aoff = np.concatenate([[0], np.cumsum(sample.alleles_per_site)])
-    roff = np.concatenate([[0], np.cumsum(sample.reads_per_allele0)])
-
-    def score(s):
-        fd = {names[s][k]: (sample.reads0[roff[a]:roff[a + 1]].astype(np.float32), None)
-              for k, a in enumerate(range(aoff[s], aoff[s + 1]))}
-        wrapper(fd, sample.ref_onehot[s:s + 1].astype(np.float32))
-
-    score(0)                                                           # warm
+    calls = feature_dicts(make_config_sites(config, 48, seed + 999 + worker))
+    wrapper(*calls[0])                                                 # warm
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
-        score(n % sample.n_sites)
+        wrapper(*calls[n % len(calls)])
         n += 1
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(seed, budget_s=12.0):
+def cpu_baseline(seed, budget_s=12.0, config="C2"):
     """The CPU oracle (torch-CPU conv back end = the reference's own third-party kernels) on a bounded sample
     of the same workload, in the reference's deployment form: one single-threaded worker process per usable
     host core, one site per call.  The batched all-threads form is reported beside it.  Must run before this
     process touches the GPU (it forks)."""
     import multiprocessing as mp
     import torch
-    from hello_amd import netspec as ns, synth, weights
+    from hello_amd import netspec as ns, weights
     from oracle import moe_oracle as mo
     cores = host_cores()
     with mp.get_context("fork").Pool(cores) as workers:
-        res = workers.map(_per_site_worker, [(seed, w, budget_s) for w in range(cores)])
+        res = workers.map(_per_site_worker, [(config, seed, w, budget_s) for w in range(cores)])
     rate = sum(n / dt for n, dt in res)
     done_sites = sum(n for n, _ in res)
 
-    spec = ns.build("single_tech")
+    spec = ns.build(BENCH_CONFIGS[config]["spec"])
     torch.set_num_threads(cores)
     oracle = mo.Oracle(spec, weights.synth_state(spec, seed=seed), backend="torch")
     chunk = 64
-    sample = synth.make_sites(chunk * 8, seed=seed + 999, coverage=30)
+    sample = make_config_sites(config, chunk * 8, seed + 999)
     mo.forward_batch(oracle, sample.site_slice(0, 8), chunk_sites=8)      # warm
     done, t0 = 0, time.perf_counter()
     while done < sample.n_sites and time.perf_counter() - t0 < budget_s / 2:
         mo.forward_batch(oracle, sample.site_slice(done, done + chunk), chunk_sites=chunk)
         done += chunk
     dt = time.perf_counter() - t0
-    # the other half of BASELINE.json's metric: what the CPU path answers on a fixed sample, kept aside for
-    # the comparison with the engine's answers on the same sites (``parity`` in the JSON line)
-    check = synth.make_sites(PARITY_SITES, seed=seed + 4242, coverage=30)
-    want_logits, _ = mo.forward_batch(mo.Oracle(spec, weights.synth_state(spec, seed=seed)), check, chunk_sites=1)
-    aoff = np.concatenate([[0], np.cumsum(check.alleles_per_site)])
-    probs = mo.sigmoid(want_logits[0])
-    want_post = np.concatenate([mo.posteriors([probs[aoff[s]:aoff[s + 1]]] + [np.zeros(aoff[s + 1] - aoff[s], np.float32)] * 2,
-                                              np.array([1, 0, 0], np.float32))[0] for s in range(check.n_sites)])
-    cpu_baseline.reference_answers = (check, probs, want_post)
-    return {"value": round(rate, 2), "unit": "sites/s", "cores": int(cores), "kind": "port",
-            "sample": f"{done_sites} synthetic sites (cov 30) in {budget_s:.0f} s: {cores} single-threaded worker "
+    return {"value": round(rate, 2), "unit": "sites/s", "cores": int(cores), "kind": "port", "config": config,
+            "sample": f"{done_sites} synthetic sites of {config} in {budget_s:.0f} s: {cores} single-threaded worker "
                       f"processes, one site per call through oracle/moe_oracle.py's per-site wrapper (the "
                       f"reference's deployment form, call.py:26-30,111), torch-CPU conv back end",
             "per_core": round(rate / cores, 2),
@@ -212,14 +327,21 @@ def launch_ranks(gpus, argv):
 
 
 def lib_sha256():
-    """sha256 of the HIP library this run loads (the file hello_amd.engine opens): ties `roofline.traffic` to the binary the
-    committed PMC passes profiled (profiles/hbm_traffic.json records the same hash, tools/profile_round.sh)."""
+    """sha256 of the HIP library this run LOADED -- the file hello_amd.engine opened (HELLO_LIB when it is set: the kernel A/B case
+    this guard exists for), never a path assumed here: ties `roofline.traffic` to the binary the committed PMC passes profiled
+    (profiles/hbm_traffic.json records the same hash, tools/profile_round.sh).  None when the file cannot be read: the traffic is
+    then reported as stale instead of the measurement being lost after the run."""
     import hashlib
-    h = hashlib.sha256()
-    with open(os.path.join(ROOT, "hello_amd", "libhello_mi355x.so"), "rb") as fh:
-        for chunk in iter(lambda: fh.read(1 << 20), b""):
-            h.update(chunk)
-    return h.hexdigest()
+    try:
+        from hello_amd import engine
+        h = hashlib.sha256()
+        with open(engine._LIB_PATH, "rb") as fh:
+            for chunk in iter(lambda: fh.read(1 << 20), b""):
+                h.update(chunk)
+        return h.hexdigest()
+    except Exception as exc:
+        print(f"bench: could not hash the loaded library: {exc!r}", file=sys.stderr)
+        return None
 
 
 def committed_traffic(path, loaded_sha):
@@ -247,11 +369,61 @@ def committed_traffic(path, loaded_sha):
     return tjson.get("bytes_per_launch"), forward, prov
 
 
+def checksum(columns):
+    """What a rank says about the float32 columns it produced, and what rank 0 says about the columns it received for that rank: the
+    two must be EQUAL (same bytes -> same crc32; the sums are float64 over the same values in the same order)."""
+    import zlib
+    x = np.ascontiguousarray(columns, dtype=np.float32)
+    flat = x.reshape(-1)
+    return {"n": int(flat.size), "crc32": int(zlib.crc32(flat.tobytes())), "sum": float(flat.sum(dtype=np.float64)),
+            "abs_sum": float(np.abs(flat).sum(dtype=np.float64)), "first": float(flat[0]) if flat.size else None,
+            "last": float(flat[-1]) if flat.size else None}
+
+
+def to_device(batch, dev):
+    """A SiteBatch whose pileups (and reference one-hot) are resident on ``dev``."""
+    import torch
+    from hello_amd.synth import SiteBatch
+    t = lambda x: None if x is None else (x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))).to(dev)   # noqa: E731
+    return SiteBatch(t(batch.reads0), batch.reads_per_allele0, batch.alleles_per_site, t(batch.ref_onehot), t(batch.reads1),
+                     batch.reads_per_allele1)
+
+
+def device_outputs(eng, batch, dev):
+    """Preallocated (logits, meta | None, posteriors) device tensors of one batch."""
+    import torch
+    from hello_amd.engine import n_pairs
+    f32 = dict(dtype=torch.float32, device=dev)
+    return (torch.empty((eng.n_experts, batch.n_alleles), **f32), torch.empty((batch.n_sites, 3), **f32) if eng.has_meta else None,
+            torch.empty((4, n_pairs(batch.alleles_per_site)), **f32))
+
+
+def readconv_roofline(eng, op_rows, batches):
+    """The dominant kernel of a forward, priced from the engine's per-op HIP events: every fused read-convolver op of the program (one
+    per read technology) -- or, in a program without one, the slowest op.  -> dict(kernel, launch_ms = mean device ms per forward
+    summed over those ops, algorithmic / executed FLOPs per forward, ops)."""
+    from hello_amd import compiler
+    ops = eng.program.ops
+    index = [i for i, o in enumerate(ops) if o.kind == compiler.OP_READCONV_FUSED]
+    if not index:
+        index = [max(range(len(op_rows)), key=lambda i: op_rows[i][2])]
+    ms = sum(op_rows[i][2] for i in index)
+    rows = lambda o: float(np.mean([_rows_of(o, b) for b in batches]))                                          # noqa: E731
+    alg = sum(2.0 * ops[i].macs_per_row * rows(ops[i]) for i in index)
+    exe = sum(2.0 * (ops[i].exec_macs_per_row or ops[i].macs_per_row) * rows(ops[i]) for i in index)
+    fusedk = ops[index[0]].kind == compiler.OP_READCONV_FUSED
+    return dict(kernel="readconv_kernel" if fusedk else op_rows[index[0]][0], fused=fusedk, launch_ms=ms, flops=alg, exec_flops=exe,
+                n_ops=len(index), rows=sum(rows(ops[i]) for i in index))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(BENCH_CONFIGS), default="C2",
+                    help="which BASELINE.json configuration the timed region runs (default C2 = configs[1], the one `metric` is "
+                         "quoted on); the default run also reports C3, C4, C5 and hybrid_full in its `configs` block")
     ap.add_argument("--sites", type=int, default=8192, help="candidate sites per engine launch")
     ap.add_argument("--launches-per-step", type=int, default=10,
                     help="launches of --sites sites that make one step's batch on one GPU (10 x 8192 = 81 920 sites: "
@@ -260,7 +432,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of the CPU baseline's per-site leg (its batched leg takes half)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the device-resident, latency, small-batch and parity legs (headline only)")
+                    help="skip the device-resident, latency, small-batch, parity and other-configuration legs (headline only)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configurations)")
+    ap.add_argument("--config-launches", type=int, default=40, help="timed launches of each configuration of the `configs` block")
     ap.add_argument("--fused", choices=["full", "trunk", "none"], default="full",
                     help="read convolver: one fused kernel from the bytes / layer-by-layer stem + fused trunk / "
                          "layer by layer")
@@ -272,6 +446,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--op-times", action="store_true", help="print per-op device times to stderr")
     args = ap.parse_args()
+    cfg = BENCH_CONFIGS[args.config]
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not under_launcher:
@@ -281,24 +456,35 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    # CPU baseline first, on rank 0 at every N: it forks worker processes, which must happen before this process touches the
-    # GPU (and is skipped under a profiler, whose preloaded library has initialised the GPU already).  At N > 1 the other
-    # ranks are blocked in the rendezvous below while it runs (no engine, no feeder threads yet), so it has the host to
-    # itself exactly as at N = 1 and is over before any timed region starts.
+    # CPU work first, on rank 0 at every N: the baseline and the oracle's reference answers fork worker processes, which must
+    # happen before this process touches the GPU (and is skipped under a profiler, whose preloaded library has initialised the
+    # GPU already).  At N > 1 the other ranks are blocked in the rendezvous below while it runs (no engine, no feeder threads
+    # yet), so it has the host to itself exactly as at N = 1 and is over before any timed region starts.
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    cpu = None
-    if rank == 0 and not args.no_cpu_baseline and not profiled:
-        try:
-            cpu = cpu_baseline(args.seed, budget_s=args.cpu_budget)
-            if world > 1:
-                cpu["when"] = f"on rank 0 before the {world}-rank rendezvous (the other ranks wait idle in it)"
-        except Exception as exc:           # the GPU measurement must not be lost to a host-side hiccup (fork limits ...)
-            print(f"cpu baseline failed: {exc!r}", file=sys.stderr)
-            cpu = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}
+    secondary = world == 1 and not args.no_secondary
+    other_configs = [c for c in SECONDARY_CONFIGS if c != args.config] if (secondary and args.config == "C2" and not args.no_configs) else []
+    cpu, answers = None, {}
+    if rank == 0 and not profiled:
+        if not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(args.seed, budget_s=args.cpu_budget, config=args.config)
+                if world > 1:
+                    cpu["when"] = f"on rank 0 before the {world}-rank rendezvous (the other ranks wait idle in it)"
+            except Exception as exc:           # the GPU measurement must not be lost to a host-side hiccup (fork limits ...)
+                print(f"cpu baseline failed: {exc!r}", file=sys.stderr)
+                cpu = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}
+        if secondary:
+            try:
+                t_or = time.perf_counter()
+                answers = oracle_answers([args.config] + other_configs, args.seed, n_sites=PARITY_SITES)
+                print(f"bench: oracle answers on {PARITY_SITES} check sites of {', '.join(answers)} in {time.perf_counter() - t_or:.1f} s",
+                      file=sys.stderr)
+            except Exception as exc:
+                print(f"oracle reference answers failed: {exc!r}", file=sys.stderr)
 
     import torch
-    from hello_amd import netspec as ns, shard, synth, weights
-    from hello_amd.engine import Engine, n_pairs
+    from hello_amd import netspec as ns, shard, weights
+    from hello_amd.engine import Engine
     from hello_amd.pipeline import HostPipeline, pin_batch
 
     if world != args.gpus:
@@ -332,7 +518,7 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
-    spec = ns.build("single_tech")
+    spec = ns.build(cfg["spec"])
     state = weights.synth_state(spec, seed=args.seed)
     # the headline is exact fp32 and says so from the engine's own record of what it computes in (never from a literal)
     eng = Engine(spec, state, device=dev_index, fused={"full": True, "trunk": "trunk", "none": False}[args.fused], arithmetic="fp32")
@@ -340,7 +526,7 @@ def main():
         raise SystemExit(f"the headline engine computes in {eng.program.arithmetic!r}: `value` / dtype 'f32' are exact fp32 only")
 
     # ---- the pinned host pool (the same seeded batches on every rank: one global site stream) ---------------
-    pool = [synth.make_sites(args.sites, seed=1000 + i + args.seed, coverage=30) for i in range(args.pool)]
+    pool = [make_config_sites(args.config, args.sites, 1000 + i + args.seed) for i in range(args.pool)]
     counts = [dict(reads_per_site=shard.reads_per_site(b), alleles_per_site=b.alleles_per_site) for b in pool]
     pipe = HostPipeline(eng, depth=2, posteriors=True)
     pinned_cache = {}
@@ -361,6 +547,9 @@ def main():
 
     identity = shard.device_identity(dev_index)
 
+    def n_reads(b):
+        return int(b.reads0.shape[0]) + (0 if b.reads1 is None else int(b.reads1.shape[0]))
+
     def timed_region(mode, profile):
         """W untimed + exactly K timed steps of this rank's share of the global step batch under ``mode`` (weak | strong),
         fenced on both sides, results harvested to host and -- at N > 1 -- gathered to rank 0 inside the region.
@@ -370,24 +559,28 @@ def main():
         piece_batches = [pinned(k, lo, hi) for k, lo, hi in pieces]
         step_sites = sum(hi - lo for _, lo, hi in pieces)
         step_alleles = sizes[rank][1]
-        step_reads = sum(int(b.reads0.shape[0]) for b in piece_batches)
+        step_reads = sum(n_reads(b) for b in piece_batches)
         assert step_sites == sizes[rank][0] and step_alleles == sum(int(b.n_alleles) for b in piece_batches)
-        # a rank's logits of the whole run stay resident for the single gather at the end
-        sink = (torch.zeros((eng.n_experts, max(args.steps, 1) * max(step_alleles, 1)), dtype=torch.float32, device=dev)
-                if dist is not None else None)
+        # a rank's logits (and meta weights) of the whole run stay resident for the single gather at the end
+        sink = sink_meta = None
+        if dist is not None:
+            sink = torch.zeros((eng.n_experts, max(args.steps, 1) * max(step_alleles, 1)), dtype=torch.float32, device=dev)
+            if eng.has_meta:
+                sink_meta = torch.zeros((max(args.steps, 1) * max(step_sites, 1), 3), dtype=torch.float32, device=dev)
 
         def run_steps(n_steps, keep):
             """n_steps passes over this rank's pieces through the pipeline; every result is harvested to host
             memory before this returns.  -> number of launches harvested."""
-            harvested, col = 0, 0
+            harvested, col, row = 0, 0, 0
             for s in range(n_steps):
                 for p, b in enumerate(piece_batches):
-                    snk = (sink, None, col, 0) if (sink is not None and keep is not None) else None
+                    snk = (sink, sink_meta, col, row) if (sink is not None and keep is not None) else None
                     for item in pipe.submit(b, tag=(s, p), sink=snk):
                         harvested += 1
                         if keep is not None:
                             keep.append(item)
                     col += int(b.n_alleles)
+                    row += int(b.n_sites)
             for item in pipe.flush():
                 harvested += 1
                 if keep is not None:
@@ -403,9 +596,9 @@ def main():
         t0 = time.perf_counter()
         harvested = run_steps(args.steps, results)
         t_scored = time.perf_counter()
-        gathered, gather_ms, gather_host_ms = None, None, None
+        gathered, gathered_meta, gather_ms, gather_host_ms = None, None, None, None
         if dist is not None:
-            # the one collective of the path: every rank's logits of the run -> rank 0, then to its host.
+            # the one collective of the path: every rank's logits (+ meta) of the run -> rank 0, then to its host.
             # Timed with two events on the current stream (RCCL orders its work with it) and with the host clock.
             run_sizes = [(s * args.steps, a * args.steps) for s, a in sizes]
             ev0 = ev1 = None
@@ -413,11 +606,14 @@ def main():
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
             g0 = time.perf_counter()
-            gathered, _ = shard.gather_results(sink, None, run_sizes, eng.n_experts, False, dst=0)
+            own_sites, own_alleles = run_sizes[rank]
+            gathered, gathered_meta = shard.gather_results(sink[:, :own_alleles], None if sink_meta is None else sink_meta[:own_sites],
+                                                           run_sizes, eng.n_experts, eng.has_meta, dst=0)
             if ev1 is not None:
                 ev1.record()
             if gathered is not None:
                 gathered = gathered.cpu()
+                gathered_meta = None if gathered_meta is None else gathered_meta.cpu()
             if ev1 is not None:
                 ev1.synchronize()
                 gather_ms = float(ev0.elapsed_time(ev1))
@@ -436,57 +632,82 @@ def main():
                       launches=int(n_launches), timed_seconds=round(own_dt, 6), scored_seconds=round(t_scored - t0, 6),
                       gather_ms=None if gather_ms is None else round(gather_ms, 4),
                       gather_host_ms=None if gather_host_ms is None else round(gather_host_ms, 4),
-                      pinned_input_bytes=int(sum(int(b.reads0.numel()) for b in {id(b): b for b in piece_batches}.values())),
+                      pinned_input_bytes=int(sum(batch_input_bytes(b) for b in {id(b): b for b in piece_batches}.values())),
                       cpus_pinned=len(cpus), cpu_list=shard_cpu_ranges(cpus))
         return dict(mode=mode, dt=dt, value=sites_total / dt, sites_total=sites_total, sizes=sizes, pieces=pieces,
-                    piece_batches=piece_batches, results=results, gathered=gathered, n_launches=n_launches, report=report,
-                    gather_ms=gather_ms, gather_host_ms=gather_host_ms)
+                    piece_batches=piece_batches, results=results, gathered=gathered, gathered_meta=gathered_meta, n_launches=n_launches,
+                    report=report, gather_ms=gather_ms, gather_host_ms=gather_host_ms)
+
+    def check_run(r):
+        """Every pass over a pool batch must reproduce its first result bit for bit, and rank 0's own columns of the gathered logits
+        (and rows of the gathered meta weights) must be its own results (checked outside the timed region).  Every rank puts the
+        checksum of the columns IT produced into its report (`own_checksum`); rank 0 keeps the checksums of the columns it RECEIVED
+        for every rank (`received_checksums`): after the reports are collected the two are compared rank by rank
+        (`gather_verified_ranks`).  Drops the run's host results.  -> (drift, finite)."""
+        res, got, got_meta = r.pop("results"), r.pop("gathered"), r.pop("gathered_meta")
+        first, bad = {}, 0
+        for (s_, p), logits, meta, post in res:
+            if p not in first:
+                first[p] = (logits, meta, post)
+            elif not (np.array_equal(logits, first[p][0]) and np.array_equal(post, first[p][2])
+                      and (meta is None or np.array_equal(meta, first[p][1]))):
+                bad += 1
+        mine = np.concatenate([lg for _, lg, _, _ in res], axis=1) if res else np.zeros((eng.n_experts, 0), np.float32)
+        mine_meta = (np.concatenate([m for _, _, m, _ in res], axis=0) if res else np.zeros((0, 3), np.float32)) if eng.has_meta else None
+        r["report"]["own_checksum"] = {"logits": checksum(mine), "meta": None if mine_meta is None else checksum(mine_meta)}
+        if got is not None:
+            bad += 0 if np.array_equal(got[:, :mine.shape[1]].numpy(), mine) else 1
+            if got_meta is not None:
+                bad += 0 if np.array_equal(got_meta[:mine_meta.shape[0]].numpy(), mine_meta) else 1
+            received, col, row = [], 0, 0
+            for s, a in r["sizes"]:
+                s, a = s * args.steps, a * args.steps
+                received.append({"logits": checksum(got[:, col:col + a].numpy()),
+                                 "meta": None if got_meta is None else checksum(got_meta[row:row + s].numpy())})
+                col, row = col + a, row + s
+            r["received_checksums"] = received
+        ok = all(np.isfinite(lg).all() and np.isfinite(po).all() for _, lg, _, po in res[:len(r["piece_batches"])])
+        return bad, ok
+
+    def verify_gather(r, reports):
+        """-> number of ranks whose own checksum equals the checksum of what rank 0 received for them (None without a gather)."""
+        received = r.get("received_checksums")
+        if received is None:
+            return None
+        by_rank = {int(x.get("rank", 0)): x.get("own_checksum") for x in reports}
+        return int(sum(1 for k, rc in enumerate(received) if by_rank.get(k) == rc))
 
     headline_mode = "strong" if args.scaling == "strong" else "weak"
     run = timed_region(headline_mode, profile=True)
     dt, value, sizes, pieces, piece_batches = run["dt"], run["value"], run["sizes"], run["pieces"], run["piece_batches"]
-    results, gathered, n_launches, sites_total = run["results"], run["gathered"], run["n_launches"], run["sites_total"]
+    n_launches, sites_total = run["n_launches"], run["sites_total"]
     pinned_bytes = run["report"]["pinned_input_bytes"]
 
     # ---- the dominant kernel's launch time over the timed region (HIP events on the launch stream) ---------
     op_rows, n_fw = eng.op_times_ms()
     eng.set_profiling(0)
     fused = eng.program.fused_read_convolver
-    dom_index = max(range(len(op_rows)), key=lambda i: op_rows[i][2])
-    dom_op = eng.program.ops[dom_index]
-    dom_ms = op_rows[dom_index][2]                                              # average launch duration
-    reads_per_launch = float(np.mean([b.reads0.shape[0] for b in piece_batches]))
-    rows_dom = reads_per_launch if dom_op.kind == 8 else float(np.mean([b.n_alleles for b in piece_batches]))
-    dom_flops = 2.0 * dom_op.macs_per_row * rows_dom                            # algorithmic FLOPs per launch
-    dom_exec = 2.0 * (dom_op.exec_macs_per_row or dom_op.macs_per_row) * rows_dom
+    dom = readconv_roofline(eng, op_rows, piece_batches)
+    dom_ms, dom_flops, dom_exec = dom["launch_ms"], dom["flops"], dom["exec_flops"]
+    reads_per_launch = float(np.mean([n_reads(b) for b in piece_batches]))
     algorithmic = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     executed = dom_exec / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    def check_run(r):
-        """Every pass over a pool batch must reproduce its first result bit for bit, and rank 0's own columns of the gathered
-        logits must be its own results (checked outside the timed region).  Drops the run's host results.  -> (drift, finite)."""
-        res, got = r.pop("results"), r.pop("gathered")
-        first, bad = {}, 0
-        for (s_, p), logits, meta, post in res:
-            if p not in first:
-                first[p] = (logits, post)
-            elif not (np.array_equal(logits, first[p][0]) and np.array_equal(post, first[p][1])):
-                bad += 1
-        if got is not None:
-            mine = np.concatenate([lg for _, lg, _, _ in res], axis=1) if res else np.zeros((eng.n_experts, 0), np.float32)
-            bad += 0 if np.array_equal(got[:, :mine.shape[1]].numpy(), mine) else 1
-        ok = all(np.isfinite(lg).all() and np.isfinite(po).all() for _, lg, _, po in res[:len(r["piece_batches"])])
-        return bad, ok
-    del results, gathered
     drift, finite = check_run(run)
 
     # HBM bytes from the committed PMC passes of the same command (profiles/hbm_traffic.json, tools/profile_round.sh): the
     # dominant kernel per launch (`traffic`, the contract's field) and EVERY kernel of the forward (`forward_traffic`) --
-    # reported only when that file was measured on THIS library (sha256 of the .so this process loaded), else null + stale
+    # reported only when that file was measured on THIS library (sha256 of the .so this process loaded) AND this configuration
+    # (the passes profile the default C2 run), else null + stale
     traffic, forward_traffic, traffic_prov = committed_traffic(os.path.join(ROOT, "profiles", "hbm_traffic.json"), lib_sha256())
-    flops_launch = float(np.mean([site_flops(spec, pool[k].site_slice(lo, hi))[0] for k, lo, hi in pieces]))
+    if args.config != "C2":
+        traffic, forward_traffic = None, None
+        traffic_prov["traffic_stale"] = True
+        traffic_prov["note"] = "the committed PMC passes profile the default configuration (C2)"
+    flops_launch = float(np.mean([program_flops(eng.program, pool[k].site_slice(lo, hi))[0] for k, lo, hi in pieces]))
     launch_s = dt / n_launches
+    per_read_macs = [o.macs_per_row for o in eng.program.ops if o.kind == 8]
     roofline = {
-        "bound": "mfma", "kernel": "readconv_kernel" if dom_op.kind == 8 else op_rows[dom_index][0],
+        "bound": "mfma", "kernel": dom["kernel"],
         # `achieved` = the FLOPs the matrix cores EXECUTE per launch / the kernel's average launch duration: the k3/s1
         # convolutions run in Winograd form (F(3,3): 5 instead of 9 fp32 contractions per 3 positions; F(2,3): 4
         # instead of 6 per 2), so the hardware fraction is priced on executed MFMA work and stays <= 1
@@ -496,37 +717,32 @@ def main():
         # the same launch priced on ALGORITHMIC work (direct-form 2 * MAC, SURVEY.md 8d: 10.152 MFLOP per read)
         "algorithmic_achieved": round(algorithmic, 3), "algorithmic_frac": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
         "formulas": {"frac": "2 * executed MAC per read * reads per launch / launch_ms / 157.3 TFLOP/s",
-                     "algorithmic_frac": "2 * 5 076 096 MAC per read * reads per launch / launch_ms / 157.3 TFLOP/s "
-                                         "(exceeds 1 because Winograd executes fewer MFMA FLOPs than the direct form)"},
-        # `launch` = one forward's run of the dominant kernel: since round 2 that is TWO launches of readconv_kernel (whole
-        # rounds of 8-group workgroups, then one-group workgroups: readconv_plan) followed by its small finalize kernel;
-        # launch_ms is the device time from the first launch's start to the finalize's end (two HIP events)
-        "launch_ms": round(dom_ms, 4), "launches_timed": int(n_fw), "kernel_launches_per_forward": 2 if dom_op.kind == 8 else 1,
+                     "algorithmic_frac": f"2 * {' | '.join(str(m) for m in per_read_macs) or 'direct-form'} MAC per read * reads per launch / launch_ms / "
+                                         "157.3 TFLOP/s (exceeds 1 because Winograd executes fewer MFMA FLOPs than the direct form)"},
+        # `launch` = one forward's run of the dominant kernel: since round 2 that is TWO launches of readconv_kernel per read
+        # technology (whole rounds of 8-group workgroups, then one-group workgroups: readconv_plan) followed by its small finalize
+        # kernel; launch_ms is the device time from the first launch's start to the finalize's end (two HIP events), summed over the
+        # model's read technologies
+        "launch_ms": round(dom_ms, 4), "launches_timed": int(n_fw), "kernel_launches_per_forward": 2 * dom["n_ops"] if dom["fused"] else 1,
         "reads_per_launch": round(reads_per_launch, 1),
         "flop_per_launch": float(dom_flops), "executed_flop_per_launch": float(dom_exec),
         "arithmetic": eng.program.arithmetic,          # the engine's own record, never a literal
         "form": "k3/s1 convolutions in Winograd form (residual trunk and allele stage F(3,3), stem F(2,3))" if eng.program.winograd else "direct form",
         "whole_launch_algorithmic_frac": round(flops_launch / launch_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-        "hbm_algorithmic_gbs": round((900.0 * reads_per_launch) / launch_s / 1e9, 3),
-        "pcie_h2d_gbs": round(float(np.mean([b.reads0.numel() for b in piece_batches])) / launch_s / 1e9, 3),
+        "hbm_algorithmic_gbs": round(float(np.mean([batch_input_bytes(b) for b in piece_batches])) / launch_s / 1e9, 3),
+        "pcie_h2d_gbs": round(float(np.mean([batch_input_bytes(b) for b in piece_batches])) / launch_s / 1e9, 3),
     }
 
-    device_resident = latency = small = parity = two_engines = bf16x3 = None
-    if world == 1 and not args.no_secondary:
+    device_resident = latency = small = parity = two_engines = bf16x3 = configs = None
+    if secondary:
         stream = torch.cuda.current_stream(dev).cuda_stream
         # ---- device-resident rate: pileups already in HBM, outputs left there (no PCIe in the loop) --------------
         try:
-            res = []
-            for b in pool[:2]:
-                a, p = b.n_alleles, n_pairs(b.alleles_per_site)
-                res.append(dict(batch=b, reads=torch.from_numpy(b.reads0).to(dev),
-                                out=(torch.empty((1, a), dtype=torch.float32, device=dev), None,
-                                     torch.empty((4, p), dtype=torch.float32, device=dev))))
+            res = [dict(batch=b, dev=to_device(b, dev), out=device_outputs(eng, b, dev)) for b in pool[:2]]
 
             def dstep(i):
                 r = res[i % len(res)]
-                eng.forward(r["reads"], r["batch"].reads_per_allele0, r["batch"].alleles_per_site, stream=stream,
-                            out=r["out"], posteriors=True)
+                eng.forward_batch(r["dev"], stream=stream, out=r["out"], posteriors=True)
             for i in range(3):
                 dstep(i)
             torch.cuda.synchronize(dev)
@@ -551,9 +767,8 @@ def main():
             r0 = res[0]["batch"]
             stage = [(op, ms) for op, (k, n, ms) in zip(eng.program.ops, rows) if op.kind != 8]
             stage_ms = sum(ms for _, ms in stage)
-            rows_of = {0: r0.reads0.shape[0], 2: r0.n_alleles, 3: r0.n_sites}
-            stage_exec = sum(2.0 * (op.exec_macs_per_row or op.macs_per_row) * rows_of.get(op.domain, 0) for op, _ in stage)
-            stage_alg = sum(2.0 * op.macs_per_row * rows_of.get(op.domain, 0) for op, _ in stage)
+            stage_exec = sum(2.0 * (op.exec_macs_per_row or op.macs_per_row) * _rows_of(op, r0) for op, _ in stage)
+            stage_alg = sum(2.0 * op.macs_per_row * _rows_of(op, r0) for op, _ in stage)
             roofline["allele_stage"] = {
                 "ms_per_launch": round(stage_ms, 4), "kernel_launches": len(stage),
                 "executed_tflops": round(stage_exec / (stage_ms * 1e-3) / 1e12, 2) if stage_ms > 0 else None,
@@ -583,7 +798,6 @@ def main():
         # second engine's kernels fill the tails of the first one's launches (9th round of the compressor's workgroups,
         # last round of the read convolver's).  Not the headline: concurrent kernels stretch each other's durations,
         # which would blur the per-kernel roofline above.
-        two_engines = None
         try:
             pinned2 = [pinned(k, 0, pool[k].n_sites) for k in range(len(pool))]
             eng2 = Engine(spec, state, device=dev_index)
@@ -611,20 +825,14 @@ def main():
         # ---- the selectable arithmetic modes (read convolver's residual trunk on the bf16 matrix cores as 3-term splits,
         # fp32 residual stream): NOT the headline -- `value` is exact fp32 -- reported beside it with their own parity
         bf16x3 = {}
-        for mode in ("bf16x3", "bf16x3+32"):
+        for mode in (("bf16x3", "bf16x3+32") if args.config == "C2" else ()):
             try:
                 engb = Engine(spec, state, device=dev_index, arithmetic=mode)
-                resb = []
-                for b in pool[:2]:
-                    a, p = b.n_alleles, n_pairs(b.alleles_per_site)
-                    resb.append(dict(batch=b, reads=torch.from_numpy(b.reads0).to(dev),
-                                     out=(torch.empty((1, a), dtype=torch.float32, device=dev), None,
-                                          torch.empty((4, p), dtype=torch.float32, device=dev))))
+                resb = [dict(dev=to_device(b, dev), out=device_outputs(engb, b, dev)) for b in pool[:2]]
 
                 def bstep(i):
                     r = resb[i % len(resb)]
-                    engb.forward(r["reads"], r["batch"].reads_per_allele0, r["batch"].alleles_per_site, stream=stream,
-                                 out=r["out"], posteriors=True)
+                    engb.forward_batch(r["dev"], stream=stream, out=r["out"], posteriors=True)
                 for i in range(3):
                     bstep(i)
                 torch.cuda.synchronize(dev)
@@ -653,12 +861,8 @@ def main():
                 entry = {"device_resident": round(args.sites * 40 / dt_b, 1), "host_to_host": round(args.sites * got / dt_h, 1),
                          "unit": "sites/s", "ms_per_launch": round(1e3 * dt_b / 40, 4), "readconv_launch_ms": round(kernel_ms, 4),
                          "split_convolutions": split_layers}
-                if cpu is not None and getattr(cpu_baseline, "reference_answers", None) is not None:
-                    check, want_probs, want_post = cpu_baseline.reference_answers
-                    gl, _, gp = engb.forward_batch(check, posteriors=True)
-                    entry["parity"] = {"max_abs_delta_allele_probability": float(np.abs(1.0 / (1.0 + np.exp(-gl[0].astype(np.float64))) - want_probs).max()),
-                                       "max_abs_delta_pair_posterior": float(np.abs(gp[0] - want_post).max()), "tolerance": 1e-4,
-                                       "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
+                if args.config in answers:
+                    entry["parity"] = parity_of(engb, answers[args.config])
                 bf16x3[mode] = entry
                 del resb
                 engb.close()
@@ -673,13 +877,9 @@ def main():
         try:
             from hello_amd.wrapper import ScoringNetwork
             net = ScoringNetwork(spec, state, device=dev_index, providePredictions=True)
-            lb = synth.make_sites(256, seed=args.seed + 77, coverage=30)
-            names = synth.allele_names(lb)
-            aoff = np.concatenate([[0], np.cumsum(lb.alleles_per_site)])
-            roff = np.concatenate([[0], np.cumsum(lb.reads_per_allele0)])
-            site_args = [({names[s][j]: (torch.from_numpy(lb.reads0[roff[a]:roff[a + 1]]).float(), None)
-                           for j, a in enumerate(range(aoff[s], aoff[s + 1]))},
-                          torch.from_numpy(lb.ref_onehot[s:s + 1]).float()) for s in range(lb.n_sites)]
+            lb = make_config_sites(args.config, 256, args.seed + 77)
+            site_args = [({a: (torch.from_numpy(f), None if g is None else torch.from_numpy(g)) for a, (f, g) in fd.items()},
+                          torch.from_numpy(seg)) for fd, seg in feature_dicts(lb)]
             for fd, seg in site_args[:16]:
                 net(fd, seg)
             t1 = time.perf_counter()
@@ -689,13 +889,13 @@ def main():
 
             def launch_ms(n, on_device, reps):
                 sub = lb.site_slice(0, n)
-                reads = torch.from_numpy(sub.reads0).to(dev) if on_device else sub.reads0
+                sub = to_device(sub, dev) if on_device else sub
                 for _ in range(3):
-                    net.engine.forward(reads, sub.reads_per_allele0, sub.alleles_per_site, posteriors=True)
+                    net.engine.forward_batch(sub, posteriors=True)
                 torch.cuda.synchronize(dev)
                 t = time.perf_counter()
                 for _ in range(reps):
-                    net.engine.forward(reads, sub.reads_per_allele0, sub.alleles_per_site, posteriors=True)
+                    net.engine.forward_batch(sub, posteriors=True)
                 torch.cuda.synchronize(dev)
                 return 1e3 * (time.perf_counter() - t) / reps
             latency = {
@@ -718,15 +918,13 @@ def main():
         try:
             small_engines = [eng] + [Engine(spec, state, device=dev_index) for _ in range(3)]
             streams = [torch.cuda.Stream(dev) for _ in small_engines]
-            sb = synth.make_sites(256, seed=args.seed + 77, coverage=30)
-            sreads = torch.from_numpy(sb.reads0).to(dev)
+            sb = to_device(make_config_sites(args.config, 256, args.seed + 77), dev)
             torch.cuda.synchronize(dev)
 
             def small_step(i):
                 k = i % len(small_engines)
                 with torch.cuda.stream(streams[k]):
-                    small_engines[k].forward(sreads, sb.reads_per_allele0, sb.alleles_per_site,
-                                             stream=streams[k].cuda_stream, posteriors=True)
+                    small_engines[k].forward_batch(sb, stream=streams[k].cuda_stream, posteriors=True)
             for i in range(8):
                 small_step(i)
             torch.cuda.synchronize(dev)
@@ -744,17 +942,76 @@ def main():
         except Exception as exc:
             print(f"small-batch leg failed: {exc!r}", file=sys.stderr)
 
-        if cpu is not None and getattr(cpu_baseline, "reference_answers", None) is not None:
-            check, want_probs, want_post = cpu_baseline.reference_answers
-            got_logits, _, got_post = eng.forward_batch(check, posteriors=True)
-            got_probs = 1.0 / (1.0 + np.exp(-got_logits[0].astype(np.float64)))
-            parity = {"max_abs_delta_allele_probability": float(np.abs(got_probs - want_probs).max()),
-                      "max_abs_delta_pair_posterior": float(np.abs(got_post[0] - want_post).max()),
-                      "tolerance": 1e-4, "sites": int(check.n_sites), "alleles": int(check.n_alleles),
-                      "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
+        if args.config in answers:
+            parity = parity_of(eng, answers[args.config])
+
+        # ---- the OTHER BASELINE.json configurations, through the same path (make_sites -> pinned host batch -> HostPipeline ->
+        # Engine, posteriors back on the host): host-to-host rate at --sites sites per launch, the dominant kernel's roofline
+        # fraction from the engine's HIP events, max |delta| vs the oracle on the check sites
+        if other_configs:
+            configs = {}
+            for name in other_configs:
+                try:
+                    t_leg = time.perf_counter()
+                    c = BENCH_CONFIGS[name]
+                    spec_c = ns.build(c["spec"])
+                    eng_c = Engine(spec_c, weights.synth_state(spec_c, seed=args.seed), device=dev_index, arithmetic="fp32")
+                    raw = make_config_sites(name, args.sites, 2000 + args.seed)
+                    host = pin_batch(raw)
+                    pipe_c = HostPipeline(eng_c, depth=2, posteriors=True)
+                    for i in range(3):
+                        pipe_c.submit(host, tag=i)
+                    pipe_c.flush()
+                    torch.cuda.synchronize(dev)
+                    n_c = max(args.config_launches, 1)
+                    eng_c.set_profiling(n_c, only="readconv_fused")
+                    outs = []
+                    t1 = time.perf_counter()
+                    for i in range(n_c):
+                        outs += pipe_c.submit(host, tag=i)
+                    outs += pipe_c.flush()
+                    torch.cuda.synchronize(dev)
+                    dt_c = time.perf_counter() - t1
+                    rows_c, n_fw_c = eng_c.op_times_ms()
+                    eng_c.set_profiling(0)
+                    assert len(outs) == n_c
+                    same = all(np.array_equal(o[1], outs[0][1]) and np.array_equal(o[3], outs[0][3])
+                               and (o[2] is None or np.array_equal(o[2], outs[0][2])) for o in outs[1:])
+                    d = readconv_roofline(eng_c, rows_c, [raw])
+                    alg_c, exe_c = program_flops(eng_c.program, raw)
+                    ms_c = 1e3 * dt_c / n_c
+                    configs[name] = {
+                        "workload": c["label"], "model": c["spec"], "value": round(args.sites * n_c / dt_c, 1), "unit": "sites/s",
+                        "sites_per_launch": args.sites, "launches": n_c, "ms_per_launch": round(ms_c, 4),
+                        "reads_per_site": round((int(raw.reads0.shape[0]) + (0 if raw.reads1 is None else int(raw.reads1.shape[0]))) / raw.n_sites, 2),
+                        "alleles_per_site": round(raw.n_alleles / raw.n_sites, 3), "channels": [eng_c.program.channels0, eng_c.program.channels1],
+                        "n_experts": eng_c.n_experts, "has_meta": bool(eng_c.has_meta),
+                        "roofline_frac": round(d["exec_flops"] / (d["launch_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "roofline_algorithmic_frac": round(d["flops"] / (d["launch_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "roofline": {"bound": "mfma", "kernel": d["kernel"], "launch_ms": round(d["launch_ms"], 4), "launches_timed": int(n_fw_c),
+                                     "read_technologies": d["n_ops"], "reads_per_launch": d["rows"], "flop_per_launch": d["flops"],
+                                     "executed_flop_per_launch": d["exec_flops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"},
+                        "whole_launch_algorithmic_frac": round(alg_c / (ms_c * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "whole_launch_executed_frac": round(exe_c / (ms_c * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "mflop_per_site": round(alg_c / raw.n_sites / 1e6, 1),
+                        "repeat_passes_bit_identical": bool(same), "arithmetic": eng_c.program.arithmetic,
+                        "parity": parity_of(eng_c, answers[name]) if name in answers else None,
+                        "leg_seconds": None}
+                    eng_c.close()
+                    del host, raw, pipe_c, outs
+                    torch.cuda.empty_cache()
+                    configs[name]["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
+                except Exception as exc:
+                    print(f"configuration leg {name} failed: {exc!r}", file=sys.stderr)
+                    configs[name] = {"value": None, "error": repr(exc)}
+            configs["note"] = ("the other BASELINE.json configurations through the headline's path on this GPU: host-resident pileups -> "
+                               "host-resident logits + posteriors (HostPipeline), one pinned batch of --sites sites cycled; "
+                               "`python bench.py --config <name> [--gpus N]` runs any of them as the timed region itself")
 
     # ---- who ran where (after the timed region): every rank's own report, one all_gather_object -----------------------
-    reports = shard.summarize_ranks(shard.collect_rank_reports(run["report"]))
+    raw_reports = shard.collect_rank_reports(run["report"])
+    gather_verified = verify_gather(run, raw_reports)
+    reports = shard.summarize_ranks(raw_reports)
     strong = None
     if args.scaling == "both":
         if world > 1:
@@ -763,13 +1020,14 @@ def main():
             drift2, finite2 = check_run(run2)
             drift += drift2
             finite = finite and finite2
-            rep2 = shard.summarize_ranks(shard.collect_rank_reports(run2["report"]))
+            raw2 = shard.collect_rank_reports(run2["report"])
+            rep2 = shard.summarize_ranks(raw2)
             strong = {"value": round(run2["value"], 1), "unit": "sites/s", "scaling": "strong",
                       "ms_per_step": round(1e3 * run2["dt"] / max(args.steps, 1), 4), "sites_total": int(run2["sites_total"]),
                       "timed_region_s": round(run2["dt"], 3), "gather_ms": run2["gather_ms"], "gather_host_ms": run2["gather_host_ms"],
                       "slowest_rank": rep2["slowest_rank"], "balance": rep2["balance"], "distinct_devices": rep2["distinct_devices"],
                       "repeat_passes_bit_identical": drift2 == 0, "outputs_finite": bool(finite2),
-                      "ranks": rep2["ranks"]}
+                      "gather_verified_ranks": verify_gather(run2, raw2), "ranks": rep2["ranks"]}
             del run2
         else:
             strong = {"value": round(value, 1), "unit": "sites/s", "scaling": "strong",
@@ -783,26 +1041,30 @@ def main():
     if rank == 0:
         b0 = pool[0]
         scaling_label = headline_mode
-        print(f"bench: N = {world} ({backend if dist is not None else 'no process group'}), `value` = {scaling_label.upper()} scaling"
+        print(f"bench: N = {world} ({backend if dist is not None else 'no process group'}), config {args.config}, `value` = {scaling_label.upper()} scaling"
               + (f", strong scaling beside it: {strong['value']:.0f} sites/s" if strong and world > 1 else "")
-              + f"; {reports['distinct_devices']} distinct device(s) over {reports['ranks_seen']} rank(s)", file=sys.stderr)
+              + f"; {reports['distinct_devices']} distinct device(s) over {reports['ranks_seen']} rank(s)"
+              + (f"; gather verified for {gather_verified} of {world} rank(s)" if gather_verified is not None else ""), file=sys.stderr)
         line = {
             "metric": "candidate sites/sec (whole node)", "value": round(value, 1), "unit": "sites/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / max(args.steps, 1), 4), "higher_is_better": True, "scaling": scaling_label,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Illumina 30x single-tech model (moe_attention single_tech weight_norm), synthetic "
-                                   f"pileups cov 30, seeded synthetic weights; host-resident uint8 pileups + counts -> "
+            "config": {"workload": f"{cfg['label']}, seeded synthetic weights; host-resident uint8 pileups + counts -> "
                                    f"host-resident logits + genotype-pair posteriors (PCIe both ways inside the timed "
                                    f"region) through shard.partition_sites + HostPipeline; a step = "
                                    f"{args.launches_per_step} launches x {args.sites} sites per GPU, cycling a pinned "
                                    f"pool of {args.pool} distinct batches",
+                       "name": args.config, "model": cfg["spec"],
                        "sites_per_launch": args.sites, "launches_per_step_per_gpu": args.launches_per_step,
                        "sites_per_step": int(sum(s for s, _ in sizes)), "sites_total": int(sites_total),
                        "timed_region_s": round(dt, 3),
-                       "reads_per_site": round(b0.reads0.shape[0] / b0.n_sites, 2),
+                       "reads_per_site": round(n_reads(b0) / b0.n_sites, 2),
                        "alleles_per_site": round(b0.n_alleles / b0.n_sites, 3),
-                       "window": 150, "channels": 6, "parallelism": f"site-sharded dp{world}, one gather at the end",
+                       "window": int(eng.program.window), "channels": int(eng.program.channels0),
+                       "channels_second_technology": int(eng.program.channels1) or None,
+                       "n_experts": int(eng.n_experts), "has_meta": bool(eng.has_meta),
+                       "parallelism": f"site-sharded dp{world}, one gather at the end",
                        "arithmetic": eng.program.arithmetic,
                        "fused_read_convolver": bool(fused), "outputs": "logits + genotype-pair posteriors (host)",
                        "host_cpus_of_rank0": len(cpus), "pinned_input_bytes_of_rank0": pinned_bytes,
@@ -810,12 +1072,16 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu, "cpu_baseline_reason": cpu_reason,
             # audit of the run: one entry per rank (device PCI address / UUID, sites, reads, own seconds, launches, pinned bytes,
-            # CPUs), collected with one all_gather_object after the closing fence
+            # CPUs, checksum of the columns it produced), collected with one all_gather_object after the closing fence
             "backend": (backend if dist is not None else None), "ranks_seen": reports["ranks_seen"],
             "distinct_devices": reports["distinct_devices"], "identity_sources": reports["identity_sources"],
             "identity_warning": reports["identity_warning"], "slowest_rank": reports["slowest_rank"],
             "rank_seconds_min_max": reports["rank_seconds_min_max"], "balance": reports["balance"],
-            "gather_ms": run["gather_ms"], "gather_host_ms": run["gather_host_ms"], "ranks": reports["ranks"],
+            "gather_ms": run["gather_ms"], "gather_host_ms": run["gather_host_ms"],
+            # the gather proves itself: for how many ranks the checksum of what rank 0 RECEIVED equals the checksum that rank
+            # computed locally of what it PRODUCED (crc32 + float64 sums + first / last value; null when no process group is up)
+            "gather_verified_ranks": gather_verified,
+            "ranks": reports["ranks"],
             "strong_scaling": strong,
             "device_resident": device_resident,
             "two_engines": two_engines,
@@ -823,6 +1089,7 @@ def main():
             "latency": latency,
             "parity": parity,
             "small_batch": small,
+            "configs": configs,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -831,6 +1098,8 @@ def main():
     eng.close()
     if drift:
         raise SystemExit(f"{drift} repeated passes differed from the first pass over the same batch")
+    if gather_verified is not None and rank == 0 and gather_verified != world:
+        raise SystemExit(f"the gather delivered the columns of only {gather_verified} of {world} ranks intact")
 
 
 if __name__ == "__main__":

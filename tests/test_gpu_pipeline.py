@@ -128,6 +128,7 @@ def test_bench_under_torchrun_is_auditable():
     assert r["reads"] > 25 * r["sites"] and r["pinned_input_bytes"] > 0 and r["pinned_input_bytes"] % 900 == 0 and r["cpus_pinned"] >= 1
     assert 0 < r["timed_seconds"] <= b["config"]["timed_region_s"] + 1e-3 and b["gather_ms"] is not None and b["gather_ms"] >= 0
     assert b["strong_scaling"]["value"] == b["value"] and "N = 1" in b["strong_scaling"]["note"]
+    assert b["gather_verified_ranks"] == 1 and a["gather_verified_ranks"] is None and b["config"]["name"] == "C2"     # RCCL at world 1: the gather checks itself
     assert a["backend"] is None and a["ranks_seen"] == 1 and a["distinct_devices"] == 1 and a["gather_ms"] is None
     # the CPU baseline was switched off here: null with its reason
     assert a["cpu_baseline"] is None and "--no-cpu-baseline" in a["cpu_baseline_reason"] and b["cpu_baseline"] is None
@@ -167,7 +168,75 @@ def test_bench_gpus_2_from_a_plain_shell_starts_its_own_ranks():
     assert st["scaling"] == "strong" and st["sites_total"] == 3 * 2 * 512 and [r["rank"] for r in st["ranks"]] == [0, 1]
     assert st["repeat_passes_bit_identical"] and st["outputs_finite"] and st["value"] > 0
     assert sum(r["sites"] for r in st["ranks"]) == st["sites_total"]
+    assert z["gather_verified_ranks"] == 2 and st["gather_verified_ranks"] == 2
     assert "starting 2 ranks as a child" in out.stderr
+
+
+@pytest.mark.parametrize("config,model,second,experts,meta", [("C4", "hybrid_no_ensemble", 6, 1, False),
+                                                              ("hybrid_full", "hybrid_full", 6, 3, True)])
+def test_bench_gpus_2_runs_the_hybrid_configurations_through_the_gather(config, model, second, experts, meta):
+    """VERDICT r05 item 1 + 7: `python bench.py --gpus 2 --config C4` typed plainly (HELLO_BENCH_BACKEND=gloo: both ranks on this box's
+    one GPU) runs BASELINE.json's hybrid configuration as the timed region -- two read technologies per rank, the one gather -- and the
+    gather proves itself: every rank ships the checksum of the columns it produced, rank 0 compares it with the checksum of what it
+    received (`gather_verified_ranks` == 2, in the weak and in the strong region).  With hybrid_full the three experts' logits AND the
+    per-site meta weights cross the gather."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(_bench_env(), HELLO_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", config, "--no-cpu-baseline"] + SMALL,
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1, out.stdout[-2000:]
+    z = json.loads(lines[0])
+    c = z["config"]
+    assert z["n_gpus"] == 2 and z["backend"] == "gloo" and z["ranks_seen"] == 2 and c["name"] == config and c["model"] == model
+    assert c["channels"] == 6 and c["channels_second_technology"] == second and c["n_experts"] == experts and c["has_meta"] is meta
+    assert c["sites_total"] == 2 * 3 * 2 * 512 and c["repeat_passes_bit_identical"] and c["outputs_finite"] and c["reads_per_site"] > 40
+    assert z["gather_verified_ranks"] == 2 and z["strong_scaling"]["gather_verified_ranks"] == 2
+    for r in z["ranks"]:
+        own = r["own_checksum"]
+        assert own["logits"]["n"] == experts * r["alleles"] and (own["meta"] is not None) is meta
+        if meta:
+            assert own["meta"]["n"] == 3 * r["sites"] and abs(own["meta"]["sum"] - r["sites"]) < 1e-2 * r["sites"]      # softmax rows sum to 1
+        assert r["pinned_input_bytes"] % 900 == 0 and r["reads"] > 40 * r["sites"]
+    rf = z["roofline"]
+    assert rf["kernel"] == "readconv_kernel" and rf["kernel_launches_per_forward"] == 4 and 0 < rf["frac"] <= 1.0
+    assert rf["traffic"] is None and rf["traffic_stale"] is True               # the committed PMC passes profile C2
+    assert z["configs"] is None and z["parity"] is None                        # secondary legs run at N = 1 only
+
+
+def test_bench_default_run_reports_every_baseline_configuration():
+    """the default (C2) run carries a `configs` block -- C3, C4, C5 and hybrid_full through the headline's path
+    (pinned host batch -> HostPipeline -> Engine -> posteriors on the host): rate, the read convolver's roofline fraction from the
+    engine's HIP events, and max |delta| against the oracle's per-site answers on the check sites.  Small sizes here; the driver's run
+    uses 8 192 sites per launch over 40 launches."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--sites", "512", "--launches-per-step", "2",
+                          "--cpu-budget", "1", "--config-launches", "4"], cwd=root, env=_bench_env(), capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    z = json.loads(_json_lines(out.stdout)[-1])
+    assert z["config"]["name"] == "C2" and z["parity"]["within_tolerance"] and z["parity"]["sites"] == 96
+    assert z["cpu_baseline"]["config"] == "C2" and z["cpu_baseline"]["value"] > 0
+    assert z["gather_verified_ranks"] is None                                  # no process group in a plain N = 1 run
+    cfgs = z["configs"]
+    assert {"C3", "C4", "C5", "hybrid_full"} <= set(cfgs)
+    for name, model, techs in (("C3", "single_tech", 1), ("C4", "hybrid_no_ensemble", 2), ("C5", "single_tech_hp", 1), ("hybrid_full", "hybrid_full", 2)):
+        e = cfgs[name]
+        assert e["model"] == model and e["value"] > 0 and e["launches"] == 4 and e["sites_per_launch"] == 512, (name, e)
+        assert 0 < e["roofline_frac"] <= 1.0 and e["roofline_algorithmic_frac"] > e["roofline_frac"] and e["roofline"]["read_technologies"] == techs
+        assert e["repeat_passes_bit_identical"] and e["arithmetic"] == "fp32"
+        par = e["parity"]
+        assert par["within_tolerance"] and par["sites"] == 96 and par["max_abs_delta_pair_posterior"] <= 1e-4 and par["max_abs_delta_allele_probability"] <= 1e-4
+    assert cfgs["hybrid_full"]["parity"]["max_abs_delta_meta"] <= 1e-4 and cfgs["hybrid_full"]["n_experts"] == 3 and cfgs["hybrid_full"]["has_meta"]
+    assert cfgs["C5"]["channels"] == [7, 0] and cfgs["C4"]["channels"] == [6, 6]
 
 
 @pytest.mark.bench

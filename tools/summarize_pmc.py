@@ -74,13 +74,18 @@ def table(d, stats_csv, forwards):
 
 
 def provenance():
-    """Which binary the passes profiled: sha256 of hello_amd/libhello_mi355x.so as it lies beside this tool (the file the profiled
-    bench.py loaded) and the commit the caller names ($HELLO_PROFILE_COMMIT: the GPU box's copy of the tree has no .git).
-    bench.py reports `roofline.traffic` only when this hash equals the hash of the library it loaded."""
+    """Which binary the passes profiled: sha256 of the library the profiled bench.py LOADED -- HELLO_LIB when it is set (the path
+    hello_amd.engine opens, read the same way here without importing torch), else the in-tree hello_amd/libhello_mi355x.so -- and
+    the commit the caller names ($HELLO_PROFILE_COMMIT: the GPU box's copy of the tree has no .git).  bench.py reports
+    `roofline.traffic` only when this hash equals the hash of the library it loaded."""
     import hashlib
-    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hello_amd", "libhello_mi355x.so")
-    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
-    return {"lib_sha256": sha, "commit": os.environ.get("HELLO_PROFILE_COMMIT") or None}
+    lib = os.environ.get("HELLO_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hello_amd",
+                                                      "libhello_mi355x.so")
+    try:
+        sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()
+    except OSError:
+        sha = None
+    return {"lib_sha256": sha, "lib_path": lib, "commit": os.environ.get("HELLO_PROFILE_COMMIT") or None}
 
 
 def traffic(d):
