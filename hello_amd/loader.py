@@ -68,7 +68,8 @@ def sniff(path: str) -> str:
     with open(path, "rb") as fh:
         head = fh.read(64)
     if head.startswith(_LFS_MAGIC):
-        fields = dict(line.split(" ", 1) for line in open(path, "r", errors="replace").read().splitlines() if " " in line)
+        with open(path, "r", errors="replace") as fh:
+            fields = dict(line.split(" ", 1) for line in fh.read().splitlines() if " " in line)
         raise ValueError(
             f"{path} is a git-LFS pointer ({os.path.getsize(path)} bytes of text, oid {fields.get('oid', '?')}, the real model is "
             f"{fields.get('size', '?')} bytes), not the model itself: the clone was made without git-lfs.  Fetch the model with "
@@ -80,7 +81,7 @@ def sniff(path: str) -> str:
         return "native" if _is_native(path) else "torch-zip"
     if head.startswith(b"\x1f\x8b"):
         return "gzip"
-    if head[:1] == b"\x80" and 2 <= head[1] <= 5:
+    if len(head) >= 2 and head[:1] == b"\x80" and 2 <= head[1] <= 5:
         return "torch-legacy"
     raise ValueError(f"{path} is neither a torch.save file (zip archive or legacy pickle stream) nor a native hello_amd .npz: it starts "
                      f"with {head[:16]!r}.  Expected the reference's *.wrapper.dnn (python/create_model_wrapper.py) or a file written "
@@ -317,7 +318,9 @@ def _load_reference_pickle(path: str, kind: str = "torch-zip"):
         try:
             obj = torch.load(path, map_location="cpu", weights_only=False)
         except (pickle.UnpicklingError, AttributeError, ModuleNotFoundError, EOFError, RuntimeError) as exc:
-            raise ValueError(f"{path} ({kind} stream) could not be unpickled as a reference model: {exc!r}.  The loader supplies stand-ins "
+            # a RuntimeError from torch.load is reported under its own type and text (a corrupt zip member, an unsupported storage ...):
+            # the message below keeps both, so an unrelated torch failure is not mistaken for a class the stand-ins lack
+            raise ValueError(f"{path} ({kind} stream) could not be unpickled as a reference model: {type(exc).__name__}: {exc}.  The loader supplies stand-ins "
                              f"for the classes of NNTools and MixtureOfExpertsAdvanced[XferLearning] only; a pickle naming other modules, "
                              f"or a truncated file, cannot be read") from exc
     if not hasattr(obj, "_modules"):
@@ -339,9 +342,18 @@ def load_spec(path: str) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:
     return _load_reference_pickle(path, kind)
 
 
-def load(path: str, device: int = 0, **kw):
+def load(path: str, device: int = 0, shared: bool = False, **kw):
     """Drop-in for ``torch.load(path)`` in the reference caller: returns a network object with
-    ``.eval()``, ``.providePredictions`` and ``__call__(featureDict, ref_segment)``."""
+    ``.eval()``, ``.providePredictions`` and ``__call__(featureDict, ref_segment)``.
+
+    ``shared=True`` is for the reference's deployment form -- a pool of worker processes that each load the model and score one
+    site per call (call.py:111,215-221): the object then holds no engine of its own; its calls go to ONE scoring server per
+    (model file, GPU), started by the first worker, which coalesces the workers' concurrent sites into one launch
+    (``hello_amd.shared``).  The calling process never touches the GPU."""
+    if shared:
+        from .shared import SharedScoringNetwork
+        sniff(path)                                # a git-LFS pointer / an empty file is refused here, by name, not in the server's log
+        return SharedScoringNetwork(path, device=device, **kw)
     from .wrapper import ScoringNetwork
     spec, state = load_spec(path)
     return ScoringNetwork(spec, state, device=device, **kw)

@@ -13,21 +13,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "bench: a timing comparison (wide band), kept apart from the functional assertions")
-    config.addinivalue_line("markers", "slow: the full parity matrix behind the trimmed one (deselect with -m 'gpu and not slow')")
-
-
-def pytest_addoption(parser):
-    parser.addoption("--runslow", action="store_true", default=False,
-                     help="also run the tests marked slow: the full parity matrix behind the trimmed one (or HELLO_TEST_SLOW=1)")
-
-
-def pytest_collection_modifyitems(config, items):
-    if config.getoption("--runslow") or os.environ.get("HELLO_TEST_SLOW") == "1":
-        return
-    skip = pytest.mark.skip(reason="slow: the full parity matrix; run with --runslow or HELLO_TEST_SLOW=1")
-    for item in items:
-        if "slow" in item.keywords:
-            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -1,48 +1,44 @@
-"""The reference's deployment form on one GPU: N worker processes, each with its own engine, each scoring ONE site per
-call through the plug-in surface (python/call.py:26-30,111: a process pool, torch single-threaded per worker).
+"""The reference's deployment form on one GPU: N worker processes, each scoring ONE site per call through the plug-in surface
+(python/call.py:26-30,111: a process pool, torch single-threaded per worker; python/caller_calling.py:863-868,872-891).
 
-    python tools/per_site_multiprocess.py [--workers 4] [--calls 2000]
+    python tools/per_site_multiprocess.py [--workers 4] [--calls 2000]                 # every worker its own engine
+    python tools/per_site_multiprocess.py --shared [--workers 16] [--calls 2000]       # loader.load(path, shared=True): ONE server
 
-Prints each worker's rate and the aggregate.  At most 6 processes may use the card on the shared pool.
+Prints each worker's rate and the aggregate (and, with --shared, the server's launch statistics).  Without --shared at most 6
+processes may use the card on the shared pool; with --shared only the server process does, so the worker count is free.
 """
 import argparse
+import json
 import multiprocessing as mp
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def worker(rank, calls, start_evt, out_q):
+def worker(rank, calls, start_evt, out_q, model_path, shared, config):
     import numpy as np  # noqa: F401
     import torch
-    from hello_amd import netspec as ns, synth, weights
-    from hello_amd.wrapper import ScoringNetwork
+    import bench
+    from hello_amd import loader
     torch.set_num_threads(1)
-    spec = ns.build("single_tech")
-    net = ScoringNetwork(spec, weights.synth_state(spec, seed=1), device=0, providePredictions=True)
-    batch = synth.make_sites(256, seed=3 + rank, coverage=30)
-    sites, r, a = [], 0, 0
-    for s in range(batch.n_sites):
-        fd = {}
-        for k in range(int(batch.alleles_per_site[s])):
-            n = int(batch.reads_per_allele0[a])
-            fd["A" * (k + 1)] = (torch.from_numpy(batch.reads0[r:r + n]).float(), None)
-            r += n
-            a += 1
-        sites.append((fd, torch.zeros(1, 150, 5)))
+    net = loader.load(model_path, shared=shared, providePredictions=True)
+    sites = [({a: (torch.from_numpy(f), None if g is None else torch.from_numpy(g)) for a, (f, g) in fd.items()}, torch.from_numpy(seg))
+             for fd, seg in bench.feature_dicts(bench.make_config_sites(config, 256, 3 + rank))]
     for fd, seg in sites[:32]:
         net(fd, seg)
-    out_q.put(("ready", rank, 0.0))
+    out_q.put(("ready", rank, 0.0, None))
     start_evt.wait()
     t = time.perf_counter()
     for i in range(calls):
         fd, seg = sites[i % len(sites)]
         net(fd, seg)
     dt = time.perf_counter() - t
-    out_q.put(("done", rank, calls / dt))
+    stats = net.server_stats() if shared else None
+    out_q.put(("done", rank, calls / dt, stats))
     net.close()
 
 
@@ -50,23 +46,42 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--calls", type=int, default=2000)
+    ap.add_argument("--shared", action="store_true", help="workers load the model with shared=True: one scoring server for all of them")
+    ap.add_argument("--engines", type=int, default=2, help="engines (scorer threads) of the shared server")
+    ap.add_argument("--config", default="C2", help="bench.py configuration (model + synthetic sites)")
     args = ap.parse_args()
-    if args.workers > 6:
+    if args.workers > 6 and not args.shared:
         raise SystemExit("at most 6 processes may use the card on this pool")
+    import bench
+    from hello_amd import loader, netspec as ns, weights
+    tmp = tempfile.mkdtemp(prefix="hello_per_site_")
+    os.environ.setdefault("HELLO_SHARED_DIR", os.path.join(tmp, "rendezvous"))
+    os.environ["HELLO_SHARED_ENGINES"] = str(args.engines)
+    spec_name = bench.BENCH_CONFIGS[args.config]["spec"]
+    spec = ns.build(spec_name)
+    model_path = os.path.join(tmp, spec_name + ".npz")
+    loader.save_native(model_path, spec_name, weights.synth_state(spec, seed=1))
     ctx = mp.get_context("spawn")
     start_evt, q = ctx.Event(), ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, args.calls, start_evt, q)) for r in range(args.workers)]
+    procs = [ctx.Process(target=worker, args=(r, args.calls, start_evt, q, model_path, args.shared, args.config)) for r in range(args.workers)]
     for p in procs:
         p.start()
     for _ in procs:
-        assert q.get(timeout=300)[0] == "ready"
+        assert q.get(timeout=600)[0] == "ready"
+    t0 = time.perf_counter()
     start_evt.set()
-    rates = sorted((q.get(timeout=600) for _ in procs), key=lambda x: x[1])
+    rates = sorted((q.get(timeout=900) for _ in procs), key=lambda x: x[1])
+    wall = time.perf_counter() - t0
     for p in procs:
         p.join()
-    for _, rank, rate in rates:
+    for _, rank, rate, _ in rates:
         print(f"  worker {rank}: {rate:8.0f} sites/s ({1e3 / rate:.3f} ms per call)")
-    print(f"{args.workers} worker processes, one site per call each: {sum(r[2] for r in rates):,.0f} sites/s in aggregate")
+    form = f"loader.load(path, shared=True): one server process, {args.engines} engine(s)" if args.shared else "an engine per worker"
+    print(f"{args.workers} worker processes ({args.config}), one site per call each, {form}: {sum(r[2] for r in rates):,.0f} sites/s in aggregate "
+          f"({args.workers * args.calls / wall:,.0f} by the wall clock of the slowest worker)")
+    if args.shared:
+        stats = max((r[3] for r in rates), key=lambda s: s["sites"])
+        print(f"  server: {json.dumps(stats)}; mean sites per launch {stats['sites'] / max(stats['launches'], 1):.1f}")
 
 
 if __name__ == "__main__":
