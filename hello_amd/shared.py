@@ -126,9 +126,9 @@ class _Slot:
 
     def read_result(self, n_experts: int, has_meta: bool):
         a, p = int(self.header[H_ALLELES]), int(self.header[H_PAIRS])
-        logits = self.logits[:n_experts * a].reshape(n_experts, a).copy()
+        logits = self.logits.reshape(3, MAX_ALLELES)[:n_experts, :a].copy()          # rows of fixed stride: the server scatters a whole launch at once
         meta = self.meta[:3].copy() if has_meta else None
-        post = self.post[:4 * p].reshape(4, p).copy()
+        post = self.post.reshape(4, MAX_PAIRS)[:, :p].copy()
         return logits, meta, post
 
     def read_error(self) -> str:
@@ -156,10 +156,10 @@ class _Slot:
         return a, reads0, rpa0, reads1, rpa1, ref
 
     def write_result(self, logits, meta, post) -> None:
-        self.logits[:logits.size] = logits.reshape(-1)
+        self.logits.reshape(3, MAX_ALLELES)[:logits.shape[0], :logits.shape[1]] = logits
         if meta is not None:
             self.meta[:3] = meta
-        self.post[:post.size] = post.reshape(-1)
+        self.post.reshape(4, MAX_PAIRS)[:, :post.shape[1]] = post
 
     def write_error(self, message: str) -> None:
         raw = message.encode("utf-8", "replace")[:ERR_BYTES]
@@ -196,42 +196,66 @@ Scorer = Callable[[np.ndarray, np.ndarray, np.ndarray, Optional[np.ndarray], Opt
 
 
 class SiteServer:
-    """One scoring server: a listening Unix socket, a shared-memory segment of ``max_clients`` slots, one selector loop and
-    ``len(scorers)`` scorer threads.  ``scorers`` are callables ``score(reads0, rpa0, aps, reads1, rpa1, ref) -> (logits [E, A],
-    meta [S, 3] | None, posteriors [4, P])`` -- ``engine_scorer(Engine)`` in the product; each is called from its own thread only.
-    ``info`` describes the model to clients: window, channels0, channels1, n_experts, has_meta, uses_ref, ensemble."""
+    """One scoring server: a listening Unix socket, a shared-memory segment of ``max_clients`` slots and ``len(scorers)`` scorer
+    threads.  ``scorers`` are callables ``score(reads0, rpa0, aps, reads1, rpa1, ref) -> (logits [E, A], meta [S, 3] | None,
+    posteriors [4, P])`` -- ``engine_scorer(Engine)`` in the product; each is called from its own thread only.  ``info`` describes
+    the model to clients: window, channels0, channels1, n_experts, has_meta, uses_ref, ensemble.
+
+    Threads are leader / follower: whichever scorer thread is idle holds the poll lock, waits on the sockets itself (accepting
+    clients, noticing the dead ones, reading request bytes), takes EVERY pending slot as its launch and hands the lock to the next
+    idle thread before it scores -- no hand-over between a poller and a scorer on a site's way in.  A poller that has fewer requests
+    than there are clients who could still send one (connected minus in flight elsewhere) lingers up to ``linger_s`` for them: a
+    launch costs nearly the same for 1 or 16 sites (0.27 / 0.40 ms), so a few tens of microseconds of patience buy sites per launch
+    (measured on one MI355X, 16 workers: 17.7 k sites/s without lingering, 26.2 k with 120 us; cutting the clients into one group per
+    engine so that the groups run out of phase was measured too and is slower -- 22.3 k: the launches' host halves serialise on the
+    interpreter lock; profiles/r06_per_site_shared_sweep.txt)."""
 
     def __init__(self, socket_path: str, shm_path: str, info: Dict, scorers: Sequence[Scorer], slot_bytes: int = DEFAULT_SLOT_BYTES,
-                 max_clients: int = DEFAULT_MAX_CLIENTS, idle_exit_s: Optional[float] = 15.0, max_batch_sites: int = 4096):
+                 max_clients: int = DEFAULT_MAX_CLIENTS, idle_exit_s: Optional[float] = 15.0, max_batch_sites: int = 4096,
+                 linger_s: Optional[float] = None):
         self.socket_path, self.shm_path = socket_path, shm_path
         self.info = dict(info, protocol=PROTOCOL, slot_bytes=int(slot_bytes), max_clients=int(max_clients), shm_path=shm_path, pid=os.getpid())
-        self.layout = SlotLayout(info["window"], info["channels0"], info["channels1"], slot_bytes)
+        self.layout = lay = SlotLayout(info["window"], info["channels0"], info["channels1"], slot_bytes)
         self.scorers = list(scorers)
         self.idle_exit_s, self.max_batch_sites = idle_exit_s, int(max_batch_sites)
-        self.max_clients = int(max_clients)
+        self.linger_s = float(linger_s if linger_s is not None else float(os.environ.get("HELLO_SHARED_LINGER_US", 120)) * 1e-6)
+        self.max_clients = m = int(max_clients)
         fd = os.open(shm_path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
         try:
-            os.ftruncate(fd, self.max_clients * self.layout.slot_bytes)
-            self._map = mmap.mmap(fd, self.max_clients * self.layout.slot_bytes)
+            os.ftruncate(fd, m * lay.slot_bytes)
+            self._map = mmap.mmap(fd, m * lay.slot_bytes)
         finally:
             os.close(fd)
-        self.slots = [_Slot(self._map, i, self.layout) for i in range(self.max_clients)]
-        self._free = deque(range(self.max_clients))
+        self.slots = [_Slot(self._map, i, lay) for i in range(m)]
+        # the same fields of EVERY slot as one strided array each: a launch gathers and scatters with a few NumPy calls, whatever its size
+        sb = lay.slot_bytes
+        view = lambda shape, dtype, off, strides: np.ndarray(shape, dtype, buffer=self._map, offset=off, strides=(sb,) + strides)   # noqa: E731
+        self._hdr = view((m, HEADER_INTS), np.int32, lay.header, (4,))
+        self._rpa0 = view((m, MAX_ALLELES), np.int32, lay.rpa0, (4,))
+        self._rpa1 = view((m, MAX_ALLELES), np.int32, lay.rpa1, (4,))
+        self._ref = view((m, lay.window, 5), np.uint8, lay.ref, (5, 1))
+        self._logits = view((m, 3, MAX_ALLELES), np.float32, lay.logits, (4 * MAX_ALLELES, 4))
+        self._meta = view((m, 4), np.float32, lay.meta, (4,))
+        self._post = view((m, 4, MAX_PAIRS), np.float32, lay.post, (4 * MAX_PAIRS, 4))
+        self._free = deque(range(m))
         self._socks: Dict[int, socket.socket] = {}             # slot index -> client socket
-        self._pending: deque = deque()
+        self._pending: List[int] = []                          # requests read off the sockets, not yet part of a launch (poller's)
         self._inflight: set = set()                            # slots a scorer thread is reading / writing right now
         self._zombies: set = set()                             # ... whose client went away meanwhile: freed when the launch is over
-        self._cond = threading.Condition()
+        self._state = threading.Lock()                         # guards _inflight / _zombies / _free / stats
+        self._poll = threading.Lock()                          # the leader's: sockets, selector, _pending, _socks
         self._stop = False
+        self._idle_since = time.monotonic()
+        self._sel = None
         self.stats = dict(launches=0, sites=0, largest_launch=0, clients_seen=0, errors=0)
         if os.path.exists(socket_path):
             os.unlink(socket_path)
         self._listener = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
         self._listener.bind(socket_path)
         os.chmod(socket_path, 0o600)
-        self._listener.listen(self.max_clients)
+        self._listener.listen(m)
 
-    # -- scorer threads ---------------------------------------------------------------------------------------------
+    # -- a launch ---------------------------------------------------------------------------------------------------
     def _reply(self, index: int, byte: bytes) -> None:
         sock = self._socks.get(index)
         if sock is None:
@@ -241,67 +265,88 @@ class SiteServer:
         except OSError:
             pass                                   # the client went away while its site was being scored
 
-    def _score_batch(self, score: Scorer, take: List[int]) -> None:
-        sites, good = [], []
-        for index in take:
-            try:
-                sites.append(self.slots[index].site_views())
-                good.append(index)
-            except ValueError as exc:
-                self.slots[index].write_error(str(exc))
-                self._reply(index, ERR)
-        if not good:
-            return
-        second = sites[0][3] is not None
-        with_ref = sites[0][5] is not None
+    def _refuse(self, index: int, message: str) -> None:
+        self.slots[index].write_error(message)
+        self._reply(index, ERR)
+
+    def _gather(self, take: List[int]):
+        """The slots of one launch -> (slot indices kept, batch arrays).  A client is another process: every header is checked
+        against the slot's capacity and its own tables before a byte of it is followed; a slot that fails is answered with the reason
+        and left out."""
+        lay = self.layout
+        idx = np.asarray(take, dtype=np.int64)
+        h = self._hdr[idx]
+        a, r0, r1, has_ref = (h[:, k].astype(np.int64) for k in (H_ALLELES, H_READS0, H_READS1, H_HAS_REF))
+        rb0, rb1 = lay.row_bytes(0), lay.row_bytes(1)
+        cols = np.arange(MAX_ALLELES)[None, :]
+        live = cols < a[:, None]
+        t0 = np.where(live, self._rpa0[idx], 0)
+        t1 = np.where(live, self._rpa1[idx], 0)
+        ok = (a >= 1) & (a <= MAX_ALLELES) & (r0 >= a) & (r1 >= 0) & ((r1 == 0) | (lay.channels1 > 0)) & (r0 * rb0 + r1 * rb1 <= lay.read_capacity)
+        ok &= (t0.sum(axis=1) == r0) & (np.where(live, t0, 1).min(axis=1) >= 1)
+        ok &= (r1 == 0) | ((t1.sum(axis=1) == r1) & (np.where(live, t1, 1).min(axis=1) >= 1))
         # a launch holds sites of one shape of call (every client of a server speaks for the same model): a stray one is refused
-        keep = [k for k, s in enumerate(sites) if (s[3] is not None) == second and (s[5] is not None) == with_ref]
-        for k in set(range(len(sites))) - set(keep):
-            self.slots[good[k]].write_error("this site's optional inputs (second technology / reference segment) differ from the launch's")
-            self._reply(good[k], ERR)
-        sites, good = [sites[k] for k in keep], [good[k] for k in keep]
-        aps = np.array([s[0] for s in sites], np.int32)
-        cat = (lambda k: sites[0][k]) if len(sites) == 1 else (lambda k: np.concatenate([s[k] for s in sites]))
-        reads0, rpa0 = cat(1), cat(2)
-        reads1, rpa1 = (cat(3), cat(4)) if second else (None, None)
-        ref = np.stack([s[5] for s in sites]) if with_ref else None
-        try:
-            logits, meta, post = score(reads0, rpa0, aps, reads1, rpa1, ref)
-        except Exception as exc:                   # the whole launch failed: every site of it is answered with the reason
-            self.stats["errors"] += 1
-            for index in good:
-                self.slots[index].write_error(f"{type(exc).__name__}: {exc}")
-                self._reply(index, ERR)
+        second, with_ref = bool(r1[0] > 0), bool(has_ref[0])
+        ok &= ((r1 > 0) == second) & ((has_ref != 0) == with_ref)
+        if not ok.all():
+            for k in np.nonzero(~ok)[0]:
+                self._refuse(int(idx[k]), f"slot {int(idx[k])}: the header describes no site that fits the slot and the launch (alleles {int(a[k])}, "
+                                          f"reads {int(r0[k])} / {int(r1[k])}; reads per allele must add up, every allele needs a read, optional "
+                                          f"inputs must match the launch's)")
+            keep = np.nonzero(ok)[0]
+            if keep.size == 0:
+                return [], None
+            idx, a, r0, r1, t0, t1, live = idx[keep], a[keep], r0[keep], r1[keep], t0[keep], t1[keep], live[keep]
+        n = idx.shape[0]
+        slots = self.slots
+        if n == 1:
+            i = int(idx[0])
+            reads0 = slots[i].reads[:int(r0[0]) * rb0]
+            reads1 = slots[i].reads[int(r0[0]) * rb0:int(r0[0]) * rb0 + int(r1[0]) * rb1] if second else None
+        else:
+            reads0 = np.concatenate([slots[int(i)].reads[:int(n0)] for i, n0 in zip(idx, r0 * rb0)])
+            reads1 = np.concatenate([slots[int(i)].reads[int(n0):int(n0 + n1)] for i, n0, n1 in zip(idx, r0 * rb0, r1 * rb1)]) if second else None
+        batch = dict(aps=a.astype(np.int32), rpa0=t0[live].astype(np.int32), reads0=reads0.reshape(-1, lay.window, lay.channels0),
+                     rpa1=t1[live].astype(np.int32) if second else None,
+                     reads1=reads1.reshape(-1, lay.window, lay.channels1) if second else None,
+                     ref=np.ascontiguousarray(self._ref[idx]) if with_ref else None)
+        return idx, batch
+
+    def _scatter(self, idx, aps, logits, meta, post) -> None:
+        n = idx.shape[0]
+        a = aps.astype(np.int64)
+        site_a = np.repeat(np.arange(n), a)
+        local_a = np.arange(site_a.shape[0]) - np.repeat(np.cumsum(a) - a, a)
+        self._logits[idx[site_a][None, :], np.arange(logits.shape[0])[:, None], local_a[None, :]] = logits
+        if meta is not None:
+            self._meta[idx, :3] = meta
+        p = a * (a + 1) // 2
+        site_p = np.repeat(np.arange(n), p)
+        local_p = np.arange(site_p.shape[0]) - np.repeat(np.cumsum(p) - p, p)
+        self._post[idx[site_p][None, :], np.arange(4)[:, None], local_p[None, :]] = post
+
+    def _score_batch(self, score: Scorer, take: List[int]) -> None:
+        idx, b = self._gather(take)
+        if b is None:
             return
-        a_off = np.concatenate([[0], np.cumsum(aps)])
-        p_off = np.concatenate([[0], np.cumsum(aps.astype(np.int64) * (aps + 1) // 2)])
-        for k, index in enumerate(good):
-            self.slots[index].write_result(logits[:, a_off[k]:a_off[k + 1]], None if meta is None else meta[k], post[:, p_off[k]:p_off[k + 1]])
-            self._reply(index, OK)
-        self.stats["launches"] += 1
-        self.stats["sites"] += len(good)
-        self.stats["largest_launch"] = max(self.stats["largest_launch"], len(good))
+        try:
+            logits, meta, post = score(b["reads0"], b["rpa0"], b["aps"], b["reads1"], b["rpa1"], b["ref"])
+            self._scatter(idx, b["aps"], logits, meta, post)
+        except Exception as exc:                   # the whole launch failed: every site of it is answered with the reason
+            with self._state:
+                self.stats["errors"] += 1
+            for index in idx:
+                self._refuse(int(index), f"{type(exc).__name__}: {exc}")
+            return
+        for index in idx:
+            self._reply(int(index), OK)
+        with self._state:
+            self.stats["launches"] += 1
+            self.stats["sites"] += int(idx.shape[0])
+            self.stats["largest_launch"] = max(self.stats["largest_launch"], int(idx.shape[0]))
 
-    def _scorer_loop(self, score: Scorer) -> None:
-        while True:
-            with self._cond:
-                while not self._pending and not self._stop:
-                    self._cond.wait(0.25)
-                if self._stop and not self._pending:
-                    return
-                take = [self._pending.popleft() for _ in range(min(len(self._pending), self.max_batch_sites))]
-                self._inflight.update(take)
-            try:
-                self._score_batch(score, take)
-            finally:
-                with self._cond:
-                    self._inflight.difference_update(take)
-                    for index in [i for i in take if i in self._zombies]:
-                        self._zombies.discard(index)
-                        self._free.append(index)
-
-    # -- selector loop ----------------------------------------------------------------------------------------------
-    def _accept(self, sel) -> None:
+    # -- the leader: sockets -----------------------------------------------------------------------------------------
+    def _accept(self) -> None:
         import selectors
         conn, _ = self._listener.accept()
         try:
@@ -311,82 +356,121 @@ class SiteServer:
                 _send_msg(conn, {"error": f"protocol {hello.get('protocol')} != {PROTOCOL}"})
                 conn.close()
                 return
-            if not self._free:
+            with self._state:
+                index = self._free.popleft() if self._free else None
+            if index is None:
                 _send_msg(conn, {"error": f"all {self.max_clients} slots are taken"})
                 conn.close()
                 return
-            index = self._free.popleft()
             _send_msg(conn, dict(self.info, slot=index))
             conn.settimeout(None)
         except (OSError, ValueError, ConnectionError):
             conn.close()
             return
         self._socks[index] = conn
-        self.stats["clients_seen"] += 1
-        sel.register(conn, selectors.EVENT_READ, index)
+        with self._state:
+            self.stats["clients_seen"] += 1
+        self._sel.register(conn, selectors.EVENT_READ, index)
 
-    def _drop(self, sel, index: int) -> None:
+    def _drop(self, index: int) -> None:
         sock = self._socks.pop(index, None)
-        if sock is not None:
+        if sock is None:
+            return
+        try:
+            self._sel.unregister(sock)
+        except (KeyError, ValueError):
+            pass
+        sock.close()
+        if index in self._pending:                 # a dead client's queued site is not scored
+            self._pending.remove(index)
+        with self._state:                          # its slot is reusable -- but not while a launch still reads it
+            if index in self._inflight:
+                self._zombies.add(index)
+            else:
+                self._free.append(index)
+
+    def _poll_once(self, timeout: float) -> None:
+        for key, _ in self._sel.select(timeout=timeout):
+            if key.data is None:
+                self._accept()
+                continue
+            index = key.data
             try:
-                sel.unregister(sock)
-            except (KeyError, ValueError):
-                pass
-            sock.close()
-            with self._cond:                       # a dead client's queued site is not scored; its slot is reusable afterwards
-                try:
-                    self._pending.remove(index)
-                except ValueError:
-                    pass
-                if index in self._inflight:        # ... but not while a launch still reads it
-                    self._zombies.add(index)
-                else:
-                    self._free.append(index)
+                data = key.fileobj.recv(64)
+            except OSError:
+                data = b""
+            if not data:
+                self._drop(index)
+            elif data.count(REQ):                  # one outstanding request per client: further bytes are ignored
+                self._pending.append(index)
+            elif data.count(STATS):                # the server's counters, as JSON in the slot's message area
+                with self._state:
+                    stats = dict(self.stats, clients=len(self._socks), engines=len(self.scorers))
+                self.slots[index].write_error(json.dumps(stats))
+                self._reply(index, OK)
+
+    def _collect(self) -> List[int]:
+        """Called with the poll lock held: wait for requests, linger briefly for the clients that could still send one, and return
+        the slots of the next launch (empty when stopping)."""
+        first = None
+        while not self._stop:
+            if not self._pending:
+                first = None
+                self._poll_once(0.25)
+                if self._socks or self._pending:
+                    self._idle_since = time.monotonic()
+                elif self.idle_exit_s is not None and time.monotonic() - self._idle_since > self.idle_exit_s:
+                    self._stop = True
+                continue
+            now = time.monotonic()
+            first = first if first is not None else now
+            with self._state:
+                could_still_come = len(self._socks) - len(self._inflight) - len(self._pending)
+            left = self.linger_s - (now - first)
+            if could_still_come <= 0 or left <= 0 or len(self._pending) >= self.max_batch_sites:
+                break
+            self._poll_once(min(left, 50e-6))
+        n = self.max_batch_sites
+        take, self._pending = self._pending[:n], self._pending[n:]
+        with self._state:
+            self._inflight.update(take)
+        return take
+
+    def _scorer_loop(self, score: Scorer) -> None:
+        while not self._stop:
+            with self._poll:
+                take = self._collect() if not self._stop else []
+            if not take:
+                continue
+            try:
+                self._score_batch(score, take)
+            finally:
+                with self._state:
+                    self._inflight.difference_update(take)
+                    for index in [i for i in take if i in self._zombies]:
+                        self._zombies.discard(index)
+                        self._free.append(index)
 
     def serve(self) -> None:
         """Run until ``stop()`` or until no client has been connected for ``idle_exit_s`` seconds.  Cleans up its files."""
         import selectors
-        sel = selectors.DefaultSelector()
-        sel.register(self._listener, selectors.EVENT_READ, None)
+        self._sel = selectors.SelectSelector()     # select(2): microsecond timeouts (epoll's and poll's are rounded up to milliseconds)
+        self._sel.register(self._listener, selectors.EVENT_READ, None)
+        self._idle_since = time.monotonic()
         threads = [threading.Thread(target=self._scorer_loop, args=(s,), daemon=True) for s in self.scorers]
-        for t in threads:
-            t.start()
-        idle_since = time.monotonic()
         try:
-            while not self._stop:
-                events = sel.select(timeout=0.5)
-                for key, _ in events:
-                    if key.data is None:
-                        self._accept(sel)
-                        continue
-                    index = key.data
-                    try:
-                        data = key.fileobj.recv(64)
-                    except OSError:
-                        data = b""
-                    if not data:
-                        self._drop(sel, index)
-                        continue
-                    if data.count(REQ):            # one outstanding request per client: further bytes are ignored
-                        with self._cond:
-                            self._pending.append(index)
-                            self._cond.notify()
-                    elif data.count(STATS):        # the server's counters, as JSON in the slot's message area
-                        self.slots[index].write_error(json.dumps(dict(self.stats, clients=len(self._socks), engines=len(self.scorers))))
-                        self._reply(index, OK)
-                if self._socks:
-                    idle_since = time.monotonic()
-                elif self.idle_exit_s is not None and time.monotonic() - idle_since > self.idle_exit_s:
-                    break
+            for t in threads:
+                t.start()
+            while not self._stop and any(t.is_alive() for t in threads):
+                time.sleep(0.05)
         finally:
             self._stop = True
-            with self._cond:
-                self._cond.notify_all()
             for t in threads:
-                t.join(timeout=5.0)
-            for index in list(self._socks):
-                self._drop(sel, index)
-            sel.close()
+                t.join(timeout=10.0)
+            with self._poll:
+                for index in list(self._socks):
+                    self._drop(index)
+                self._sel.close()
             self._listener.close()
             for path in (self.socket_path, self.shm_path):
                 try:
@@ -502,7 +586,7 @@ class SharedScoringNetwork:
     reference's return structures, MixtureOfExpertsAdvanced.py:520-589), scored by the shared server of (model file, GPU)."""
 
     def __init__(self, path: str, device: int = 0, providePredictions: bool = False, engines: Optional[int] = None, arithmetic: Optional[str] = None,
-                 request_timeout: float = 120.0, start_timeout: float = 300.0, idle_exit_s: float = 15.0, directory: Optional[str] = None,
+                 request_timeout: float = 120.0, start_timeout: float = 300.0, idle_exit_s: Optional[float] = None, directory: Optional[str] = None,
                  connect_only: bool = False, socket_path: Optional[str] = None):
         self.path, self.device = path, int(device)
         self.providePredictions = providePredictions
@@ -515,6 +599,7 @@ class SharedScoringNetwork:
                 raise RuntimeError(f"no scoring server accepts connections at {socket_path}")
         else:
             engines = int(engines or os.environ.get("HELLO_SHARED_ENGINES", 2))      # scorer threads of a server THIS client starts
+            idle_exit_s = float(idle_exit_s if idle_exit_s is not None else os.environ.get("HELLO_SHARED_IDLE_EXIT", 15.0))
             sock = self._connect_or_start(engines, arithmetic, start_timeout, idle_exit_s, directory, connect_only)
         try:
             _send_msg(sock, {"protocol": PROTOCOL, "pid": os.getpid()})

@@ -32,6 +32,7 @@ def _as_arrays(result):
 @pytest.fixture
 def model_file(tmp_path, monkeypatch):
     monkeypatch.setenv("HELLO_SHARED_DIR", str(tmp_path / "rendezvous"))
+    monkeypatch.setenv("HELLO_SHARED_IDLE_EXIT", "1")         # the box admits few processes on its card: a test's server leaves at once
 
     def make(config, seed=11):
         spec = ns.build(config)
@@ -73,6 +74,7 @@ def test_shared_call_is_bit_identical_to_the_direct_per_site_call(model_file, co
 
 def _worker(path, rendezvous, rank, n_calls, out_q):
     os.environ["HELLO_SHARED_DIR"] = rendezvous
+    os.environ["HELLO_SHARED_IDLE_EXIT"] = "1"
     sys.path.insert(0, ROOT)
     import torch
     torch.set_num_threads(1)

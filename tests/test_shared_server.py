@@ -219,8 +219,8 @@ def test_server_death_raises_in_the_client_and_does_not_hang(server):
     killer.join()
     with pytest.raises(RuntimeError, match="closed"):
         net(fd, seg)
-    with pytest.raises(RuntimeError, match="no scoring server accepts"):
-        shared.SharedScoringNetwork("unused", socket_path=sock)
+    with pytest.raises(RuntimeError, match="no scoring server accepts|hung up during the handshake"):
+        shared.SharedScoringNetwork("unused", socket_path=sock)                           # (the dying process's backlog may still take a connect)
 
 
 def test_a_wedged_server_is_bounded_by_the_request_timeout(server):

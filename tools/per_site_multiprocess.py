@@ -38,6 +38,14 @@ def worker(rank, calls, start_evt, out_q, model_path, shared, config):
         net(fd, seg)
     dt = time.perf_counter() - t
     stats = net.server_stats() if shared else None
+    if stats is not None:                          # does this worker hold the GPU's device nodes open?  (it must not: only the server does)
+        fds = []
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                fds.append(os.readlink(f"/proc/self/fd/{fd}"))
+            except OSError:
+                pass
+        stats["worker_gpu_fds"] = sorted({f for f in fds if "kfd" in f or "renderD" in f})
     out_q.put(("done", rank, calls / dt, stats))
     net.close()
 
@@ -57,6 +65,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="hello_per_site_")
     os.environ.setdefault("HELLO_SHARED_DIR", os.path.join(tmp, "rendezvous"))
     os.environ["HELLO_SHARED_ENGINES"] = str(args.engines)
+    os.environ.setdefault("HELLO_SHARED_IDLE_EXIT", "1")      # this run's server leaves as soon as its workers have (few processes fit on the card)
     spec_name = bench.BENCH_CONFIGS[args.config]["spec"]
     spec = ns.build(spec_name)
     model_path = os.path.join(tmp, spec_name + ".npz")
