@@ -921,13 +921,15 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                     const long long bulk_reads = plan.rest_wgs ? plan.bulk_wgs * plan.groups_per_wg * G : total;
                     a.groups_per_wg = plan.groups_per_wg;
                     a.n_reads = bulk_reads;
-                    if ((e->stamp_mode & 1) && !t1) {
+                    int32_t stamp_lay[5] = {0, 0, 0, 0, 0};
+                    const int stamp_waves = hello::readconv_stamp_waves();
+                    if ((e->stamp_mode & 1) && !t1 && total > 0) {
                         // diagnostic forward: the stamped instantiation of the kernel (refused by the launch for any schedule but
-                        // the default fp32 Winograd one from the bytes)
+                        // the default fp32 Winograd one from the bytes).  A forward without reads stamps nothing.
                         if (wide || !a.reads) return fail(HELLO_ERR_ARG, "stamps: the canonical fused read convolver from the bytes only");
                         const long long wgs = plan.rest_wgs ? plan.bulk_wgs + plan.rest_wgs : (long long)((total + (long long)G * plan.groups_per_wg - 1) / ((long long)G * plan.groups_per_wg));
                         const int slots = hello::readconv_stamp_slots();
-                        const size_t bytes = (size_t)wgs * 4 * plan.groups_per_wg * slots * sizeof(uint64_t);
+                        const size_t bytes = (size_t)wgs * stamp_waves * plan.groups_per_wg * slots * sizeof(uint64_t);
                         if (bytes > e->d_stamps.cap) {
                             HIP_TRY(hipStreamSynchronize(stream));
                             if (e->d_stamps.ensure(bytes)) return fail(HELLO_ERR_HIP, "device allocation of %zu bytes failed", bytes);
@@ -936,13 +938,14 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                         a.stamps = (unsigned long long*)e->d_stamps.p;
                         a.stamp_groups = plan.groups_per_wg;
                         a.stamp_mode = e->stamp_mode;
-                        const int32_t lay[5] = {(int32_t)wgs, 4, plan.groups_per_wg, slots, (int32_t)(plan.rest_wgs ? plan.bulk_wgs : wgs)};
-                        for (int i = 0; i < 5; ++i) e->stamp_layout[i] = lay[i];
+                        const int32_t lay[5] = {(int32_t)wgs, stamp_waves, plan.groups_per_wg, slots, (int32_t)(plan.rest_wgs ? plan.bulk_wgs : wgs)};
+                        for (int i = 0; i < 5; ++i) stamp_lay[i] = lay[i];
+                        e->stamp_layout[0] = 0;               // nothing to read until both launches below have been accepted
                     }
                     HIP_TRY(wide ? hello::launch_readconv_wide(a, stream) : hello::launch_readconv_fused(a, stream));
                     if (plan.rest_wgs) {
                         hello::ReadConvArgs b = a;
-                        if (b.stamps) b.stamps += (size_t)plan.bulk_wgs * 4 * plan.groups_per_wg * hello::readconv_stamp_slots();
+                        if (b.stamps) b.stamps += (size_t)plan.bulk_wgs * stamp_waves * plan.groups_per_wg * hello::readconv_stamp_slots();
                         if (b.reads) b.reads += bulk_reads * d.window * o.cin;
                         else b.pooled += bulk_reads * (long long)o.lin * o.cin;
                         b.allele_of_read += bulk_reads;
@@ -951,6 +954,8 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                         b.n_reads = total - bulk_reads;
                         HIP_TRY(wide ? hello::launch_readconv_wide(b, stream) : hello::launch_readconv_fused(b, stream));
                     }
+                    if (a.stamps)                             // both launches went out: the layout debug_read_stamps reports is theirs
+                        for (int i = 0; i < 5; ++i) e->stamp_layout[i] = stamp_lay[i];
                 }
                 HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,
                                                         (float*)ptr(o.dst), A, o.lout, o.cout, stream));

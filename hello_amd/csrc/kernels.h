@@ -96,6 +96,7 @@ struct ReadConvArgs {
     int stamp_mode;            // bit 1: pad the LDS so that one workgroup is resident per CU
 };
 int readconv_stamp_slots();
+int readconv_stamp_waves();
 bool readconv_supports_window(int window);
 int readconv_reads_per_group(int window);
 int readconv_frame_rows(int window);       // positions per read after the read convolver: 36 | 61

@@ -151,6 +151,7 @@ bool readconv_supports_extra_blocks(int extra_blocks) { return extra_blocks == 0
 bool readconv_supports_window(int window) { return window == 150 || window == 250; }
 int readconv_reads_per_group(int window) { return window == 250 ? Geometry250::G : Geometry::G; }
 int readconv_stamp_slots() { return rc::STAMP_SLOTS; }
+int readconv_stamp_waves() { return Geometry::NW; }    // waves per workgroup of the stamped instantiation (the kernel indexes its records with CF::NW)
 int readconv_frame_rows(int window) { return window == 250 ? Geometry250::L2 : Geometry::L2; }
 // Groups a workgroup walks.  More groups per workgroup = fewer partial-sum slots and one prologue per several
 // groups (measured 1.2 %), but fewer, longer workgroups = a coarser tail when the last wave of workgroups does
@@ -1803,7 +1804,7 @@ static hipError_t launch_cfg(const ReadConvArgs& a, hipStream_t stream) {
         // workgroup's LDS past half a CU's, so that ONE workgroup is resident per CU (one wave per SIMD)
         if constexpr (std::is_same<CF, Geometry>::value && NB64 == 3 && WINO && !BF16 && !STEM_ONLY) {
             if (!a.reads || (a.channels != 6 && a.channels != 7) || a.stamp_groups < 1) return hipErrorInvalidValue;
-            static bool stamped_on[64] = {};
+            static bool stamped_on[64] = {};          // (engines on threads that share a device race benignly, like configured_on: the call is idempotent)
             if (!stamped_on[dev]) {
                 const hipError_t e = hipFuncSetAttribute((const void*)readconv_kernel<CF, true, NB64, WINO, false, false, true>,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);

@@ -137,7 +137,7 @@ def write_flat(path: str, arrays: dict) -> str:
     return path
 
 
-def _header_entry(path: str, name: str, entry, room: int):
+def _header_entry(path: str, name: str, entry, room: int, base: int = 0):
     """One checked entry of a ``.hshard`` header -> (dtype, shape, offset, bytes).  The header is the file's own claim
     about itself: a negative offset or dimension would make NumPy slice from the END of the buffer and hand back a wrong
     view without an error, so everything is refused here by name."""
@@ -160,9 +160,11 @@ def _header_entry(path: str, name: str, entry, room: int):
     nbytes = count * dt.itemsize
     if at + nbytes > room:
         raise ValueError(f"malformed shard {path}: array {name} runs past the end of the file")
-    if at % dt.itemsize:
-        # the view is handed by pointer to C and to the GPU: it must be aligned to its element (the writer aligns to 64)
-        raise ValueError(f"malformed shard {path}: array {name} starts at byte {at}, not a multiple of its {dt.itemsize}-byte element")
+    if (base + at) % dt.itemsize:
+        # the view is handed by pointer to C and to the GPU: its ABSOLUTE position in the file (header length included: a foreign
+        # writer need not pad its header to 64 bytes like write_flat) must be aligned to its element
+        raise ValueError(f"malformed shard {path}: array {name} starts at byte {base + at} of the file ({at} behind a header that ends at "
+                         f"{base}), not a multiple of its {dt.itemsize}-byte element")
     return dt, tuple(shape), at, nbytes
 
 
@@ -199,7 +201,7 @@ def read_flat(path: str) -> dict:
     base = 16 + n
     out, spans = {}, []
     for name, entry in header.items():
-        dt, shape, at, nbytes = _header_entry(path, name, entry, buf.shape[0] - base)
+        dt, shape, at, nbytes = _header_entry(path, name, entry, buf.shape[0] - base, base)
         spans.append((name, at, nbytes))
         out[name] = buf[base + at:base + at + nbytes].view(dt).reshape(shape)
     _refuse_overlaps(path, spans)
@@ -217,11 +219,11 @@ def read_flat_arrays(path: str, names: Sequence[str]) -> dict:
         if n > size - 16:
             raise ValueError(f"malformed shard {path}: the header is cut short ({size - 16} of {n} bytes)")
         header = _header(path, fh.read(n), n)
-        _refuse_overlaps(path, [(k,) + _header_entry(path, k, e, size - 16 - n)[2:] for k, e in header.items()])
+        _refuse_overlaps(path, [(k,) + _header_entry(path, k, e, size - 16 - n, 16 + n)[2:] for k, e in header.items()])
         out = {}
         for name in names:
             if name in header:
-                dt, shape, at, nbytes = _header_entry(path, name, header[name], size - 16 - n)
+                dt, shape, at, nbytes = _header_entry(path, name, header[name], size - 16 - n, 16 + n)
                 fh.seek(16 + n + at)
                 raw = fh.read(nbytes)
                 if len(raw) != nbytes:
@@ -375,6 +377,24 @@ class PackedShard:
                 where = f" ({kind} {i}" + (f", {self.chromosomes[i]}:{int(self.start[i])}" if named else "") + ")"
             raise ValueError(f"malformed shard: {what}{where}")
 
+        # every array the launch's staging block takes (shard_pipeline._fill concatenates them into typed views of one pinned block)
+        # must be an integer array whose values fit the staging type: a float or out-of-range array is refused here, by name,
+        # not by a casting error in the middle of a launch (or silently wrapped)
+        staged = dict(ref=np.uint8, ref_off=np.int64, window_start=np.int64, start=np.int64, stop=np.int64, alleles_per_site=np.int32)
+        for tech in (0, 1):
+            staged.update({f"{k}{tech}": t for k, t in (("reads_per_allele", np.int32), ("bases", np.uint8), ("quals", np.uint8),
+                                                         ("read_off", np.int64), ("cigars", np.uint32), ("cigar_off", np.int64),
+                                                         ("ref_start", np.int64), ("mapq", np.uint8), ("orientation", np.int8), ("hp", np.uint8))})
+        for name, want in staged.items():
+            if name not in self.z:
+                continue
+            arr = np.asarray(self.z[name])
+            if arr.dtype.kind not in "iu":
+                bad(f"array {name} has dtype {arr.dtype} (the launch stages it as {np.dtype(want).name}: integer arrays only)")
+            if arr.size and arr.dtype != np.dtype(want):
+                lim = np.iinfo(want)
+                if int(arr.min()) < lim.min or int(arr.max()) > lim.max:
+                    bad(f"array {name} ({arr.dtype}) holds values outside {np.dtype(want).name}, the type the launch stages it as")
         if S and int(self.alleles_per_site.min()) < 1:
             bad("a site without alleles", int(np.argmin(self.alleles_per_site)))
         for name in ("chromosome_of_site", "start", "stop", "window_start"):

@@ -308,7 +308,8 @@ def test_malformed_shards_are_refused(tmp_path):
         h = {k: list(v) for k, v in header.items()}
         for k, (field, value) in patch.items():
             h[k][field] = value
-        head = _json.dumps(h).encode("ascii")           # array offsets count from the end of the header: its length is free
+        head = _json.dumps(h).encode("ascii")           # array offsets count from the end of the header, which is padded so that
+        head += b" " * ((-(16 + len(head))) % 64)       # the arrays keep their absolute alignment (write_flat does the same)
         out = str(tmp_path / name)
         open(out, "wb").write(raw[:8] + np.uint64(len(head)).tobytes() + head + raw[16 + n:])
         return out
@@ -346,6 +347,24 @@ def test_malformed_shards_are_refused(tmp_path):
     for bad in ("frac_dim.hshard", "bool_dim.hshard", "overlap.hshard"):
         with pytest.raises(ValueError, match="non-integer|overlap"):
             shards.read_flat_arrays(str(tmp_path / bad), ["reads_per_allele0"])
+    # alignment is a property of the ABSOLUTE position: a foreign writer's header of odd length (write_flat pads to 64)
+    # shifts every array off its element's alignment although each offset alone looks aligned
+    head = _json.dumps(header).encode("ascii")
+    head += b" " * ((-(16 + len(head))) % 64 + 3)
+    open(tmp_path / "odd_header.hshard", "wb").write(raw[:8] + np.uint64(len(head)).tobytes() + head + raw[16 + n:])
+    for reader in (shards.read_flat, lambda p: shards.read_flat_arrays(p, ["start"])):
+        with pytest.raises(ValueError, match="starts at byte .* of the file .* not a multiple of its"):
+            reader(str(tmp_path / "odd_header.hshard"))
+    # ... and the arrays a launch stages must be integer arrays that fit their staging type: refused on load, by name
+    flat0 = shards.read_flat(path)
+    for patch, message in ((dict(mapq0=np.asarray(flat0["mapq0"], np.float32)), "array mapq0 has dtype float32"),
+                           (dict(cigars0=np.asarray(flat0["cigars0"], np.int64) + (1 << 33)), "array cigars0 .int64. holds values outside uint32"),
+                           (dict(window_start=np.asarray(flat0["window_start"], np.float64)), "array window_start has dtype float64")):
+        mistyped = shards.write_flat(str(tmp_path / "mistyped.hshard"), dict({k: np.array(v) for k, v in flat0.items()}, **patch))
+        with pytest.raises(ValueError, match=message):
+            shards.PackedShard.from_file(mistyped)
+    wider = shards.write_flat(str(tmp_path / "wider.hshard"), dict({k: np.array(v) for k, v in flat0.items()}, mapq0=np.asarray(flat0["mapq0"], np.int64)))
+    assert shards.PackedShard.from_file(wider).n_sites == shards.PackedShard.from_file(path).n_sites      # wider storage, values in range: fine
     # the load balancer's read totals honour has_second: stray second-technology counts of a single-technology shard weigh nothing
     from hello_amd import call as driver
     flat = shards.read_flat(path)
