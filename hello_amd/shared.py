@@ -14,12 +14,14 @@ keep their loop and their call, and share ONE engine process per GPU instead:
   Unix-domain socket and blocks in ``recv`` for the one-byte answer; then reads logits / meta / pair posteriors out of the
   slot and shapes them like the reference's return value.
 * ``SiteServer`` (one per (model file, GPU); a fresh child process of the first client -- ``python -m hello_amd.shared
-  --serve ...`` started with ``subprocess.Popen`` before anything in it touches the GPU; never a re-exec): one selector
-  loop takes the request bytes, scorer threads -- one engine each -- drain ALL pending slots into one
-  ``Engine.forward`` launch and scatter the answers back.  While one scorer's launch is on the GPU the next batch
-  collects and is launched by the other, so K blocked workers become launches of up to K sites instead of K one-site
-  launches.  Results are in slot order = arrival order; a site's answer does not depend on which other sites shared its
-  launch beyond the engine's documented ~1e-6 (bit-identical when it was alone).
+  --serve ...`` started with ``subprocess.Popen`` before anything in it touches the GPU; never a re-exec): the NATIVE server of
+  the in-tree library (``csrc/site_server.hip`` behind ``hello_site_server_*`` of ``include/hello_mi355x.h``): one scorer
+  thread per engine, leader / follower -- the idle thread waits on the sockets itself, drains ALL pending slots into one
+  ``hello_engine_forward`` launch, lingers a few tens of microseconds for the workers that could still send a site, and
+  scatters the answers back; no interpreter on a site's path.  K blocked workers become launches of up to K sites instead
+  of K one-site launches.  A site's answer does not depend on which other sites shared its launch beyond the engine's
+  documented ~1e-6 (bit-identical when it was alone).  This module is the client, the rendezvous and
+  the server process's ``main``.
 
 Liveness: the socket is the liveness signal both ways.  A server that dies closes every client's socket: the blocked
 ``recv`` returns and the client raises ``RuntimeError`` (no hang; a timeout bounds even a wedged server).  A client that dies
@@ -28,6 +30,7 @@ model once per shard, caller_calling.py:863: the server outlives them, so the mo
 """
 from __future__ import annotations
 
+import ctypes as C
 import hashlib
 import json
 import mmap
@@ -37,8 +40,7 @@ import struct
 import sys
 import threading
 import time
-from collections import deque
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, Optional, Sequence
 
 import numpy as np
 
@@ -84,7 +86,7 @@ class SlotLayout:
 
 
 class _Slot:
-    """NumPy views of one slot of the mapped segment."""
+    """NumPy views of one slot of the mapped segment: the client's side (the server reads and writes the same bytes in C++)."""
 
     def __init__(self, buf, index: int, lay: SlotLayout):
         base = index * lay.slot_bytes
@@ -135,37 +137,6 @@ class _Slot:
         n = int(self.header[H_ERRLEN])
         return bytes(self.err[:max(0, min(n, ERR_BYTES))]).decode("utf-8", "replace")
 
-    # -- server side -----------------------------------------------------------------------------------------------
-    def site_views(self):
-        """-> (alleles, reads0 [R0, L, C0] view, rpa0, reads1 view | None, rpa1 | None, ref [L, 5] | None); raises ValueError on a
-        header that does not describe a site that fits the slot (a client is another process: nothing it writes is trusted)."""
-        lay, h = self.lay, self.header
-        a, r0, r1 = int(h[H_ALLELES]), int(h[H_READS0]), int(h[H_READS1])
-        if not (1 <= a <= MAX_ALLELES) or r0 < a or r1 < 0 or (r1 and not lay.channels1):
-            raise ValueError(f"slot {self.index}: header describes no site (alleles {a}, reads {r0} / {r1})")
-        n0, n1 = r0 * lay.row_bytes(0), r1 * lay.row_bytes(1)
-        if n0 + n1 > lay.read_capacity:
-            raise ValueError(f"slot {self.index}: {n0 + n1} pileup bytes exceed the slot")
-        rpa0 = self.rpa0[:a]
-        rpa1 = self.rpa1[:a] if r1 else None
-        if int(rpa0.sum()) != r0 or rpa0.min() < 1 or (rpa1 is not None and (int(rpa1.sum()) != r1 or rpa1.min() < 1)):
-            raise ValueError(f"slot {self.index}: reads per allele do not add up to the read count (or an allele has no read)")
-        reads0 = self.reads[:n0].reshape(r0, lay.window, lay.channels0)
-        reads1 = self.reads[n0:n0 + n1].reshape(r1, lay.window, lay.channels1) if r1 else None
-        ref = self.ref.reshape(lay.window, 5) if h[H_HAS_REF] else None
-        return a, reads0, rpa0, reads1, rpa1, ref
-
-    def write_result(self, logits, meta, post) -> None:
-        self.logits.reshape(3, MAX_ALLELES)[:logits.shape[0], :logits.shape[1]] = logits
-        if meta is not None:
-            self.meta[:3] = meta
-        self.post.reshape(4, MAX_PAIRS)[:, :post.shape[1]] = post
-
-    def write_error(self, message: str) -> None:
-        raw = message.encode("utf-8", "replace")[:ERR_BYTES]
-        self.err[:len(raw)] = np.frombuffer(raw, np.uint8)
-        self.header[H_ERRLEN] = len(raw)
-
 
 def _send_msg(sock, obj) -> None:
     raw = json.dumps(obj).encode()
@@ -195,298 +166,149 @@ def _recv_msg(sock):
 Scorer = Callable[[np.ndarray, np.ndarray, np.ndarray, Optional[np.ndarray], Optional[np.ndarray], Optional[np.ndarray]], tuple]
 
 
+class _ServerConfig(C.Structure):                  # hello_site_server_config of include/hello_mi355x.h
+    _fields_ = [("window", C.c_int32), ("channels0", C.c_int32), ("channels1", C.c_int32), ("n_experts", C.c_int32),
+                ("has_meta", C.c_int32), ("uses_ref", C.c_int32), ("max_clients", C.c_int32), ("max_batch_sites", C.c_int32),
+                ("slot_bytes", C.c_int64), ("idle_exit_s", C.c_double), ("linger_s", C.c_double), ("info_json", C.c_char_p)]
+
+
+class _ServerStats(C.Structure):                   # hello_site_server_stats
+    _fields_ = [("launches", C.c_int64), ("sites", C.c_int64), ("errors", C.c_int64), ("largest_launch", C.c_int32), ("clients_seen", C.c_int32)]
+
+
+class _SlotLayoutC(C.Structure):                   # hello_site_slot_layout
+    _fields_ = [(k, C.c_int64) for k in ("header", "rpa0", "rpa1", "ref", "logits", "meta", "post", "err", "reads", "read_capacity")]
+
+
+_SCORER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                         C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32)
+_server_lib = None
+
+
+def server_library():
+    """The in-tree library's server entry points (host C++, csrc/site_server.hip); loads without a GPU."""
+    global _server_lib
+    if _server_lib is None:
+        from . import engine
+        lib = engine.load_library()
+        if not hasattr(lib, "hello_site_server_create"):
+            raise RuntimeError(f"{engine._LIB_PATH} was built before the shared scoring server (hello_site_server_*): rebuild it")
+        vp = C.c_void_p
+        lib.hello_site_slot_layout_of.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_SlotLayoutC)]
+        lib.hello_site_server_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(_ServerConfig), C.POINTER(vp)]
+        lib.hello_site_server_add_engine.argtypes = [vp, vp]
+        lib.hello_site_server_add_scorer.argtypes = [vp, _SCORER_FN, vp]
+        lib.hello_site_server_run.argtypes = [vp]
+        lib.hello_site_server_stop.argtypes = [vp]
+        lib.hello_site_server_stop.restype = None
+        lib.hello_site_server_get_stats.argtypes = [vp, C.POINTER(_ServerStats)]
+        lib.hello_site_server_destroy.argtypes = [vp]
+        lib.hello_site_server_destroy.restype = None
+        for fn in ("hello_site_slot_layout_of", "hello_site_server_create", "hello_site_server_add_engine", "hello_site_server_add_scorer",
+                   "hello_site_server_run", "hello_site_server_get_stats"):
+            getattr(lib, fn).restype = C.c_int
+        _server_lib = lib
+    return _server_lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"hello_mi355x: {server_library().hello_last_error().decode()} (status {rc})")
+
+
+def _callback(score: Scorer, info: Dict):
+    """A Python scorer behind the C ABI's hello_site_scorer (tests: the server without a GPU).  -> the ctypes callback object."""
+    window, c0, c1, n_experts = info["window"], info["channels0"], info["channels1"], info["n_experts"]
+
+    def view(ptr, dtype, shape):
+        n = int(np.prod(shape))
+        if not ptr or not n:
+            return None if not ptr else np.zeros(shape, dtype)
+        return np.frombuffer((C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype).reshape(shape)
+
+    def fn(ctx, reads0, rpa0, reads1, rpa1, aps, ref, S, A, R0, R1, logits, meta, post, err, err_cap):
+        try:
+            counts = view(aps, np.int32, (S,))
+            P = int((counts.astype(np.int64) * (counts + 1) // 2).sum())
+            lg, mt, po = score(view(reads0, np.uint8, (R0, window, c0)), view(rpa0, np.int32, (A,)), counts,
+                               view(reads1, np.uint8, (R1, window, c1)) if reads1 else None, view(rpa1, np.int32, (A,)) if rpa1 else None,
+                               view(ref, np.uint8, (S, window, 5)) if ref else None)
+            view(logits, np.float32, (n_experts, A))[...] = lg
+            if meta and mt is not None:
+                view(meta, np.float32, (S, 3))[...] = mt
+            view(post, np.float32, (4, P))[...] = po
+            return 0
+        except Exception as exc:                   # noqa: BLE001 -- reported to the launch's clients through the C ABI
+            raw = f"{type(exc).__name__}: {exc}".encode("utf-8", "replace")[:max(err_cap - 1, 0)]
+            C.memmove(err, raw + b"\0", len(raw) + 1)
+            return 1
+    return _SCORER_FN(fn)
+
+
 class SiteServer:
-    """One scoring server: a listening Unix socket, a shared-memory segment of ``max_clients`` slots and ``len(scorers)`` scorer
-    threads.  ``scorers`` are callables ``score(reads0, rpa0, aps, reads1, rpa1, ref) -> (logits [E, A], meta [S, 3] | None,
-    posteriors [4, P])`` -- ``engine_scorer(Engine)`` in the product; each is called from its own thread only.  ``info`` describes
-    the model to clients: window, channels0, channels1, n_experts, has_meta, uses_ref, ensemble.
+    """One scoring server: the native server of csrc/site_server.hip (a listening Unix socket, a shared-memory segment of
+    ``max_clients`` slots, one leader / follower scorer thread per engine) behind its C ABI.  ``engines`` are ``Engine`` objects
+    (the product: one ``hello_engine_forward`` per launch, no interpreter on the path); ``scorers`` are Python callables
+    ``score(reads0, rpa0, aps, reads1, rpa1, ref) -> (logits [E, A], meta [S, 3] | None, posteriors [4, P])`` behind the ABI's
+    scorer callback (tests drive the same server without a GPU through them).  ``info`` describes the model to clients: window,
+    channels0, channels1, n_experts, has_meta, uses_ref (+ whatever else the handshake should carry: ensemble, arithmetic).
 
-    Threads are leader / follower: whichever scorer thread is idle holds the poll lock, waits on the sockets itself (accepting
-    clients, noticing the dead ones, reading request bytes), takes EVERY pending slot as its launch and hands the lock to the next
-    idle thread before it scores -- no hand-over between a poller and a scorer on a site's way in.  A poller that has fewer requests
-    than there are clients who could still send one (connected minus in flight elsewhere) lingers up to ``linger_s`` for them: a
-    launch costs nearly the same for 1 or 16 sites (0.27 / 0.40 ms), so a few tens of microseconds of patience buy sites per launch
-    (measured on one MI355X, 16 workers: 17.7 k sites/s without lingering, 26.2 k with 120 us; cutting the clients into one group per
-    engine so that the groups run out of phase was measured too and is slower -- 22.3 k: the launches' host halves serialise on the
-    interpreter lock; profiles/r06_per_site_shared_sweep.txt)."""
+    A launch costs nearly the same for 1 or 16 sites (0.27 / 0.40 ms), so the thread that polls lingers up to ``linger_s`` for the
+    clients that could still send a site (connected minus in flight elsewhere) before its launch goes out (measured with the
+    round-6 Python prototype of this server on one MI355X, 16 workers: 17.7 k sites/s without lingering, 26.2 k with 120 us;
+    cutting the clients into one group per engine so that the groups run out of phase: 22.3 k; profiles/r06_per_site_shared_sweep.txt)."""
 
-    def __init__(self, socket_path: str, shm_path: str, info: Dict, scorers: Sequence[Scorer], slot_bytes: int = DEFAULT_SLOT_BYTES,
-                 max_clients: int = DEFAULT_MAX_CLIENTS, idle_exit_s: Optional[float] = 15.0, max_batch_sites: int = 4096,
-                 linger_s: Optional[float] = None):
+    def __init__(self, socket_path: str, shm_path: str, info: Dict, scorers: Sequence[Scorer] = (), engines: Sequence = (),
+                 slot_bytes: int = DEFAULT_SLOT_BYTES, max_clients: int = DEFAULT_MAX_CLIENTS, idle_exit_s: Optional[float] = 15.0,
+                 max_batch_sites: int = 4096, linger_s: Optional[float] = None):
+        self.lib = server_library()
         self.socket_path, self.shm_path = socket_path, shm_path
-        self.info = dict(info, protocol=PROTOCOL, slot_bytes=int(slot_bytes), max_clients=int(max_clients), shm_path=shm_path, pid=os.getpid())
-        self.layout = lay = SlotLayout(info["window"], info["channels0"], info["channels1"], slot_bytes)
-        self.scorers = list(scorers)
-        self.idle_exit_s, self.max_batch_sites = idle_exit_s, int(max_batch_sites)
-        self.linger_s = float(linger_s if linger_s is not None else float(os.environ.get("HELLO_SHARED_LINGER_US", 120)) * 1e-6)
-        self.max_clients = m = int(max_clients)
-        fd = os.open(shm_path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
-        try:
-            os.ftruncate(fd, m * lay.slot_bytes)
-            self._map = mmap.mmap(fd, m * lay.slot_bytes)
-        finally:
-            os.close(fd)
-        self.slots = [_Slot(self._map, i, lay) for i in range(m)]
-        # the same fields of EVERY slot as one strided array each: a launch gathers and scatters with a few NumPy calls, whatever its size
-        sb = lay.slot_bytes
-        view = lambda shape, dtype, off, strides: np.ndarray(shape, dtype, buffer=self._map, offset=off, strides=(sb,) + strides)   # noqa: E731
-        self._hdr = view((m, HEADER_INTS), np.int32, lay.header, (4,))
-        self._rpa0 = view((m, MAX_ALLELES), np.int32, lay.rpa0, (4,))
-        self._rpa1 = view((m, MAX_ALLELES), np.int32, lay.rpa1, (4,))
-        self._ref = view((m, lay.window, 5), np.uint8, lay.ref, (5, 1))
-        self._logits = view((m, 3, MAX_ALLELES), np.float32, lay.logits, (4 * MAX_ALLELES, 4))
-        self._meta = view((m, 4), np.float32, lay.meta, (4,))
-        self._post = view((m, 4, MAX_PAIRS), np.float32, lay.post, (4 * MAX_PAIRS, 4))
-        self._free = deque(range(m))
-        self._socks: Dict[int, socket.socket] = {}             # slot index -> client socket
-        self._pending: List[int] = []                          # requests read off the sockets, not yet part of a launch (poller's)
-        self._inflight: set = set()                            # slots a scorer thread is reading / writing right now
-        self._zombies: set = set()                             # ... whose client went away meanwhile: freed when the launch is over
-        self._state = threading.Lock()                         # guards _inflight / _zombies / _free / stats
-        self._poll = threading.Lock()                          # the leader's: sockets, selector, _pending, _socks
-        self._stop = False
-        self._idle_since = time.monotonic()
-        self._sel = None
-        self.stats = dict(launches=0, sites=0, largest_launch=0, clients_seen=0, errors=0)
-        if os.path.exists(socket_path):
-            os.unlink(socket_path)
-        self._listener = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-        self._listener.bind(socket_path)
-        os.chmod(socket_path, 0o600)
-        self._listener.listen(m)
+        linger = float(linger_s if linger_s is not None else float(os.environ.get("HELLO_SHARED_LINGER_US", 120)) * 1e-6)
+        extra = {k: v for k, v in info.items() if k not in ("window", "channels0", "channels1", "n_experts", "has_meta", "uses_ref")}
+        self._info_json = json.dumps(extra)[1:-1].encode()
+        cfg = _ServerConfig(int(info["window"]), int(info["channels0"]), int(info["channels1"]), int(info["n_experts"]), int(bool(info["has_meta"])),
+                            int(bool(info["uses_ref"])), int(max_clients), int(max_batch_sites), int(slot_bytes),
+                            -1.0 if idle_exit_s is None else float(idle_exit_s), linger, self._info_json or None)
+        handle = C.c_void_p()
+        _check(self.lib.hello_site_server_create(socket_path.encode(), shm_path.encode(), C.byref(cfg), C.byref(handle)))
+        self.handle = handle
+        self._keep = [_callback(s, info) for s in scorers]          # the callback objects must outlive the server
+        self._engines = list(engines)
+        for cb in self._keep:
+            _check(self.lib.hello_site_server_add_scorer(self.handle, cb, None))
+        for e in self._engines:
+            _check(self.lib.hello_site_server_add_engine(self.handle, e.handle))
+        self.n_scorers = len(self._keep) + len(self._engines)
 
-    # -- a launch ---------------------------------------------------------------------------------------------------
-    def _reply(self, index: int, byte: bytes) -> None:
-        sock = self._socks.get(index)
-        if sock is None:
-            return
-        try:
-            sock.sendall(byte)
-        except OSError:
-            pass                                   # the client went away while its site was being scored
-
-    def _refuse(self, index: int, message: str) -> None:
-        self.slots[index].write_error(message)
-        self._reply(index, ERR)
-
-    def _gather(self, take: List[int]):
-        """The slots of one launch -> (slot indices kept, batch arrays).  A client is another process: every header is checked
-        against the slot's capacity and its own tables before a byte of it is followed; a slot that fails is answered with the reason
-        and left out."""
-        lay = self.layout
-        idx = np.asarray(take, dtype=np.int64)
-        h = self._hdr[idx]
-        a, r0, r1, has_ref = (h[:, k].astype(np.int64) for k in (H_ALLELES, H_READS0, H_READS1, H_HAS_REF))
-        rb0, rb1 = lay.row_bytes(0), lay.row_bytes(1)
-        cols = np.arange(MAX_ALLELES)[None, :]
-        live = cols < a[:, None]
-        t0 = np.where(live, self._rpa0[idx], 0)
-        t1 = np.where(live, self._rpa1[idx], 0)
-        ok = (a >= 1) & (a <= MAX_ALLELES) & (r0 >= a) & (r1 >= 0) & ((r1 == 0) | (lay.channels1 > 0)) & (r0 * rb0 + r1 * rb1 <= lay.read_capacity)
-        ok &= (t0.sum(axis=1) == r0) & (np.where(live, t0, 1).min(axis=1) >= 1)
-        ok &= (r1 == 0) | ((t1.sum(axis=1) == r1) & (np.where(live, t1, 1).min(axis=1) >= 1))
-        # a launch holds sites of one shape of call (every client of a server speaks for the same model): a stray one is refused
-        second, with_ref = bool(r1[0] > 0), bool(has_ref[0])
-        ok &= ((r1 > 0) == second) & ((has_ref != 0) == with_ref)
-        if not ok.all():
-            for k in np.nonzero(~ok)[0]:
-                self._refuse(int(idx[k]), f"slot {int(idx[k])}: the header describes no site that fits the slot and the launch (alleles {int(a[k])}, "
-                                          f"reads {int(r0[k])} / {int(r1[k])}; reads per allele must add up, every allele needs a read, optional "
-                                          f"inputs must match the launch's)")
-            keep = np.nonzero(ok)[0]
-            if keep.size == 0:
-                return [], None
-            idx, a, r0, r1, t0, t1, live = idx[keep], a[keep], r0[keep], r1[keep], t0[keep], t1[keep], live[keep]
-        n = idx.shape[0]
-        slots = self.slots
-        if n == 1:
-            i = int(idx[0])
-            reads0 = slots[i].reads[:int(r0[0]) * rb0]
-            reads1 = slots[i].reads[int(r0[0]) * rb0:int(r0[0]) * rb0 + int(r1[0]) * rb1] if second else None
-        else:
-            reads0 = np.concatenate([slots[int(i)].reads[:int(n0)] for i, n0 in zip(idx, r0 * rb0)])
-            reads1 = np.concatenate([slots[int(i)].reads[int(n0):int(n0 + n1)] for i, n0, n1 in zip(idx, r0 * rb0, r1 * rb1)]) if second else None
-        batch = dict(aps=a.astype(np.int32), rpa0=t0[live].astype(np.int32), reads0=reads0.reshape(-1, lay.window, lay.channels0),
-                     rpa1=t1[live].astype(np.int32) if second else None,
-                     reads1=reads1.reshape(-1, lay.window, lay.channels1) if second else None,
-                     ref=np.ascontiguousarray(self._ref[idx]) if with_ref else None)
-        return idx, batch
-
-    def _scatter(self, idx, aps, logits, meta, post) -> None:
-        n = idx.shape[0]
-        a = aps.astype(np.int64)
-        site_a = np.repeat(np.arange(n), a)
-        local_a = np.arange(site_a.shape[0]) - np.repeat(np.cumsum(a) - a, a)
-        self._logits[idx[site_a][None, :], np.arange(logits.shape[0])[:, None], local_a[None, :]] = logits
-        if meta is not None:
-            self._meta[idx, :3] = meta
-        p = a * (a + 1) // 2
-        site_p = np.repeat(np.arange(n), p)
-        local_p = np.arange(site_p.shape[0]) - np.repeat(np.cumsum(p) - p, p)
-        self._post[idx[site_p][None, :], np.arange(4)[:, None], local_p[None, :]] = post
-
-    def _score_batch(self, score: Scorer, take: List[int]) -> None:
-        idx, b = self._gather(take)
-        if b is None:
-            return
-        try:
-            logits, meta, post = score(b["reads0"], b["rpa0"], b["aps"], b["reads1"], b["rpa1"], b["ref"])
-            self._scatter(idx, b["aps"], logits, meta, post)
-        except Exception as exc:                   # the whole launch failed: every site of it is answered with the reason
-            with self._state:
-                self.stats["errors"] += 1
-            for index in idx:
-                self._refuse(int(index), f"{type(exc).__name__}: {exc}")
-            return
-        for index in idx:
-            self._reply(int(index), OK)
-        with self._state:
-            self.stats["launches"] += 1
-            self.stats["sites"] += int(idx.shape[0])
-            self.stats["largest_launch"] = max(self.stats["largest_launch"], int(idx.shape[0]))
-
-    # -- the leader: sockets -----------------------------------------------------------------------------------------
-    def _accept(self) -> None:
-        import selectors
-        conn, _ = self._listener.accept()
-        try:
-            conn.settimeout(5.0)
-            hello = _recv_msg(conn)
-            if hello.get("protocol") != PROTOCOL:
-                _send_msg(conn, {"error": f"protocol {hello.get('protocol')} != {PROTOCOL}"})
-                conn.close()
-                return
-            with self._state:
-                index = self._free.popleft() if self._free else None
-            if index is None:
-                _send_msg(conn, {"error": f"all {self.max_clients} slots are taken"})
-                conn.close()
-                return
-            _send_msg(conn, dict(self.info, slot=index))
-            conn.settimeout(None)
-        except (OSError, ValueError, ConnectionError):
-            conn.close()
-            return
-        self._socks[index] = conn
-        with self._state:
-            self.stats["clients_seen"] += 1
-        self._sel.register(conn, selectors.EVENT_READ, index)
-
-    def _drop(self, index: int) -> None:
-        sock = self._socks.pop(index, None)
-        if sock is None:
-            return
-        try:
-            self._sel.unregister(sock)
-        except (KeyError, ValueError):
-            pass
-        sock.close()
-        if index in self._pending:                 # a dead client's queued site is not scored
-            self._pending.remove(index)
-        with self._state:                          # its slot is reusable -- but not while a launch still reads it
-            if index in self._inflight:
-                self._zombies.add(index)
-            else:
-                self._free.append(index)
-
-    def _poll_once(self, timeout: float) -> None:
-        for key, _ in self._sel.select(timeout=timeout):
-            if key.data is None:
-                self._accept()
-                continue
-            index = key.data
-            try:
-                data = key.fileobj.recv(64)
-            except OSError:
-                data = b""
-            if not data:
-                self._drop(index)
-            elif data.count(REQ):                  # one outstanding request per client: further bytes are ignored
-                self._pending.append(index)
-            elif data.count(STATS):                # the server's counters, as JSON in the slot's message area
-                with self._state:
-                    stats = dict(self.stats, clients=len(self._socks), engines=len(self.scorers))
-                self.slots[index].write_error(json.dumps(stats))
-                self._reply(index, OK)
-
-    def _collect(self) -> List[int]:
-        """Called with the poll lock held: wait for requests, linger briefly for the clients that could still send one, and return
-        the slots of the next launch (empty when stopping)."""
-        first = None
-        while not self._stop:
-            if not self._pending:
-                first = None
-                self._poll_once(0.25)
-                if self._socks or self._pending:
-                    self._idle_since = time.monotonic()
-                elif self.idle_exit_s is not None and time.monotonic() - self._idle_since > self.idle_exit_s:
-                    self._stop = True
-                continue
-            now = time.monotonic()
-            first = first if first is not None else now
-            with self._state:
-                could_still_come = len(self._socks) - len(self._inflight) - len(self._pending)
-            left = self.linger_s - (now - first)
-            if could_still_come <= 0 or left <= 0 or len(self._pending) >= self.max_batch_sites:
-                break
-            self._poll_once(min(left, 50e-6))
-        n = self.max_batch_sites
-        take, self._pending = self._pending[:n], self._pending[n:]
-        with self._state:
-            self._inflight.update(take)
-        return take
-
-    def _scorer_loop(self, score: Scorer) -> None:
-        while not self._stop:
-            with self._poll:
-                take = self._collect() if not self._stop else []
-            if not take:
-                continue
-            try:
-                self._score_batch(score, take)
-            finally:
-                with self._state:
-                    self._inflight.difference_update(take)
-                    for index in [i for i in take if i in self._zombies]:
-                        self._zombies.discard(index)
-                        self._free.append(index)
+    @property
+    def stats(self) -> Dict:
+        st = _ServerStats()
+        _check(self.lib.hello_site_server_get_stats(self.handle, C.byref(st)))
+        return dict(launches=int(st.launches), sites=int(st.sites), largest_launch=int(st.largest_launch), clients_seen=int(st.clients_seen),
+                    errors=int(st.errors))
 
     def serve(self) -> None:
-        """Run until ``stop()`` or until no client has been connected for ``idle_exit_s`` seconds.  Cleans up its files."""
-        import selectors
-        self._sel = selectors.SelectSelector()     # select(2): microsecond timeouts (epoll's and poll's are rounded up to milliseconds)
-        self._sel.register(self._listener, selectors.EVENT_READ, None)
-        self._idle_since = time.monotonic()
-        threads = [threading.Thread(target=self._scorer_loop, args=(s,), daemon=True) for s in self.scorers]
+        """Run until ``stop()`` or until no client has been connected for ``idle_exit_s`` seconds; then release everything (the
+        segment and the socket file are unlinked).  The blocking C call runs on a helper thread so that this (the main) thread
+        keeps executing bytecode: Python signal handlers -- which call ``stop()`` -- run while the server serves."""
+        result = []
+        worker = threading.Thread(target=lambda: result.append(self.lib.hello_site_server_run(self.handle)), daemon=True)
+        worker.start()
         try:
-            for t in threads:
-                t.start()
-            while not self._stop and any(t.is_alive() for t in threads):
-                time.sleep(0.05)
+            while worker.is_alive():
+                worker.join(0.2)
         finally:
-            self._stop = True
-            for t in threads:
-                t.join(timeout=10.0)
-            with self._poll:
-                for index in list(self._socks):
-                    self._drop(index)
-                self._sel.close()
-            self._listener.close()
-            for path in (self.socket_path, self.shm_path):
-                try:
-                    os.unlink(path)
-                except OSError:
-                    pass
+            self.lib.hello_site_server_stop(self.handle)
+            worker.join(15.0)
+            self.last_stats = self.stats
+            self.lib.hello_site_server_destroy(self.handle)
+            self.handle = None
+        if result and result[0] != 0:
+            _check(result[0])
 
     def stop(self) -> None:
-        self._stop = True
-
-
-def engine_scorer(engine) -> Scorer:
-    """The product's scorer: one ``Engine.forward`` launch over host arrays (logits, meta, pair posteriors back on the host)."""
-    def score(reads0, rpa0, aps, reads1, rpa1, ref):
-        return engine.forward(reads0, rpa0, aps, reads1, rpa1, ref, posteriors=True)
-    return score
+        if self.handle:
+            self.lib.hello_site_server_stop(self.handle)
 
 
 def model_info(program, spec) -> Dict:
@@ -504,7 +326,7 @@ def serve_model(path: str, device: int, socket_path: str, shm_path: str, engines
     from .engine import Engine
     spec, state = loader.load_spec(path)
     engs = [Engine(spec, state, device=device, arithmetic=arithmetic) for _ in range(max(1, engines))]
-    server = SiteServer(socket_path, shm_path, model_info(engs[0].program, spec), [engine_scorer(e) for e in engs],
+    server = SiteServer(socket_path, shm_path, model_info(engs[0].program, spec), engines=engs,
                         slot_bytes=slot_bytes, max_clients=max_clients, idle_exit_s=idle_exit_s)
     for sig in (signal.SIGTERM, signal.SIGINT):
         signal.signal(sig, lambda *_: server.stop())
@@ -514,7 +336,7 @@ def serve_model(path: str, device: int, socket_path: str, shm_path: str, engines
     finally:
         for e in engs:
             e.close()
-        print(f"hello_amd.shared: server {os.getpid()} leaves: {json.dumps(server.stats)}", file=sys.stderr, flush=True)
+        print(f"hello_amd.shared: server {os.getpid()} leaves: {json.dumps(getattr(server, 'last_stats', {}))}", file=sys.stderr, flush=True)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -719,7 +541,9 @@ class SharedScoringNetwork:
             raise RuntimeError(f"hello_mi355x (shared server): {self._slot.read_error()}")
         logits, meta, post = self._slot.read_result(info["n_experts"], info["has_meta"])
         keys = pair_keys(names[0])
-        rows = [dict(zip(keys, torch.from_numpy(post[r]).unbind(0))) for r in range(4)]
+        n = len(keys)
+        scalars = torch.from_numpy(post.reshape(-1)).unbind(0)           # 0-dim tensors of all four rows with one call
+        rows = [dict(zip(keys, scalars[r * n:(r + 1) * n])) for r in range(4)]
         if not self.providePredictions:
             return rows[0]
         m = torch.from_numpy(meta) if info["has_meta"] else _SINGLE_EXPERT_META.clone()

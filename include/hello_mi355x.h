@@ -333,6 +333,65 @@ void hello_records_destroy(hello_records* records);
 const char* hello_last_error(void);
 int hello_abi_version(void);
 
+/* ---- shared scoring server (host only; one per GPU) ------------------------------------------------------------------
+ * Stands in for: the model copy every worker process of the reference's pool loads for itself and calls once per site
+ * (python/call.py:111,215-221; python/caller_calling.py:863-868,872-891).  The workers keep their loop and their call
+ * (hello_amd/shared.py: the client packs a site into its slot of a shared-memory segment, sends one byte on a Unix-domain
+ * socket and blocks for the one-byte answer); ONE server process per (model file, GPU) drains all pending slots into one
+ * hello_engine_forward launch and scatters logits / meta / pair posteriors back.  An addition within ABI version 2.
+ *
+ * Slot (offsets: hello_site_slot_layout_of): int32 header [16] = {alleles, reads0, reads1, has_ref, pairs, message length};
+ * int32 reads_per_allele0 / 1 [HELLO_SITE_MAX_ALLELES]; uint8 reference one-hot [window][5]; results float32 logits
+ * [3][HELLO_SITE_MAX_ALLELES], meta [4], posteriors [4][MAX_ALLELES (MAX_ALLELES + 1) / 2]; a message area (errors, statistics
+ * as JSON); then the pileup bytes of technology 0 followed by technology 1.
+ * Wire: the client sends <u32 length><JSON with "protocol">, the server answers <u32 length><JSON: slot, slot_bytes, max_clients,
+ * shm_path, pid, the model's dimensions, `info_json`>; afterwards one byte each way per request: 'R' (score my slot) or 'S'
+ * (statistics into my slot's message area) -> 'K' (done) or 'E' (refused: the reason is in the message area). */
+#define HELLO_SITE_PROTOCOL 1
+#define HELLO_SITE_MAX_ALLELES 64
+
+typedef struct hello_site_slot_layout {      /* byte offsets inside one slot */
+    int64_t header, rpa0, rpa1, ref, logits, meta, post, err, reads, read_capacity;
+} hello_site_slot_layout;
+
+typedef struct hello_site_server_config {
+    int32_t window, channels0, channels1;    /* the model, as the clients are told (and as every slot is checked against) */
+    int32_t n_experts, has_meta, uses_ref;
+    int32_t max_clients;                     /* slots of the segment */
+    int32_t max_batch_sites;                 /* sites of one launch at most */
+    int64_t slot_bytes;
+    double idle_exit_s;                      /* leave after this long without a client; < 0: never */
+    double linger_s;                         /* patience for the clients that could still send a site before a launch goes out */
+    const char* info_json;                   /* further members of the handshake object ("k": v, ...) or NULL */
+} hello_site_server_config;
+
+typedef struct hello_site_server_stats {
+    int64_t launches, sites, errors;
+    int32_t largest_launch, clients_seen;
+} hello_site_server_stats;
+
+/* A scorer other than an engine (tests drive the server without a GPU through this): fill logits [n_experts][A], meta [S][3]
+ * (NULL when the model has none) and posteriors [4][sum_s A_s(A_s+1)/2]; return 0, or non-zero with a message in `err`. */
+typedef int (*hello_site_scorer)(void* ctx, const uint8_t* reads0, const int32_t* reads_per_allele0, const uint8_t* reads1,
+                                 const int32_t* reads_per_allele1, const int32_t* alleles_per_site, const uint8_t* ref_onehot,
+                                 int32_t n_sites, int32_t n_alleles, int64_t n_reads0, int64_t n_reads1, float* logits, float* meta,
+                                 float* posteriors, char* err, int32_t err_capacity);
+
+typedef struct hello_site_server hello_site_server;
+
+int hello_site_slot_layout_of(int32_t window, int32_t channels0, int32_t channels1, int64_t slot_bytes, hello_site_slot_layout* out);
+/* Creates the segment file and the listening socket (a connectable socket = a ready server: add the scorers first or right after). */
+int hello_site_server_create(const char* socket_path, const char* shm_path, const hello_site_server_config* config, hello_site_server** out);
+/* One scorer thread per engine / scorer added; every engine is used from its own thread only. */
+int hello_site_server_add_engine(hello_site_server* server, hello_engine* engine);
+int hello_site_server_add_scorer(hello_site_server* server, hello_site_scorer scorer, void* ctx);
+/* Blocks: serves until hello_site_server_stop (callable from any thread or a signal handler) or the idle limit. */
+int hello_site_server_run(hello_site_server* server);
+void hello_site_server_stop(hello_site_server* server);
+int hello_site_server_get_stats(hello_site_server* server, hello_site_server_stats* out);
+/* Closes the sockets, unmaps and unlinks the segment and the socket file. */
+void hello_site_server_destroy(hello_site_server* server);
+
 #ifdef __cplusplus
 }
 #endif

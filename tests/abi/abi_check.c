@@ -50,6 +50,40 @@ int main(void) {
     FIELD(hello_records_view, n_records); FIELD(hello_records_view, best_pair); FIELD(hello_records_view, best_p);
     FIELD(hello_records_view, qual);
 
+    STRUCT(hello_site_slot_layout);
+    FIELD(hello_site_slot_layout, header); FIELD(hello_site_slot_layout, rpa0); FIELD(hello_site_slot_layout, rpa1);
+    FIELD(hello_site_slot_layout, ref); FIELD(hello_site_slot_layout, logits); FIELD(hello_site_slot_layout, meta);
+    FIELD(hello_site_slot_layout, post); FIELD(hello_site_slot_layout, err); FIELD(hello_site_slot_layout, reads);
+    FIELD(hello_site_slot_layout, read_capacity);
+
+    STRUCT(hello_site_server_config);
+    FIELD(hello_site_server_config, window); FIELD(hello_site_server_config, channels0); FIELD(hello_site_server_config, channels1);
+    FIELD(hello_site_server_config, n_experts); FIELD(hello_site_server_config, has_meta); FIELD(hello_site_server_config, uses_ref);
+    FIELD(hello_site_server_config, max_clients); FIELD(hello_site_server_config, max_batch_sites);
+    FIELD(hello_site_server_config, slot_bytes); FIELD(hello_site_server_config, idle_exit_s); FIELD(hello_site_server_config, linger_s);
+    FIELD(hello_site_server_config, info_json);
+
+    STRUCT(hello_site_server_stats);
+    FIELD(hello_site_server_stats, launches); FIELD(hello_site_server_stats, sites); FIELD(hello_site_server_stats, errors);
+    FIELD(hello_site_server_stats, largest_launch); FIELD(hello_site_server_stats, clients_seen);
+
+    printf("const HELLO_SITE_PROTOCOL %d\nconst HELLO_SITE_MAX_ALLELES %d\n", HELLO_SITE_PROTOCOL, HELLO_SITE_MAX_ALLELES);
+    {
+        hello_site_slot_layout lay;
+        hello_site_server* server = (hello_site_server*)0x1;
+        rc = hello_site_slot_layout_of(150, 6, 7, 1 << 20, &lay);
+        printf("call hello_site_slot_layout_of %d %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", rc, (long long)lay.header, (long long)lay.rpa0,
+               (long long)lay.rpa1, (long long)lay.ref, (long long)lay.logits, (long long)lay.meta, (long long)lay.post, (long long)lay.err,
+               (long long)lay.reads, (long long)lay.read_capacity);
+        if (rc != HELLO_OK) return 5;
+        if (hello_site_slot_layout_of(150, 6, 0, 512, &lay) != HELLO_ERR_ARG) return 6;       /* a slot that cannot hold one read */
+        rc = hello_site_server_create(NULL, NULL, NULL, &server);
+        printf("call hello_site_server_create(NULL) %d message %s\n", rc, hello_last_error());
+        if (rc != HELLO_ERR_ARG) return 7;
+        hello_site_server_stop(NULL);           /* no-ops by contract */
+        hello_site_server_destroy(NULL);
+    }
+
     printf("const HELLO_ABI_VERSION %d\n", HELLO_ABI_VERSION);
     printf("const HELLO_IN_DEVICE %d\nconst HELLO_OUT_DEVICE %d\nconst HELLO_LAYOUT_RCL %d\n", HELLO_IN_DEVICE, HELLO_OUT_DEVICE,
            HELLO_LAYOUT_RCL);

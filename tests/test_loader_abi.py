@@ -430,7 +430,7 @@ def test_c99_consumer_sees_the_structs_the_ctypes_mirrors_describe(tmp_path):
     side does not follow -- or the reverse -- fails here instead of corrupting an engine call."""
     import shutil
     import subprocess
-    from hello_amd import engine, records
+    from hello_amd import engine, records, shared
     cc = shutil.which("cc") or shutil.which("gcc")
     assert cc, "no C compiler on this box"
     lib_dir = os.path.join(ROOT, "hello_amd")
@@ -454,7 +454,9 @@ def test_c99_consumer_sees_the_structs_the_ctypes_mirrors_describe(tmp_path):
         elif kind == "call":
             calls[name] = rest[0]
     mirrors = {"hello_op": engine.HelloOp, "hello_buffer": engine.HelloBuffer, "hello_model_desc": engine.HelloModelDesc,
-               "hello_site_table": records._SiteTable, "hello_features_format": records._FeaturesFormat, "hello_records_view": records._View}
+               "hello_site_table": records._SiteTable, "hello_features_format": records._FeaturesFormat, "hello_records_view": records._View,
+               "hello_site_slot_layout": shared._SlotLayoutC, "hello_site_server_config": shared._ServerConfig,
+               "hello_site_server_stats": shared._ServerStats}
     assert set(structs) == set(mirrors) == set(fields)
     for name, mirror in mirrors.items():
         assert ctypes.sizeof(mirror) == structs[name], name
@@ -477,6 +479,12 @@ def test_c99_consumer_sees_the_structs_the_ctypes_mirrors_describe(tmp_path):
         engine.HELLO_IN_DEVICE, engine.HELLO_OUT_DEVICE, engine.HELLO_LAYOUT_RCL)
     assert consts["HELLO_OP_READCONV_FUSED"] == 8 and consts["HELLO_OP_XATTN_FRONT"] == 11 and consts["HELLO_BUF_FIRST_SCRATCH"] == 3
     assert calls["hello_abi_version"] == str(engine.ABI_VERSION)
+    # the shared scoring server's wire constants and slot layout: the Python client computes the same offsets the C++ server uses
+    assert (consts["HELLO_SITE_PROTOCOL"], consts["HELLO_SITE_MAX_ALLELES"]) == (shared.PROTOCOL, shared.MAX_ALLELES)
+    lay = shared.SlotLayout(150, 6, 7, 1 << 20)
+    assert [int(x) for x in calls["hello_site_slot_layout_of"].split()] == [0, lay.header, lay.rpa0, lay.rpa1, lay.ref, lay.logits, lay.meta, lay.post,
+                                                                          lay.err, lay.reads, lay.read_capacity]
+    assert calls["hello_site_server_create(NULL)"].startswith("-1 message ")
     assert calls["hello_engine_create(NULL)"].startswith("-1 engine_reset 1 message ") and "NULL" in calls["hello_engine_create(NULL)"]
     assert calls["hello_engine_create(out=NULL)"].startswith("-1 message ")
 

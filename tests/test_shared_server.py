@@ -1,7 +1,7 @@
 """hello_amd.shared on the CPU: slot packing, coalescing and ordering across client processes, server death (the client raises,
-no hang), client death (the slot comes back), refusals.  The server here runs with an injected deterministic scorer in place of
-the engine (a test double for the GPU: the product's ``serve_model`` builds real engines and has no other path); the real thing is
-tests/test_gpu_shared.py."""
+no hang), client death (the slot comes back), refusals.  The server here is the product's native server (csrc/site_server.hip
+behind its C ABI) with a deterministic Python scorer plugged into the ABI's scorer callback in place of an engine (a test double
+for the GPU: the product's ``serve_model`` adds real engines and has no other path); the real thing is tests/test_gpu_shared.py."""
 import multiprocessing as mp
 import os
 import signal
@@ -59,7 +59,7 @@ def expected(info, feature_dict, segment):
 
 
 def _serve(sock, shm, info, scorers, delay, idle, max_clients, ready):
-    server = shared.SiteServer(sock, shm, info, [fake_scorer(info["n_experts"], info["has_meta"], delay) for _ in range(scorers)],
+    server = shared.SiteServer(sock, shm, info, scorers=[fake_scorer(info["n_experts"], info["has_meta"], delay) for _ in range(scorers)],
                                slot_bytes=1 << 20, max_clients=max_clients, idle_exit_s=idle)
     signal.signal(signal.SIGTERM, lambda *_: server.stop())
     ready.set()
@@ -108,26 +108,23 @@ def test_slot_layout_round_trips_a_site():
     reads1 = rng.integers(0, 255, (5, 150, 7), dtype=np.uint8)
     ref = rng.integers(0, 2, (1, 150, 5), dtype=np.uint8)
     slot.write_site(reads0, rpa0, reads1, rpa1, ref)
-    a, r0, c0, r1, c1, rf = slot.site_views()
-    assert a == 3 and np.array_equal(r0, reads0) and np.array_equal(r1, reads1) and np.array_equal(c0, rpa0) and np.array_equal(c1, rpa1)
-    assert np.array_equal(rf, ref[0]) and not buf[:lay.slot_bytes].strip(b"\0")          # nothing spilled into slot 0
+    h = slot.header
+    assert (int(h[shared.H_ALLELES]), int(h[shared.H_READS0]), int(h[shared.H_READS1]), int(h[shared.H_HAS_REF]), int(h[shared.H_PAIRS])) == (3, 9, 5, 1, 6)
+    assert np.array_equal(slot.rpa0[:3], rpa0) and np.array_equal(slot.rpa1[:3], rpa1) and np.array_equal(slot.ref.reshape(150, 5), ref[0])
+    n0, n1 = reads0.size, reads1.size
+    assert np.array_equal(slot.reads[:n0].reshape(reads0.shape), reads0) and np.array_equal(slot.reads[n0:n0 + n1].reshape(reads1.shape), reads1)
+    assert not bytes(buf[:lay.slot_bytes]).strip(b"\0")                                 # nothing spilled into slot 0
+    # the result area as the server fills it: rows of fixed stride (logits [3][64], posteriors [4][2080])
     logits, meta, post = rng.standard_normal((3, 3)).astype(np.float32), np.array([.2, .3, .5], np.float32), rng.random((4, 6)).astype(np.float32)
-    slot.write_result(logits, meta, post)
+    slot.logits.reshape(3, shared.MAX_ALLELES)[:, :3] = logits
+    slot.meta[:3] = meta
+    slot.post.reshape(4, shared.MAX_PAIRS)[:, :6] = post
     got = slot.read_result(3, True)
     assert np.array_equal(got[0], logits) and np.array_equal(got[1], meta) and np.array_equal(got[2], post)
-    slot.write_error("Σ reads_per_allele ≠ R")
-    assert slot.read_error() == "Σ reads_per_allele ≠ R"
     with pytest.raises(ValueError, match="does not fit a shared slot"):
         slot.write_site(np.zeros((1200, 150, 6), np.uint8), np.array([1200], np.int32), None, None, None)
     with pytest.raises(ValueError, match="at most 64"):
         slot.write_site(np.zeros((65, 150, 6), np.uint8), np.ones(65, np.int32), None, None, None)
-    # a header that lies is refused by the server's views, not followed
-    slot.header[shared.H_READS0] = 10 ** 6
-    with pytest.raises(ValueError, match="exceed the slot|do not add up"):
-        slot.site_views()
-    slot.header[shared.H_ALLELES] = 0
-    with pytest.raises(ValueError, match="describes no site"):
-        slot.site_views()
 
 
 def test_one_client_gets_the_reference_structures(server):
@@ -160,6 +157,17 @@ def test_one_client_gets_the_reference_structures(server):
         with pytest.raises(ValueError, match="integers in 0..255"):
             net({"A": (np.full((2, 150, 6), 0.5, np.float32), None)}, seg)
         assert net.server_stats()["sites"] == 6
+        # a client is another process: a header that lies is refused by the server's checks (reason in the slot), not followed
+        good = net(fd, seg)
+        for field, value in ((shared.H_READS0, 10 ** 6), (shared.H_ALLELES, 0), (shared.H_ALLELES, 65), (shared.H_READS1, 3)):
+            keep = int(net._slot.header[field])
+            net._slot.header[field] = value
+            assert net._roundtrip() == shared.ERR and "describes no site that fits" in net._slot.read_error()
+            net._slot.header[field] = keep
+        net._slot.rpa0[0] += 1                                                            # reads per allele no longer add up
+        assert net._roundtrip() == shared.ERR
+        net._slot.rpa0[0] -= 1
+        assert net._roundtrip() == shared.OK and net(fd, seg)[0].keys() == good[0].keys()  # the server is none the worse for it
     with pytest.raises(RuntimeError, match="closed"):
         net(fd, seg)
 
