@@ -20,7 +20,6 @@
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -272,12 +271,12 @@ void poll_once(Server* s, double timeout_s) {
     }
 }
 
-// Sites one launch takes at most.  EXPERIMENT (HELLO_SITE_GROUPS=1 in the server's environment): with several engines a launch takes
-// its share of the clients (clients / engines), so that the groups run out of phase -- one group's launch on the GPU while the
-// other group's workers pack their next site -- instead of all workers in lockstep.
+// Sites one launch takes at most.  With `group_launches` and several engines a launch takes its SHARE of the clients (clients /
+// engines), so that the groups run out of phase -- one group's launch is on the GPU while the other group's workers build their
+// results and pack their next site -- instead of all workers in lockstep with the GPU idle in between (measured on one MI355X,
+// 2 engines: 16 workers 27.1 k -> 31.2 k sites/s, 32 workers 51.2 k -> 57.6 k; profiles/r06_per_site_shared_native.txt).
 int launch_cap(Server* s) {
-    static const bool groups = getenv("HELLO_SITE_GROUPS") && getenv("HELLO_SITE_GROUPS")[0] == '1';
-    if (!groups || s->scorers.size() < 2) return s->cfg.max_batch_sites;
+    if (!s->cfg.group_launches || s->scorers.size() < 2) return s->cfg.max_batch_sites;
     int clients;
     {
         std::lock_guard<std::mutex> g(s->state_mu);

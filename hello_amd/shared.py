@@ -169,7 +169,7 @@ Scorer = Callable[[np.ndarray, np.ndarray, np.ndarray, Optional[np.ndarray], Opt
 class _ServerConfig(C.Structure):                  # hello_site_server_config of include/hello_mi355x.h
     _fields_ = [("window", C.c_int32), ("channels0", C.c_int32), ("channels1", C.c_int32), ("n_experts", C.c_int32),
                 ("has_meta", C.c_int32), ("uses_ref", C.c_int32), ("max_clients", C.c_int32), ("max_batch_sites", C.c_int32),
-                ("slot_bytes", C.c_int64), ("idle_exit_s", C.c_double), ("linger_s", C.c_double), ("info_json", C.c_char_p)]
+                ("group_launches", C.c_int32), ("reserved", C.c_int32), ("slot_bytes", C.c_int64), ("idle_exit_s", C.c_double), ("linger_s", C.c_double), ("info_json", C.c_char_p)]
 
 
 class _ServerStats(C.Structure):                   # hello_site_server_stats
@@ -254,9 +254,11 @@ class SiteServer:
     channels0, channels1, n_experts, has_meta, uses_ref (+ whatever else the handshake should carry: ensemble, arithmetic).
 
     A launch costs nearly the same for 1 or 16 sites (0.27 / 0.40 ms), so the thread that polls lingers up to ``linger_s`` for the
-    clients that could still send a site (connected minus in flight elsewhere) before its launch goes out (measured with the
-    round-6 Python prototype of this server on one MI355X, 16 workers: 17.7 k sites/s without lingering, 26.2 k with 120 us;
-    cutting the clients into one group per engine so that the groups run out of phase: 22.3 k; profiles/r06_per_site_shared_sweep.txt)."""
+    clients that could still send a site (connected minus in flight elsewhere) before its launch goes out, and with several
+    engines a launch takes its share of the clients (clients / engines) so that the groups run out of phase (``HELLO_SHARED_GROUPS=0``
+    switches that off).  Measured on one MI355X, 16 workers: no lingering 24.8 k sites/s, lingering 27-30 k, + groups 31.2 k
+    (profiles/r06_per_site_shared_native.txt; the round's Python prototype of this server: 17.7 k / 26.2 k, and groups were a loss
+    there -- 22.3 k: its launches' host halves serialised on the interpreter lock; profiles/r06_per_site_shared_sweep.txt)."""
 
     def __init__(self, socket_path: str, shm_path: str, info: Dict, scorers: Sequence[Scorer] = (), engines: Sequence = (),
                  slot_bytes: int = DEFAULT_SLOT_BYTES, max_clients: int = DEFAULT_MAX_CLIENTS, idle_exit_s: Optional[float] = 15.0,
@@ -267,7 +269,8 @@ class SiteServer:
         extra = {k: v for k, v in info.items() if k not in ("window", "channels0", "channels1", "n_experts", "has_meta", "uses_ref")}
         self._info_json = json.dumps(extra)[1:-1].encode()
         cfg = _ServerConfig(int(info["window"]), int(info["channels0"]), int(info["channels1"]), int(info["n_experts"]), int(bool(info["has_meta"])),
-                            int(bool(info["uses_ref"])), int(max_clients), int(max_batch_sites), int(slot_bytes),
+                            int(bool(info["uses_ref"])), int(max_clients), int(max_batch_sites),
+                            int(os.environ.get("HELLO_SHARED_GROUPS", "1") != "0"), 0, int(slot_bytes),
                             -1.0 if idle_exit_s is None else float(idle_exit_s), linger, self._info_json or None)
         handle = C.c_void_p()
         _check(self.lib.hello_site_server_create(socket_path.encode(), shm_path.encode(), C.byref(cfg), C.byref(handle)))

@@ -359,6 +359,8 @@ typedef struct hello_site_server_config {
     int32_t n_experts, has_meta, uses_ref;
     int32_t max_clients;                     /* slots of the segment */
     int32_t max_batch_sites;                 /* sites of one launch at most */
+    int32_t group_launches;                  /* != 0 with several engines: a launch takes clients / engines sites, the groups run out of phase */
+    int32_t reserved;                        /* 0 */
     int64_t slot_bytes;
     double idle_exit_s;                      /* leave after this long without a client; < 0: never */
     double linger_s;                         /* patience for the clients that could still send a site before a launch goes out */

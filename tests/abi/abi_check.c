@@ -60,6 +60,7 @@ int main(void) {
     FIELD(hello_site_server_config, window); FIELD(hello_site_server_config, channels0); FIELD(hello_site_server_config, channels1);
     FIELD(hello_site_server_config, n_experts); FIELD(hello_site_server_config, has_meta); FIELD(hello_site_server_config, uses_ref);
     FIELD(hello_site_server_config, max_clients); FIELD(hello_site_server_config, max_batch_sites);
+    FIELD(hello_site_server_config, group_launches); FIELD(hello_site_server_config, reserved);
     FIELD(hello_site_server_config, slot_bytes); FIELD(hello_site_server_config, idle_exit_s); FIELD(hello_site_server_config, linger_s);
     FIELD(hello_site_server_config, info_json);
 
