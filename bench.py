@@ -434,6 +434,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the device-resident, latency, small-batch, parity and other-configuration legs (headline only)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configurations)")
+    ap.add_argument("--no-shared-leg", action="store_true", help="skip the worker-pool leg (`per_site_shared`: a child process tree)")
     ap.add_argument("--config-launches", type=int, default=40, help="timed launches of each configuration of the `configs` block")
     ap.add_argument("--fused", choices=["full", "trunk", "none"], default="full",
                     help="read convolver: one fused kernel from the bytes / layer-by-layer stem + fused trunk / "
@@ -733,7 +734,7 @@ def main():
         "pcie_h2d_gbs": round(float(np.mean([batch_input_bytes(b) for b in piece_batches])) / launch_s / 1e9, 3),
     }
 
-    device_resident = latency = small = parity = two_engines = bf16x3 = configs = None
+    device_resident = latency = small = parity = two_engines = bf16x3 = configs = per_site_shared = None
     if secondary:
         stream = torch.cuda.current_stream(dev).cuda_stream
         # ---- device-resident rate: pileups already in HBM, outputs left there (no PCIe in the loop) --------------
@@ -945,6 +946,26 @@ def main():
         if args.config in answers:
             parity = parity_of(eng, answers[args.config])
 
+        # ---- the reference's worker pool on this card (call.py:111,215-221): W single-threaded worker PROCESSES, each with the
+        # unchanged per-site call, sharing ONE scoring server (loader.load(path, shared=True), hello_amd/shared.py +
+        # csrc/site_server.hip).  A child process tree of its own (fresh interpreters; the workers never touch the GPU).
+        if not args.no_shared_leg:
+            try:
+                import subprocess
+                workers = max(2, min(16, host_cores()))
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "per_site_multiprocess.py"), "--shared", "--json", "--workers",
+                                      str(workers), "--calls", "1500", "--config", args.config],
+                                     cwd=ROOT, capture_output=True, text=True, timeout=600)
+                lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+                if out.returncode == 0 and lines:
+                    per_site_shared = json.loads(lines[-1])
+                    per_site_shared["note"] = ("worker processes of the reference's deployment form, one site per call each through the unchanged "
+                                               "plug-in surface, scored by one shared server process on this GPU")
+                else:
+                    print(f"shared-server leg failed (rc {out.returncode}): {out.stderr[-800:]}", file=sys.stderr)
+            except Exception as exc:
+                print(f"shared-server leg failed: {exc!r}", file=sys.stderr)
+
         # ---- the OTHER BASELINE.json configurations, through the same path (make_sites -> pinned host batch -> HostPipeline ->
         # Engine, posteriors back on the host): host-to-host rate at --sites sites per launch, the dominant kernel's roofline
         # fraction from the engine's HIP events, max |delta| vs the oracle on the check sites
@@ -1089,6 +1110,7 @@ def main():
             "latency": latency,
             "parity": parity,
             "small_batch": small,
+            "per_site_shared": per_site_shared,
             "configs": configs,
         }
         print(json.dumps(line), flush=True)

@@ -75,7 +75,7 @@ struct hello_site_server {
     std::vector<Scorer> scorers;
     // the leader's (under poll_mu): sockets and what came off them
     std::mutex poll_mu;
-    std::vector<int> fd_of_slot;                 // -1: free or zombie
+    std::unique_ptr<std::atomic<int>[]> fd_of_slot;   // -1: free or zombie; written by the leader, read by the scorer threads' replies
     std::vector<int> pending;
     double idle_since = 0.0;
     // shared small state (under state_mu)
@@ -138,7 +138,7 @@ void write_error(Server* s, int index, const char* fmt, ...) {
 }
 
 void reply(Server* s, int index, char byte) {
-    const int fd = s->fd_of_slot[index];         // read without the poll mutex: a stale fd at worst answers a socket that is closing
+    const int fd = s->fd_of_slot[index].load(std::memory_order_relaxed);   // without the poll mutex: a stale fd at worst answers a socket that is closing
     if (fd >= 0) (void)send(fd, &byte, 1, MSG_NOSIGNAL);
 }
 
@@ -202,16 +202,16 @@ void accept_client(Server* s) {
     }
     tv = timeval{0, 0};
     setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-    s->fd_of_slot[index] = fd;
+    s->fd_of_slot[index].store(fd);
     std::lock_guard<std::mutex> g(s->state_mu);
     s->n_clients++;
     s->stats.clients_seen++;
 }
 
 void drop_client(Server* s, int index) {
-    const int fd = s->fd_of_slot[index];
+    const int fd = s->fd_of_slot[index].load();
     if (fd < 0) return;
-    s->fd_of_slot[index] = -1;
+    s->fd_of_slot[index].store(-1);
     close(fd);
     for (size_t k = 0; k < s->pending.size(); ++k)          // a dead client's queued site is not scored
         if (s->pending[k] == index) {
@@ -244,8 +244,8 @@ void poll_once(Server* s, double timeout_s) {
     fds.push_back(pollfd{s->listener, POLLIN, 0});
     who.push_back(-1);
     for (int i = 0; i < s->cfg.max_clients; ++i)
-        if (s->fd_of_slot[i] >= 0) {
-            fds.push_back(pollfd{s->fd_of_slot[i], POLLIN, 0});
+        if (s->fd_of_slot[i].load(std::memory_order_relaxed) >= 0) {
+            fds.push_back(pollfd{s->fd_of_slot[i].load(std::memory_order_relaxed), POLLIN, 0});
             who.push_back(i);
         }
     timespec ts;
@@ -540,7 +540,8 @@ int hello_site_server_create(const char* socket_path, const char* shm_path, cons
         unlink(shm_path);
         return hello::set_last_error(HELLO_ERR_ARG, "site server: cannot listen on %s: %s", socket_path, strerror(e));
     }
-    s->fd_of_slot.assign((size_t)cfg->max_clients, -1);
+    s->fd_of_slot.reset(new std::atomic<int>[(size_t)cfg->max_clients]);
+    for (int i = 0; i < cfg->max_clients; ++i) s->fd_of_slot[i].store(-1);
     s->inflight.assign((size_t)cfg->max_clients, 0);
     s->zombie.assign((size_t)cfg->max_clients, 0);
     for (int i = 0; i < cfg->max_clients; ++i) s->free_slots.push_back(i);
@@ -603,8 +604,8 @@ void hello_site_server_destroy(hello_site_server* s) {
     if (!s) return;
     s->stop.store(1);
     if (s->listener >= 0) close(s->listener);
-    for (int fd : s->fd_of_slot)
-        if (fd >= 0) close(fd);
+    for (int i = 0; i < s->cfg.max_clients && s->fd_of_slot; ++i)
+        if (s->fd_of_slot[i].load() >= 0) close(s->fd_of_slot[i].load());
     if (s->map) munmap(s->map, s->map_bytes);
     unlink(s->socket_path.c_str());
     unlink(s->shm_path.c_str());

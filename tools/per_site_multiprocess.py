@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--shared", action="store_true", help="workers load the model with shared=True: one scoring server for all of them")
     ap.add_argument("--engines", type=int, default=2, help="engines (scorer threads) of the shared server")
     ap.add_argument("--config", default="C2", help="bench.py configuration (model + synthetic sites)")
+    ap.add_argument("--json", action="store_true", help="print ONE JSON line (bench.py's `per_site_shared` leg) instead of the table")
     args = ap.parse_args()
     if args.workers > 6 and not args.shared:
         raise SystemExit("at most 6 processes may use the card on this pool")
@@ -83,6 +84,14 @@ def main():
     wall = time.perf_counter() - t0
     for p in procs:
         p.join()
+    if args.json:
+        stats = max((r[3] for r in rates), key=lambda s: s["sites"]) if args.shared else None
+        print(json.dumps({"value": round(sum(r[2] for r in rates), 1), "unit": "sites/s", "workers": args.workers, "calls_per_worker": args.calls,
+                          "by_wall_clock_of_slowest": round(args.workers * args.calls / wall, 1), "config": args.config,
+                          "ms_per_call_mean": round(1e3 * args.workers / sum(r[2] for r in rates), 4),
+                          "form": "loader.load(path, shared=True): one native server process" if args.shared else "an engine per worker",
+                          "engines": args.engines if args.shared else args.workers, "server": stats}))
+        return
     for _, rank, rate, _ in rates:
         print(f"  worker {rank}: {rate:8.0f} sites/s ({1e3 / rate:.3f} ms per call)")
     form = f"loader.load(path, shared=True): one server process, {args.engines} engine(s)" if args.shared else "an engine per worker"
