@@ -955,7 +955,7 @@ def main():
                 workers = max(2, min(16, host_cores()))
                 out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "per_site_multiprocess.py"), "--shared", "--json", "--workers",
                                       str(workers), "--calls", "1500", "--config", args.config],
-                                     cwd=ROOT, capture_output=True, text=True, timeout=600)
+                                     cwd=ROOT, capture_output=True, text=True, timeout=240)
                 lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
                 if out.returncode == 0 and lines:
                     per_site_shared = json.loads(lines[-1])

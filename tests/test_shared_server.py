@@ -318,3 +318,26 @@ def test_load_shared_refuses_what_load_refuses_and_never_falls_back_to_the_cpu(t
     loader.save_native(path, "single_tech", weights.synth_state(spec, seed=1))
     with pytest.raises(RuntimeError, match="exited with status .* before it was ready"):
         loader.load(path, shared=True, start_timeout=240)
+
+
+def test_native_server_is_clean_under_threadsanitizer(tmp_path):
+    """The server's source compiled as plain host C++ with tests/abi/site_server_tsan.cpp under -fsanitize=thread: ten client THREADS
+    speaking the wire protocol (hanging up and reconnecting in the middle of their runs) against three scorer threads with launch
+    grouping on -- every answer is the caller's own, every site is scored exactly once in launches of several sites, and
+    ThreadSanitizer reports no data race (leader / follower hand-over, in-flight / zombie slots, the fd table, statistics)."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++") or shutil.which("c++")
+    assert cxx, "no C++ compiler on this box"
+    exe = str(tmp_path / "site_server_tsan")
+    build = subprocess.run([cxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"), "-x", "c++",
+                            os.path.join(ROOT, "hello_amd", "csrc", "site_server.hip"), os.path.join(ROOT, "tests", "abi", "site_server_tsan.cpp"),
+                            "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:exitcode=66"))
+    assert "ThreadSanitizer" not in run.stderr, run.stderr[-4000:]
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr[-2000:])
+    fields = dict(zip(run.stdout.split()[0::2], run.stdout.split()[1::2]))
+    assert fields["sites"] == "3000" and fields["failures"] == "0" and fields["errors"] == "0" and int(fields["launches"]) < 3000
+    assert int(fields["clients_seen"]) > 10                                               # the clients really hung up and came back

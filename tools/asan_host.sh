@@ -1,5 +1,6 @@
 #!/bin/bash
-# AddressSanitizer + UndefinedBehaviorSanitizer over the HOST side of libhello_mi355x.so (record stage, creation-time validation, shard hand-over):
+# AddressSanitizer + UndefinedBehaviorSanitizer over the HOST side of libhello_mi355x.so (record stage, creation-time validation, shard hand-over,
+# the shared scoring server's threads / sockets / slot checks):
 # the whole library is rebuilt with the sanitizer on the host half of every translation unit (the gfx950 device code is
 # compiled as usual; GPU ASan is not available on this pool), and the CPU tests that call into the library run against it.
 #
@@ -25,5 +26,5 @@ OBJS=$(for f in $SRCS; do echo "$OUT/${f%.hip}.o"; done)
 cd "$ROOT"
 echo "# tools/asan_host.sh: $(basename "$RT"), HELLO_LIB=tools/_bin/asan/libhello_asan.so"
 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:abort_on_error=1 LD_PRELOAD="$RT" HELLO_LIB="$OUT/libhello_asan.so" \
-    python -m pytest tests/test_records.py tests/test_call_driver.py tests/test_loader_abi.py \
+    python -m pytest tests/test_records.py tests/test_call_driver.py tests/test_loader_abi.py tests/test_shared_server.py \
     -q -m "not gpu" -p no:cacheprovider "$@"

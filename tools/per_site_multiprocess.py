@@ -84,6 +84,8 @@ def main():
     wall = time.perf_counter() - t0
     for p in procs:
         p.join()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)         # the model file and the rendezvous directory of this run (the server unlinks its own files)
     if args.json:
         stats = max((r[3] for r in rates), key=lambda s: s["sites"]) if args.shared else None
         print(json.dumps({"value": round(sum(r[2] for r in rates), 1), "unit": "sites/s", "workers": args.workers, "calls_per_worker": args.calls,
