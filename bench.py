@@ -187,6 +187,15 @@ def parity_of(engine, answers):
            "against": "oracle/moe_oracle.py (NumPy back end), one site per call"}
     if want_meta is not None:
         out["max_abs_delta_meta"] = float(np.abs(got_meta - want_meta).max())
+    # "identical calls": the call of a site is its most probable genotype pair of the mixture row (caller_calling.py:698-712) and
+    # QUAL = -10 log10(1 - min(p, 1 - 1e-8)) (vcfFromContigs.py:215-220): the same pair on every check site, and how far QUAL moves
+    a = np.asarray(check.alleles_per_site, np.int64)
+    p_off = np.concatenate([[0], np.cumsum(a * (a + 1) // 2)])
+    best = lambda post: np.array([int(np.argmax(post[0, p_off[s]:p_off[s + 1]])) for s in range(check.n_sites)])     # noqa: E731
+    top = lambda post: np.array([float(post[0, p_off[s]:p_off[s + 1]].max()) for s in range(check.n_sites)])         # noqa: E731
+    qual = lambda p: -10.0 * np.log10(1.0 - np.minimum(p, 1.0 - 1e-8))                                               # noqa: E731
+    out["sites_with_identical_call"] = int((best(got_post) == best(want_post)).sum())
+    out["qual_max_abs_delta"] = float(np.abs(qual(top(got_post.astype(np.float64))) - qual(top(want_post.astype(np.float64)))).max())
     out["within_tolerance"] = bool(max(v for k, v in out.items() if k.startswith("max_abs_delta")) <= 1e-4)
     return out
 

@@ -223,7 +223,10 @@ def test_bench_default_run_reports_every_baseline_configuration():
                           "--cpu-budget", "1", "--config-launches", "4"], cwd=root, env=_bench_env(), capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stderr[-3000:]
     z = json.loads(_json_lines(out.stdout)[-1])
-    assert z["config"]["name"] == "C2" and z["parity"]["within_tolerance"] and z["parity"]["sites"] == 96
+    assert z["config"]["name"] == "C2" and z["parity"]["within_tolerance"] and z["parity"]["sites"] == 96 and z["parity"]["sites_with_identical_call"] == 96
+    ps = z["per_site_shared"]
+    assert ps is not None and ps["value"] > 0 and ps["workers"] >= 2 and ps["server"]["server"] == "native" and ps["server"]["errors"] == 0
+    assert ps["server"]["sites"] >= ps["workers"] * ps["calls_per_worker"] and ps["server"]["worker_gpu_fds"] == []
     assert z["cpu_baseline"]["config"] == "C2" and z["cpu_baseline"]["value"] > 0
     assert z["gather_verified_ranks"] is None                                  # no process group in a plain N = 1 run
     cfgs = z["configs"]
@@ -235,6 +238,7 @@ def test_bench_default_run_reports_every_baseline_configuration():
         assert e["repeat_passes_bit_identical"] and e["arithmetic"] == "fp32"
         par = e["parity"]
         assert par["within_tolerance"] and par["sites"] == 96 and par["max_abs_delta_pair_posterior"] <= 1e-4 and par["max_abs_delta_allele_probability"] <= 1e-4
+        assert par["sites_with_identical_call"] == 96 and par["qual_max_abs_delta"] < 0.5
     assert cfgs["hybrid_full"]["parity"]["max_abs_delta_meta"] <= 1e-4 and cfgs["hybrid_full"]["n_experts"] == 3 and cfgs["hybrid_full"]["has_meta"]
     assert cfgs["C5"]["channels"] == [7, 0] and cfgs["C4"]["channels"] == [6, 6]
 
