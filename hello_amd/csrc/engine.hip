@@ -1013,6 +1013,19 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     return hello::exception_status("hello_engine_forward");
 }
 
+// Host memory the GPU reads and writes in place (hipHostMalloc: pinned, mapped, coherent): a caller that builds small batches in such
+// a block passes them to hello_engine_forward as DEVICE pointers -- no staging copy, no copy-engine hop either way (the shared scoring
+// server does, csrc/site_server.hip).  NULL when the allocation fails (e.g. no GPU).
+void* hello_pinned_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void hello_pinned_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int hello_engine_posteriors(hello_engine* e, const float* logits, const float* meta, const int32_t* aps,
                             int32_t S, int32_t A, int64_t n_pairs_total, float* out, int32_t flags,
                             void* hip_stream) try {

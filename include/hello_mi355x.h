@@ -226,6 +226,13 @@ int hello_engine_featurize(hello_engine* engine,
  * binding does (hello_amd/engine.py). */
 void* hello_engine_stream(hello_engine* engine);
 
+/* Host memory the GPU reads and writes in place (pinned, mapped, coherent): pointers into such a block may be passed to
+ * hello_engine_forward under HELLO_IN_DEVICE / HELLO_OUT_DEVICE -- a small batch then crosses PCIe inside the kernels' own loads and
+ * stores, with no staging copy and no copy-engine hop (followed by hello_engine_synchronize before the host reads the outputs).
+ * NULL when the allocation fails (no GPU).  An addition within ABI version 2. */
+void* hello_pinned_alloc(size_t bytes);
+void hello_pinned_free(void* block);
+
 /* Wait for everything the engine has enqueued on its last stream. */
 int hello_engine_synchronize(hello_engine* engine);
 

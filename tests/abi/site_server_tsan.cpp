@@ -45,6 +45,9 @@ extern "C" int hello_engine_forward(hello_engine*, const uint8_t*, const int32_t
                                     int32_t, int64_t, int64_t, float*, float*, float*, int32_t, void*) {
     return HELLO_ERR_NOGPU;                       // the harness never adds an engine
 }
+extern "C" int hello_engine_synchronize(hello_engine*) { return HELLO_ERR_NOGPU; }
+extern "C" void* hello_pinned_alloc(size_t) { return nullptr; }      // (only engine scorers ask for pinned blocks)
+extern "C" void hello_pinned_free(void*) {}
 
 namespace {
 
