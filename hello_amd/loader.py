@@ -342,14 +342,15 @@ def load_spec(path: str) -> Tuple[ns.ModelSpec, Dict[str, np.ndarray]]:
     return _load_reference_pickle(path, kind)
 
 
-def load(path: str, device: int = 0, shared: bool = False, **kw):
+def load(path: str, device=0, shared: bool = False, **kw):
     """Drop-in for ``torch.load(path)`` in the reference caller: returns a network object with
     ``.eval()``, ``.providePredictions`` and ``__call__(featureDict, ref_segment)``.
 
     ``shared=True`` is for the reference's deployment form -- a pool of worker processes that each load the model and score one
     site per call (call.py:111,215-221): the object then holds no engine of its own; its calls go to ONE scoring server per
     (model file, GPU), started by the first worker, which coalesces the workers' concurrent sites into one launch
-    (``hello_amd.shared``).  The calling process never touches the GPU."""
+    (``hello_amd.shared``).  The calling process never touches the GPU.  ``device="auto"`` spreads a pool's workers over the node's GPUs
+    (process id modulo the device count): one server per GPU."""
     if shared:
         from .shared import SharedScoringNetwork
         sniff(path)                                # a git-LFS pointer / an empty file is refused here, by name, not in the server's log

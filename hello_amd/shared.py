@@ -405,15 +405,24 @@ def start_server(path: str, device: int, paths, engines: int = 2, arithmetic: Op
     raise RuntimeError(f"the scoring server for {path} was not ready after {start_timeout:.0f} s (log: {log_path})")
 
 
+def pick_device(device) -> int:
+    """``device`` as given, or -- ``"auto"`` -- this worker's share of the node: process id modulo the number of GPUs (a pool's workers
+    have consecutive ids, so they spread evenly; counting devices does not initialise the GPU), one scoring server per GPU."""
+    if device != "auto":
+        return int(device)
+    import torch
+    return os.getpid() % max(torch.cuda.device_count(), 1)
+
+
 class SharedScoringNetwork:
     """The object a worker holds as ``network`` when it loaded the model with ``shared=True``: the per-site plug-in surface of
     ``hello_amd.wrapper.ScoringNetwork`` (``.eval()``, ``.providePredictions``, ``__call__(featureDict, ref_segment)`` with the
     reference's return structures, MixtureOfExpertsAdvanced.py:520-589), scored by the shared server of (model file, GPU)."""
 
-    def __init__(self, path: str, device: int = 0, providePredictions: bool = False, engines: Optional[int] = None, arithmetic: Optional[str] = None,
+    def __init__(self, path: str, device=0, providePredictions: bool = False, engines: Optional[int] = None, arithmetic: Optional[str] = None,
                  request_timeout: float = 120.0, start_timeout: float = 300.0, idle_exit_s: Optional[float] = None, directory: Optional[str] = None,
                  connect_only: bool = False, socket_path: Optional[str] = None):
-        self.path, self.device = path, int(device)
+        self.path, self.device = path, pick_device(device)
         self.providePredictions = providePredictions
         self.training = False
         self.request_timeout = float(request_timeout)

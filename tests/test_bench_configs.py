@@ -122,3 +122,28 @@ def test_lib_sha256_follows_the_library_the_engine_opens(tmp_path, monkeypatch):
     monkeypatch.setattr(engine, "_LIB_PATH", str(tmp_path / "absent.so"))
     assert bench.lib_sha256() is None
     assert bench.committed_traffic(os.path.join(ROOT, "profiles", "hbm_traffic.json"), None)[2]["traffic_stale"] in (True, None)
+
+
+def test_oracle_pool_answers_equal_the_oracle_called_directly(tmp_path):
+    """tests/oracle_pool.py (the child process tree behind the GPU suite's exhaustive full-launch parity): started as a child, it
+    regenerates the batch from its seed, scores every site through the per-site oracle on a forked pool and writes probabilities,
+    meta weights and pair posteriors in site order -- equal to the oracle called directly, for a hybrid ensemble model."""
+    from oracle import moe_oracle as mo
+    from tests import oracle_pool
+    kw = dict(coverage=12, hybrid_coverage=6)
+    out = str(tmp_path / "answers.npz")
+    got = oracle_pool.collect(oracle_pool.start("hybrid_full", 33, 14, 77, kw, out), out, timeout=600)
+    spec = ns.build("hybrid_full")
+    batch = synth.make_sites(14, seed=77, **kw)
+    want_logits, want_meta = mo.forward_batch(mo.Oracle(spec, weights.synth_state(spec, seed=33), backend="torch"), batch, chunk_sites=1)
+    assert got["logits"].shape == (3, batch.n_alleles) and got["workers"] >= 1 and got["seconds"] > 0
+    np.testing.assert_allclose(got["logits"], want_logits, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got["probs"], mo.sigmoid(want_logits), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got["meta"], want_meta, rtol=0, atol=1e-6)
+    a = np.asarray(batch.alleles_per_site, np.int64)
+    p_off = np.concatenate([[0], np.cumsum(a * (a + 1) // 2)])
+    a_off = np.concatenate([[0], np.cumsum(a)])
+    assert got["post"].shape == (4, int(p_off[-1]))
+    for s in (0, 5, 13):
+        rows = mo.posteriors([mo.sigmoid(want_logits[e, a_off[s]:a_off[s + 1]]) for e in range(3)], want_meta[s])
+        np.testing.assert_allclose(got["post"][:, p_off[s]:p_off[s + 1]], np.stack(rows), rtol=0, atol=1e-6)

@@ -300,6 +300,15 @@ def test_rendezvous_is_per_model_file_and_device(tmp_path):
     assert oct(os.stat(tmp_path / "rv").st_mode & 0o777) == "0o700"
 
 
+def test_auto_device_spreads_workers_over_the_gpus(monkeypatch):
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(os, "getpid", lambda: 4243)
+    assert shared.pick_device("auto") == 4243 % 8 and shared.pick_device(3) == 3 and shared.pick_device("5") == 5
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)                             # no GPU visible: device 0 (the server will say so)
+    assert shared.pick_device("auto") == 0
+
+
 def test_load_shared_refuses_what_load_refuses_and_never_falls_back_to_the_cpu(tmp_path, monkeypatch):
     """``loader.load(path, shared=True)``: a git-LFS pointer is refused by name before any server starts; with a real model file and
     no GPU the server child exits (``Engine()`` raises: there is no CPU fallback) and the client raises with the end of its log."""
