@@ -135,7 +135,12 @@ struct CompressorArgs {
     const float* w;            // packed block, hello_amd/readconv_pack.py pack_compressor
     long long n_items;
     int blocks;                // identity residual blocks after the strided one: 2 | 3
+    int items_per_wg;          // 1..8 items a workgroup carries; 0: the launcher picks (small_launch_items_per_wg)
 };
+// Items per workgroup of the LDS-resident allele-stage kernels (compressor_kernel, xattn_front_kernel; one workgroup per CU).  A
+// workgroup's time grows with the items it carries (compressor: 84 us with 2, 121 us with 8; front: 29 / 57 us) while a small launch
+// leaves most CUs idle: spread the items over the CUs -- ceil(items / CUs), at most `most` (whole workgroups once every CU has one).
+int small_launch_items_per_wg(long long n_items, int most);
 int compressor_weight_floats(int blocks);
 bool compressor_supports_blocks(int blocks);
 hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream);
@@ -154,6 +159,7 @@ struct XattnFrontArgs {
     long long n_items;
     float a0, a1;              // LinearCombination coefficients (2, -1)
     int rest;                  // x = a - (s - a) in that rounding order (MoEMergedAdvanced, :372-383) instead of a0 a + a1 s
+    int items_per_wg;          // 1..8 items a workgroup carries; 0: the launcher picks (small_launch_items_per_wg)
 };
 int xattn_front_weight_floats();
 hipError_t launch_xattn_front(const XattnFrontArgs& a, hipStream_t stream);

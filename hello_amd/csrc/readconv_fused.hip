@@ -1918,8 +1918,9 @@ __global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(Compres
     float* const dump = smem + 2 * CF::BUF_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long item0 = (long long)blockIdx.x * G;
-    const int n_here = (int)((a.n_items - item0) < G ? (a.n_items - item0) : G);
+    // a workgroup carries a.items_per_wg <= G items (fewer in small launches, so that the items spread over the CUs: kernels.h)
+    const long long item0 = (long long)blockIdx.x * a.items_per_wg;
+    const int n_here = (int)((a.n_items - item0) < a.items_per_wg ? (a.n_items - item0) : a.items_per_wg);
     const float* __restrict__ W = a.w;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -2018,9 +2019,17 @@ __global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(Compres
         dst[f] = *(const f32x4*)(bufB + img_off<128, SW_3>(1 + (f >> 5), f & 31));
 }
 
-hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream) {
-    if (a.n_items <= 0) return hipSuccess;
-    if (!compressor_supports_blocks(a.blocks) || !a.frames || !a.dst || !a.w) return hipErrorInvalidValue;
+int small_launch_items_per_wg(long long n_items, int most) {
+    const long long cus = device_cus();
+    const long long n = (n_items + cus - 1) / cus;
+    return (int)(n < 1 ? 1 : (n > most ? most : n));
+}
+
+hipError_t launch_compressor_fused(const CompressorArgs& args, hipStream_t stream) {
+    if (args.n_items <= 0) return hipSuccess;
+    CompressorArgs a = args;
+    if (a.items_per_wg == 0) a.items_per_wg = small_launch_items_per_wg(a.n_items, cc::Cfg::G);
+    if (!compressor_supports_blocks(a.blocks) || !a.frames || !a.dst || !a.w || a.items_per_wg < 1 || a.items_per_wg > cc::Cfg::G) return hipErrorInvalidValue;
     static bool configured_on[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -2033,7 +2042,7 @@ hipError_t launch_compressor_fused(const CompressorArgs& a, hipStream_t stream) 
         if (e != hipSuccess) return e;
         configured_on[dev] = true;
     }
-    const unsigned grid = (unsigned)((a.n_items + cc::Cfg::G - 1) / cc::Cfg::G);
+    const unsigned grid = (unsigned)((a.n_items + a.items_per_wg - 1) / a.items_per_wg);
     if (a.blocks == 2) hipLaunchKernelGGL(compressor_kernel<2>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
     else if (a.blocks == 3) hipLaunchKernelGGL(compressor_kernel<3>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
     else hipLaunchKernelGGL(compressor_kernel<4>, dim3(grid), dim3(cc::Cfg::THREADS), cc::Cfg::LDS_BYTES, stream, a);
@@ -2085,8 +2094,9 @@ __global__ __launch_bounds__(xf::Cfg::THREADS, 2) void xattn_front_kernel(XattnF
     float* const dump = smem + CF::A_FLOATS + CF::B_ROWS * 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long item0 = (long long)blockIdx.x * G;
-    const int n_here = (int)((a.n_items - item0) < G ? (a.n_items - item0) : G);
+    // a workgroup carries a.items_per_wg <= G items (fewer in small launches, so that the items spread over the CUs: kernels.h)
+    const long long item0 = (long long)blockIdx.x * a.items_per_wg;
+    const int n_here = (int)((a.n_items - item0) < a.items_per_wg ? (a.n_items - item0) : a.items_per_wg);
     const float* __restrict__ W = a.w;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 sreg[CF::NSREG];
@@ -2191,9 +2201,11 @@ __global__ __launch_bounds__(xf::Cfg::THREADS, 2) void xattn_front_kernel(XattnF
     else layers(std::true_type{});
 }
 
-hipError_t launch_xattn_front(const XattnFrontArgs& a, hipStream_t stream) {
-    if (a.n_items <= 0) return hipSuccess;
-    if (!a.alleles || (!a.sites && !a.site_off) || !a.owner || !a.y2 || !a.sc || !a.w) return hipErrorInvalidValue;
+hipError_t launch_xattn_front(const XattnFrontArgs& args, hipStream_t stream) {
+    if (args.n_items <= 0) return hipSuccess;
+    XattnFrontArgs a = args;
+    if (a.items_per_wg == 0) a.items_per_wg = small_launch_items_per_wg(a.n_items, xf::Cfg::G);
+    if (!a.alleles || (!a.sites && !a.site_off) || !a.owner || !a.y2 || !a.sc || !a.w || a.items_per_wg < 1 || a.items_per_wg > xf::Cfg::G) return hipErrorInvalidValue;
     static bool configured_on[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -2202,7 +2214,7 @@ hipError_t launch_xattn_front(const XattnFrontArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         configured_on[dev] = true;
     }
-    const unsigned grid = (unsigned)((a.n_items + xf::Cfg::G - 1) / xf::Cfg::G);
+    const unsigned grid = (unsigned)((a.n_items + a.items_per_wg - 1) / a.items_per_wg);
     hipLaunchKernelGGL(xattn_front_kernel, dim3(grid), dim3(xf::Cfg::THREADS), xf::Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
