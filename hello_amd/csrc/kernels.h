@@ -139,7 +139,7 @@ struct CompressorArgs {
 };
 // Items per workgroup of the LDS-resident allele-stage kernels (compressor_kernel, xattn_front_kernel; one workgroup per CU).  A
 // workgroup's time grows with the items it carries (compressor: 84 us with 2, 121 us with 8; front: 29 / 57 us) while a small launch
-// leaves most CUs idle: spread the items over the CUs -- ceil(items / CUs), at most `most` (whole workgroups once every CU has one).
+// leaves most CUs idle: one or two items per workgroup while that gives each its own CU (items <= 2 CUs), else whole workgroups of `most`.
 int small_launch_items_per_wg(long long n_items, int most);
 int compressor_weight_floats(int blocks);
 bool compressor_supports_blocks(int blocks);

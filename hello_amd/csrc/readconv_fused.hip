@@ -2022,7 +2022,10 @@ __global__ __launch_bounds__(cc::Cfg::THREADS, 2) void compressor_kernel(Compres
 int small_launch_items_per_wg(long long n_items, int most) {
     const long long cus = device_cus();
     const long long n = (n_items + cus - 1) / cus;
-    return (int)(n < 1 ? 1 : (n > most ? most : n));
+    // up to two items per workgroup while that gives every item-pair its own CU; beyond that whole workgroups: more, emptier
+    // workgroups each stream the layer weights again, which costs throughput once launches of several engines share the chip
+    // (256-site launches over four engines: 444 k sites/s with whole workgroups, 426 k with three items per workgroup)
+    return (int)(n < 1 ? 1 : (n <= 2 ? n : most));
 }
 
 hipError_t launch_compressor_fused(const CompressorArgs& args, hipStream_t stream) {
