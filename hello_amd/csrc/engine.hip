@@ -120,7 +120,6 @@ struct hello_engine {
     DevBuf d_csr;                    // all per-batch index arrays, one allocation
     PinnedBuf h_csr;
     DevBuf d_logits, d_meta, d_post, d_rcl0, d_rcl1;
-    DevBuf d_out_small;        // small host-output calls: logits | meta | posteriors in ONE block (one copy back)
     PinnedBuf h_io;            // small host calls: inputs and outputs pass through pinned memory (pageable copies stall)
     DevBuf d_partial;                // fused read convolver partial sums
     DevBuf d_feat_in, d_feat_out;    // featurizer staging (host-pointer callers)
@@ -369,7 +368,6 @@ void hello_engine_destroy(hello_engine* e) {
     e->d_logits.release();
     e->d_meta.release();
     e->d_post.release();
-    e->d_out_small.release();
     e->h_io.release();
     e->d_rcl0.release();
     e->d_rcl1.release();
@@ -681,9 +679,10 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     const void* in_ptr[3] = {reads0, reads1, ref_onehot};
     const size_t in_bytes[3] = {in_bytes0, two_tech ? in_bytes1 : 0, (d.uses_ref ? ref_bytes : 0)};
     const void* buf_ptr[3] = {nullptr, nullptr, nullptr};
-    // Small host calls (one site per call is the reference's deployment form): asynchronous copies from / to pageable
-    // memory stall in the runtime's own staging, ~10 us each; below SMALL_IO bytes the engine stages through its
-    // pinned block instead -- memcpy in, one copy per input; ONE copy back for all outputs, memcpy out after the sync.
+    // Small host calls (one site per call is the reference's deployment form): below SMALL_IO bytes the inputs are copied (memcpy)
+    // into the engine's pinned, GPU-mapped block and the kernels read them THERE, across PCIe, and write the outputs into the block's
+    // other half the same way -- no copy-engine hop in either direction (a kernel-trace timeline of one-site calls showed ~30 us of a
+    // 258 us call in the two copies and the gaps around them; larger calls keep the copies: pageable memory cannot be mapped).
     constexpr size_t SMALL_IO = 256 * 1024;
     auto align16 = [](size_t b) { return (b + 15) & ~size_t(15); };
     const size_t in_total = align16(in_bytes[0]) + align16(in_bytes[1]) + align16(in_bytes[2]);
@@ -697,15 +696,13 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
         if (!in_bytes[i]) continue;
         if (in_dev) {
             buf_ptr[i] = in_ptr[i];
+        } else if (stage_in) {
+            memcpy((char*)e->h_io.p + in_cursor, in_ptr[i], in_bytes[i]);
+            buf_ptr[i] = (char*)e->h_io.p + in_cursor;
+            in_cursor += align16(in_bytes[i]);
         } else {
             if (int rc = ensure(e->scratch[i], in_bytes[i])) return rc;
-            const void* from = in_ptr[i];
-            if (stage_in) {
-                memcpy((char*)e->h_io.p + in_cursor, in_ptr[i], in_bytes[i]);
-                from = (char*)e->h_io.p + in_cursor;
-                in_cursor += align16(in_bytes[i]);
-            }
-            HIP_TRY(hipMemcpyAsync(e->scratch[i].p, from, in_bytes[i], hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(e->scratch[i].p, in_ptr[i], in_bytes[i], hipMemcpyHostToDevice, stream));
             buf_ptr[i] = e->scratch[i].p;
         }
     }
@@ -731,8 +728,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     const bool stage_out = !out_dev && out_total <= SMALL_IO;
     if (stage_out) {
         if (e->h_io.ensure(2 * SMALL_IO)) return fail(HELLO_ERR_HIP, "pinned allocation failed");
-        if (int rc = ensure(e->d_out_small, out_total)) return rc;
-        char* base = (char*)e->d_out_small.p;
+        char* base = (char*)e->h_io.p + SMALL_IO;                 // the output half of the pinned block: written by the kernels in place
         d_logits = (float*)base;
         base += align16(logit_bytes);
         if (d.has_meta) {
@@ -987,10 +983,8 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     HIP_TRY(hipEventRecord(e->ev_stop, stream));
     e->timed = true;
 
-    char* const h_out = out_total_small ? (char*)e->h_io.p + SMALL_IO : nullptr;     // the output half of the pinned block
-    if (out_total_small) {
-        HIP_TRY(hipMemcpyAsync(h_out, e->d_out_small.p, out_total_small, hipMemcpyDeviceToHost, stream));
-    } else if (!out_dev) {
+    char* const h_out = out_total_small ? (char*)e->h_io.p + SMALL_IO : nullptr;     // the output half of the pinned block (already written)
+    if (!out_total_small && !out_dev) {
         HIP_TRY(hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, stream));
         if (d.has_meta) HIP_TRY(hipMemcpyAsync(meta, d_meta, meta_bytes, hipMemcpyDeviceToHost, stream));
         if (posteriors) HIP_TRY(hipMemcpyAsync(posteriors, d_post, post_bytes, hipMemcpyDeviceToHost, stream));
