@@ -120,6 +120,7 @@ struct hello_engine {
     DevBuf d_csr;                    // all per-batch index arrays, one allocation
     PinnedBuf h_csr;
     DevBuf d_logits, d_meta, d_post, d_rcl0, d_rcl1;
+    DevBuf d_out_small;        // staged host-output calls too large to be written in place: logits | meta | posteriors in ONE block (one copy back)
     PinnedBuf h_io;            // small host calls: inputs and outputs pass through pinned memory (pageable copies stall)
     DevBuf d_partial;                // fused read convolver partial sums
     DevBuf d_feat_in, d_feat_out;    // featurizer staging (host-pointer callers)
@@ -368,6 +369,7 @@ void hello_engine_destroy(hello_engine* e) {
     e->d_logits.release();
     e->d_meta.release();
     e->d_post.release();
+    e->d_out_small.release();
     e->h_io.release();
     e->d_rcl0.release();
     e->d_rcl1.release();
@@ -726,9 +728,15 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     const size_t post_bytes = (size_t)4 * n_pairs * sizeof(float);
     const size_t out_total = align16(logit_bytes) + (d.has_meta ? align16(meta_bytes) : 0) + (posteriors ? align16(post_bytes) : 0);
     const bool stage_out = !out_dev && out_total <= SMALL_IO;
+    // ... written by the kernels IN PLACE only while they are a few KB (the posteriors kernel reads the logits back: thousands of
+    // 4-byte reads across PCIe would cost more than the one copy they save); larger staged outputs keep a device block + ONE copy
+    constexpr size_t IN_PLACE_OUT = 16 * 1024;
+    const bool out_in_place = stage_out && out_total <= IN_PLACE_OUT;
     if (stage_out) {
         if (e->h_io.ensure(2 * SMALL_IO)) return fail(HELLO_ERR_HIP, "pinned allocation failed");
-        char* base = (char*)e->h_io.p + SMALL_IO;                 // the output half of the pinned block: written by the kernels in place
+        if (!out_in_place)
+            if (int rc = ensure(e->d_out_small, out_total)) return rc;
+        char* base = out_in_place ? (char*)e->h_io.p + SMALL_IO : (char*)e->d_out_small.p;   // the output half of the pinned block | device
         d_logits = (float*)base;
         base += align16(logit_bytes);
         if (d.has_meta) {
@@ -983,8 +991,10 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     HIP_TRY(hipEventRecord(e->ev_stop, stream));
     e->timed = true;
 
-    char* const h_out = out_total_small ? (char*)e->h_io.p + SMALL_IO : nullptr;     // the output half of the pinned block (already written)
-    if (!out_total_small && !out_dev) {
+    char* const h_out = out_total_small ? (char*)e->h_io.p + SMALL_IO : nullptr;     // the output half of the pinned block
+    if (out_total_small) {
+        if (!out_in_place) HIP_TRY(hipMemcpyAsync(h_out, e->d_out_small.p, out_total_small, hipMemcpyDeviceToHost, stream));
+    } else if (!out_dev) {
         HIP_TRY(hipMemcpyAsync(logits, d_logits, logit_bytes, hipMemcpyDeviceToHost, stream));
         if (d.has_meta) HIP_TRY(hipMemcpyAsync(meta, d_meta, meta_bytes, hipMemcpyDeviceToHost, stream));
         if (posteriors) HIP_TRY(hipMemcpyAsync(posteriors, d_post, post_bytes, hipMemcpyDeviceToHost, stream));
