@@ -31,22 +31,21 @@ def main():
     args = ap.parse_args()
     spec = ns.build(args.config)
     eng = Engine(spec, weights.synth_state(spec, seed=1), device=0)
-    batch = synth.make_sites(64, seed=3, coverage=args.coverage)
+    hybrid = dict(hybrid_coverage=15) if spec.has("read_convolver1") or spec.has("readConv1") else {}
+    batch = synth.make_sites(64, seed=3, coverage=args.coverage, channels=eng.program.channels0, **hybrid)
     sites = [batch.site_slice(s, s + 1) for s in range(batch.n_sites)]
     for s in sites[:8]:
-        eng.forward(s.reads0, s.reads_per_allele0, s.alleles_per_site, posteriors=True)
+        eng.forward_batch(s, posteriors=True)
     t0 = time.perf_counter()
     for i in range(args.calls):
-        s = sites[i % len(sites)]
-        eng.forward(s.reads0, s.reads_per_allele0, s.alleles_per_site, posteriors=True)
+        eng.forward_batch(sites[i % len(sites)], posteriors=True)
     dt = time.perf_counter() - t0
     print(f"{args.config}: {args.calls} one-site calls, {1e3 * dt / args.calls:.4f} ms per call "
           f"({np.mean([s.reads0.shape[0] for s in sites]):.1f} reads, {np.mean([len(s.reads_per_allele0) for s in sites]):.2f} alleles per site)")
     if args.per_op:
         eng.set_profiling(64)
         for i in range(64):
-            s = sites[i % len(sites)]
-            eng.forward(s.reads0, s.reads_per_allele0, s.alleles_per_site, posteriors=True)
+            eng.forward_batch(sites[i % len(sites)], posteriors=True)
         rows, n = eng.op_times_ms()
         for kind, name, ms in rows:
             print(f"    {1e3 * ms:8.1f} us  {kind:18s} {name}")
