@@ -34,6 +34,7 @@ OP_XATTN_FRONT = 11
 (OP_CONV1D, OP_MAXPOOL, OP_SEGSUM, OP_MIX, OP_HEAD, OP_CONCAT, OP_ADD, OP_READCONV_FUSED, OP_LAYERNORM,
  OP_COMPRESSOR_FUSED) = range(1, 11)
 FLAG_RELU, FLAG_SRC_U8, FLAG_SOFTMAX, FLAG_MIX_REST, FLAG_SOFTPLUS, FLAG_WINOGRAD, FLAG_BF16X3, FLAG_BF16X3_32 = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_LANE_SHIFT, MAX_LANES = 8, 8            # bits 8..10 of an op's flags: the stream it runs on in a laned program (HELLO_FLAG_LANE_*)
 OP_NAMES = {1: "conv1d", 2: "maxpool", 3: "segsum", 4: "mix", 5: "head", 6: "concat", 7: "add",
             8: "readconv_fused", 9: "layernorm", 10: "compressor_fused", 11: "xattn_front"}
 
@@ -96,6 +97,7 @@ class Program:
     winograd: bool = False           # k3/s1/p1 convolutions run in Winograd form (F(2,3) / F(3,3)) where a kernel offers it
     arithmetic: str = "fp32"         # "bf16x3": the read convolver's 64-channel trunk as 3-term bf16 splits; "bf16x3+32": the 32-channel
                                      # blocks too (selectable modes, never the default)
+    n_lanes: int = 1                 # > 1: the program's independent chains carry lane numbers (small launches: assign_lanes)
 
     def describe(self) -> str:
         lines = [f"program {self.spec_name}: {len(self.ops)} ops, {len(self.buffers)} buffers, "
@@ -642,8 +644,66 @@ def _fold_concats(ops: List[Op]) -> List[Op]:
     return [o for j, o in enumerate(ops) if j not in drop]
 
 
-def _allocate(ops: List[Op], values: Dict[int, Value]):
-    """Greedy liveness packing of virtual activations into physical scratch buffers, per domain."""
+def assign_lanes(ops: List[Op], max_lanes: int = 4) -> int:
+    """Lane numbers (bits 8..10 of ``flags``) for the ops of a program still in virtual buffer ids: an op continues the lane of
+    a producer of one of its inputs while that producer is the LAST op of its lane so far, else it opens a new lane (or, with
+    none left, queues behind its first input's producer).  The chains this finds in a MoEAttention forward
+    (MixtureOfExpertsAdvanced.py:161-252): technology 0 (read convolver, compressor, its expert), technology 1, the combined
+    expert behind combiner0, and combiner1 + the meta network.  Streams are in order, so any assignment is correct as long as the
+    engine orders lanes with events where an op reads another lane's output -- which it derives from the buffer ids
+    (hello_engine_create).  -> number of lanes used."""
+    producer: Dict[int, int] = {}
+    lane_of: List[int] = []
+    tail: Dict[int, int] = {}
+    for i, o in enumerate(ops):
+        front = o.kind == OP_XATTN_FRONT                      # writes dst AND res; every other op reads res
+        reads = [v for v in (o.src0, o.src1, BUF_NONE if front else o.res) if v >= 1000 and v in producer]
+        pick = next((lane_of[producer[v]] for v in reads if tail.get(lane_of[producer[v]]) == producer[v]), None)
+        if pick is None:
+            unused = [lane for lane in range(max_lanes) if lane not in tail]
+            pick = unused[0] if unused else (lane_of[producer[reads[0]]] if reads else 0)
+        lane_of.append(pick)
+        tail[pick] = i
+        o.flags = (o.flags & ~(7 << FLAG_LANE_SHIFT)) | (pick << FLAG_LANE_SHIFT)
+        if o.kind != OP_HEAD:
+            producer[o.dst] = i
+        if front:
+            producer[o.res] = i
+    return len(tail)
+
+
+# rough device time of one op in a launch of a few sites (us; tools/one_site_profile.py): only their ORDER of magnitude matters below
+_SMALL_LAUNCH_US = {OP_READCONV_FUSED: 75.0, OP_COMPRESSOR_FUSED: 55.0, OP_XATTN_FRONT: 27.0, OP_CONV1D: 10.0, OP_HEAD: 8.0, OP_SEGSUM: 7.0}
+
+
+def schedule_lanes(ops: List[Op]) -> List[Op]:
+    """Submission order of a laned program (virtual buffer ids): by estimated START time -- an op starts when its producers and
+    its lane's previous op have finished.  The host submits ~40 launches of a three-expert model one after the other (~4 us each):
+    in program order the last chain's first kernel would be submitted after every other chain's last one, long after its inputs
+    were ready.  Any order that keeps producers before consumers and a lane's ops in their order is correct (streams are in
+    order; the engine puts events between lanes)."""
+    shift = FLAG_LANE_SHIFT
+    finish: Dict[int, float] = {}             # virtual id -> time its producer finishes
+    lane_free: Dict[int, float] = {}
+    start = []
+    for i, o in enumerate(ops):
+        front = o.kind == OP_XATTN_FRONT
+        ready = max([finish.get(v, 0.0) for v in (o.src0, o.src1, BUF_NONE if front else o.res) if v >= 1000] + [0.0])
+        lane = (o.flags >> shift) & 7
+        t0 = max(ready, lane_free.get(lane, 0.0))
+        t1 = t0 + _SMALL_LAUNCH_US.get(o.kind, 6.0)
+        lane_free[lane] = t1
+        if o.kind != OP_HEAD:
+            finish[o.dst] = t1
+        if front:
+            finish[o.res] = t1
+        start.append((t0, i))
+    return [ops[i] for _, i in sorted(start)]
+
+
+def _allocate(ops: List[Op], values: Dict[int, Value], reuse: bool = True):
+    """Greedy liveness packing of virtual activations into physical scratch buffers, per domain.  ``reuse`` False: every value
+    its own buffer (a laned program's ops run concurrently: liveness in program order says nothing there)."""
     last_use: Dict[int, int] = {}
     for i, o in enumerate(ops):
         for v in (o.src0, o.src1, o.res):
@@ -672,14 +732,14 @@ def _allocate(ops: List[Op], values: Dict[int, Value]):
             place(o.dst)
             place(o.res)
             for vsrc in {o.src0, o.src1}:
-                if vsrc >= 1000 and last_use.get(vsrc) == i and vsrc in assigned:
+                if reuse and vsrc >= 1000 and last_use.get(vsrc) == i and vsrc in assigned:
                     free[values[vsrc].domain].append(assigned[vsrc])
             continue
         if o.kind != OP_HEAD:
             place(o.dst)
         # release inputs whose last use is this op (after the output was placed: no aliasing)
         for vsrc in {o.src0, o.src1, o.res}:
-            if vsrc >= 1000 and last_use.get(vsrc) == i and vsrc in assigned:
+            if reuse and vsrc >= 1000 and last_use.get(vsrc) == i and vsrc in assigned:
                 free[values[vsrc].domain].append(assigned[vsrc])
         # an output nobody reads (cannot happen in a well-formed program) would leak; ignore
     for o in ops:
@@ -692,13 +752,16 @@ def _allocate(ops: List[Op], values: Dict[int, Value]):
 
 
 def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool = True, arithmetic: str = "fp32",
-                  fold_site_sums: bool = True) -> Program:
+                  fold_site_sums: bool = True, lanes: bool = False) -> Program:
     """``winograd``: k3/s1/p1 convolutions are evaluated in Winograd form -- F(3,3) (5 instead of 9 contractions per
     3 positions) where the row length / the fused kernel's geometry is whole triples, else F(2,3) (4 instead of 6
     per pair) -- same fp32 arithmetic, results differ from the direct form by float re-association only.
     ``fold_site_sums``: glue ops folded into their consumers -- the expert front sums a site's alleles itself, a combiner's first
     convolution reads the two tensors of its CONCAT directly (one launch and one buffer less each; the same bits); False keeps
-    the SEGSUM / CONCAT ops (tests compare the two)."""
+    the SEGSUM / CONCAT ops (tests compare the two).
+    ``lanes``: the program for SMALL launches -- the same ops, but the independent chains of a two-technology / three-expert model
+    carry lane numbers (``assign_lanes``) and no two values share a buffer, so that the engine may run the chains concurrently
+    (a launch of a few sites is latency-bound: every chain is a handful of workgroups).  ``n_lanes`` == 1 for single-chain models."""
     low = _Lowering(spec, state, fused, winograd, arithmetic)
     n_experts, has_meta = low.lower()
     if arithmetic != "fp32" and not low.used_bf16x3:
@@ -707,10 +770,13 @@ def compile_model(spec: ns.ModelSpec, state, fused: bool = True, winograd: bool 
     if fold_site_sums:
         low.ops = _fold_site_sums(low.ops)
         low.ops = _fold_concats(low.ops)
-    buffers = _allocate(low.ops, low.values)
+    n_lanes = assign_lanes(low.ops) if lanes else 1
+    if n_lanes > 1:
+        low.ops = schedule_lanes(low.ops)
+    buffers = _allocate(low.ops, low.values, reuse=n_lanes == 1)
     return Program(
         spec_name=spec.name, window=spec.window, channels0=spec.channels[0],
         channels1=spec.channels[1] if spec.hybrid_inputs else 0,
         n_experts=n_experts, has_meta=has_meta, uses_ref=low.uses_ref, ops=low.ops,
         buffers=buffers, weights=low.blob.finish(), fused_read_convolver=low.used_fused,
-        fused_compressor=low.used_fused_compressor, winograd=low.winograd, arithmetic=arithmetic)
+        fused_compressor=low.used_fused_compressor, winograd=low.winograd, arithmetic=arithmetic, n_lanes=n_lanes)

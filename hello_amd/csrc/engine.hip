@@ -122,7 +122,14 @@ struct hello_engine {
     DevBuf d_logits, d_meta, d_post, d_rcl0, d_rcl1;
     DevBuf d_out_small;        // staged host-output calls too large to be written in place: logits | meta | posteriors in ONE block (one copy back)
     PinnedBuf h_io;            // small host calls: inputs and outputs pass through pinned memory (pageable copies stall)
-    DevBuf d_partial;                // fused read convolver partial sums
+    DevBuf d_partial[2];             // fused read convolver partial sums, per read technology (their ops may run on different lanes)
+    // lanes (programs for small launches: HELLO_FLAG_LANE_*): streams 1.., per-op events where another lane reads the op's output
+    int n_lanes = 1;
+    std::vector<hipStream_t> lane_streams;      // [n_lanes], entry 0 unused (= the call's stream)
+    std::vector<hipEvent_t> op_done;            // [n_ops]: recorded after ops whose output another lane reads, and after a lane's last op
+    std::vector<std::vector<int>> op_waits;     // [n_ops]: ops on OTHER lanes whose output this op reads
+    std::vector<int> lane_tail;                 // [n_lanes]: the last op of each lane
+    hipEvent_t ev_lanes_go = nullptr;           // recorded on the call's stream once the inputs are staged: the other lanes start behind it
     DevBuf d_feat_in, d_feat_out;    // featurizer staging (host-pointer callers)
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
@@ -353,6 +360,53 @@ int hello_engine_create(const hello_model_desc* desc, const void* folded_weights
         hello_engine_destroy(e);
         return fail(HELLO_ERR_HIP, "engine setup failed: %s", hipGetErrorString(err));
     }
+    // lanes: which op waits for which, from the buffer ids (a laned program writes every scratch buffer from one op)
+    const int n_ops = (int)e->ops.size();
+    auto lane_of = [&](int i) { return (e->ops[i].flags & HELLO_FLAG_LANE_MASK) >> HELLO_FLAG_LANE_SHIFT; };
+    for (int i = 0; i < n_ops; ++i) e->n_lanes = lane_of(i) + 1 > e->n_lanes ? lane_of(i) + 1 : e->n_lanes;
+    if (e->n_lanes > 1) {
+        std::vector<int> writer(desc->n_buffers, -1);
+        e->op_waits.assign(n_ops, {});
+        e->op_done.assign(n_ops, nullptr);
+        e->lane_tail.assign(e->n_lanes, -1);
+        std::vector<char> read_elsewhere(n_ops, 0);
+        for (int i = 0; i < n_ops; ++i) {
+            const hello_op& o = e->ops[i];
+            const bool front = o.kind == HELLO_OP_XATTN_FRONT;          // writes dst AND res; every other op reads res
+            const int reads[3] = {o.src0, o.src1, front ? HELLO_BUF_NONE : o.res};
+            for (int b : reads) {
+                if (b < HELLO_BUF_FIRST_SCRATCH) continue;
+                const int w = writer[b];
+                if (w < 0) {
+                    hello_engine_destroy(e);
+                    return fail(HELLO_ERR_MODEL, "laned program: op %d reads buffer %d before any op wrote it", i, b);
+                }
+                if (lane_of(w) != lane_of(i)) {
+                    e->op_waits[i].push_back(w);
+                    read_elsewhere[w] = 1;
+                }
+            }
+            const int writes[2] = {o.kind == HELLO_OP_HEAD ? HELLO_BUF_NONE : o.dst, front ? o.res : HELLO_BUF_NONE};
+            for (int b : writes) {
+                if (b < HELLO_BUF_FIRST_SCRATCH) continue;
+                if (writer[b] >= 0) {
+                    hello_engine_destroy(e);
+                    return fail(HELLO_ERR_MODEL, "laned program: ops %d and %d both write buffer %d (a program with lanes may not reuse buffers)", writer[b], i, b);
+                }
+                writer[b] = i;
+            }
+            e->lane_tail[lane_of(i)] = i;
+        }
+        e->lane_streams.assign(e->n_lanes, nullptr);
+        for (int l = 1; l < e->n_lanes && err == hipSuccess; ++l) err = hipStreamCreateWithFlags(&e->lane_streams[l], hipStreamNonBlocking);
+        for (int i = 0; i < n_ops && err == hipSuccess; ++i)
+            if (read_elsewhere[i] || (lane_of(i) > 0 && e->lane_tail[lane_of(i)] == i)) err = hipEventCreateWithFlags(&e->op_done[i], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_lanes_go, hipEventDisableTiming);
+        if (err != hipSuccess) {
+            hello_engine_destroy(e);
+            return fail(HELLO_ERR_HIP, "lane setup failed: %s", hipGetErrorString(err));
+        }
+    }
     *out = e;
     return HELLO_OK;
 } catch (...) {
@@ -373,7 +427,13 @@ void hello_engine_destroy(hello_engine* e) {
     e->h_io.release();
     e->d_rcl0.release();
     e->d_rcl1.release();
-    e->d_partial.release();
+    e->d_partial[0].release();
+    e->d_partial[1].release();
+    for (hipStream_t st : e->lane_streams)
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : e->op_done)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_lanes_go) (void)hipEventDestroy(e->ev_lanes_go);
     e->d_feat_in.release();
     e->d_feat_out.release();
     e->d_debug.release();
@@ -765,7 +825,9 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
         const int64_t Rmax = R0 > R1 ? R0 : R1;
         const size_t slots = (size_t)A + (size_t)((Rmax + G - 1) / G) + 1;
         const size_t frame_ch = (e->wide_trunk[0] || e->wide_trunk[1]) ? 128 : 64;
-        if (int rc = ensure(e->d_partial, slots * hello::readconv_frame_rows(d.window) * frame_ch * sizeof(float))) return rc;
+        for (const hello_op& o : e->ops)
+            if (o.kind == HELLO_OP_READCONV_FUSED)
+                if (int rc = ensure(e->d_partial[o.seg == HELLO_SEG_READS1_TO_ALLELES ? 1 : 0], slots * hello::readconv_frame_rows(d.window) * frame_ch * sizeof(float))) return rc;
     }
     // experts without a head (ensemble of two: third expert is all-zero logits, :244) stay zero
     if (d.n_experts == 3) HIP_TRY(hipMemsetAsync(d_logits, 0, logit_bytes, stream));
@@ -792,7 +854,21 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
     };
     const int n_ops_total = (int)e->ops.size();
     auto wanted = [&](int i) { return i >= 0 && i < n_ops_total && (!e->prof_filter || e->ops[i].kind == e->prof_filter); };
+    // lanes: the independent chains of a multi-technology / multi-expert program run on their own streams (small launches: every
+    // chain is a handful of workgroups).  Lane 0 is the call's stream; the others start behind what it has staged so far.
+    const bool laned = e->n_lanes > 1;
+    if (laned) {
+        if (ring || e->debug_op >= 0 || (e->stamp_mode & 1))
+            return fail(HELLO_ERR_ARG, "per-op profiling / debug capture / stamps need the sequential program (this engine runs lanes)");
+        HIP_TRY(hipEventRecord(e->ev_lanes_go, stream));
+        for (int l = 1; l < e->n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(e->lane_streams[l], e->ev_lanes_go, 0));
+    }
+    hipStream_t const call_stream = stream;
     for (const hello_op& o : e->ops) {
+        const int lane = laned ? (o.flags & HELLO_FLAG_LANE_MASK) >> HELLO_FLAG_LANE_SHIFT : 0;
+        hipStream_t const stream = lane ? e->lane_streams[lane] : call_stream;      // (shadows the call's stream inside the loop)
+        if (laned)
+            for (int w : e->op_waits[op_index]) HIP_TRY(hipStreamWaitEvent(stream, e->op_done[w], 0));
         if (ring && (wanted(op_index) || wanted(op_index - 1)))
             if (int rc = mark(op_index)) return rc;
         const long long rows = rows_of(o.domain, S, A, R0, R1);
@@ -903,7 +979,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                 }
                 if (!ptr(o.src0)) return fail(HELLO_ERR_ARG, "op %d reads an input the caller did not supply", op_index);
                 a.w = e->d_weights + o.w_off;
-                a.partial = (float*)e->d_partial.p;
+                a.partial = (float*)e->d_partial[t1 ? 1 : 0].p;
                 a.allele_of_read = t1 ? e->allele_of_read1 : e->allele_of_read0;
                 a.slot_of_group = t1 ? e->group_slot1 : e->group_slot0;
                 a.n_reads = t1 ? R1 : R0;
@@ -961,7 +1037,7 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
                     if (a.stamps)                             // both launches went out: the layout debug_read_stamps reports is theirs
                         for (int i = 0; i < 5; ++i) e->stamp_layout[i] = stamp_lay[i];
                 }
-                HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial.p, t1 ? e->slot_off1 : e->slot_off0,
+                HIP_TRY(hello::launch_readconv_finalize((const float*)e->d_partial[t1 ? 1 : 0].p, t1 ? e->slot_off1 : e->slot_off0,
                                                         (float*)ptr(o.dst), A, o.lout, o.cout, stream));
                 break;
             }
@@ -979,8 +1055,12 @@ int hello_engine_forward(hello_engine* e, const uint8_t* reads0, const int32_t* 
             HIP_TRY(hipMemcpyAsync(e->d_debug.p, ptr(o.dst), n * sizeof(float), hipMemcpyDeviceToDevice, stream));
             e->debug_floats = n;
         }
+        if (laned && e->op_done[op_index]) HIP_TRY(hipEventRecord(e->op_done[op_index], stream));
         ++op_index;
     }
+    if (laned)                                       // join: the call's stream goes on (posteriors, outputs) behind every lane's last op
+        for (int l = 1; l < e->n_lanes; ++l)
+            if (e->lane_tail[l] >= 0) HIP_TRY(hipStreamWaitEvent(stream, e->op_done[e->lane_tail[l]], 0));
     if (ring) {
         if (int rc = mark(op_index)) return rc;     // the end marker (op_times_ms waits for it)
         e->prof_count++;

@@ -24,6 +24,7 @@ _LIB_PATH = os.environ.get("HELLO_LIB") or os.path.join(os.path.dirname(os.path.
                                                         "libhello_mi355x.so")
 HELLO_IN_DEVICE, HELLO_OUT_DEVICE, HELLO_LAYOUT_RCL = 1, 2, 4
 ABI_VERSION = 2          # HELLO_ABI_VERSION of include/hello_mi355x.h
+LANES_MAX_SITES = 64     # launches of at most this many sites run the laned program of a multi-chain model (Engine.forward)
 
 
 class HelloOp(C.Structure):
@@ -147,20 +148,47 @@ class Engine:
         itself in a split mode through a fixture of tests/conftest.py, not through this constructor)."""
         self.lib = load_library()
         self.spec = spec
+        # the laned program for small launches is compiled from the same options on first use (None: this engine was handed a
+        # finished program, or the model is a single chain)
+        self._lanes_recipe = None if program is not None else dict(state=state, fused=fused, winograd=winograd, arithmetic=arithmetic or "fp32")
         if program is None:
             program = compiler.compile_model(spec, state, fused=fused, winograd=winograd, arithmetic=arithmetic or "fp32")
         self.program = program
         p = self.program
-        desc, self._desc_arrays = model_desc(p)
-        blob = np.ascontiguousarray(p.weights, dtype=np.float32)
-        handle = C.c_void_p()
-        _check(self.lib.hello_engine_create(C.byref(desc), blob.ctypes.data, blob.nbytes, device,
-                                            C.byref(handle)))
-        self.handle = handle
         self.device = device
+        self.handle, self._desc_arrays = self._create(p)
+        self.lanes_handle = None            # a second native engine holding the laned program (multi-chain models, small launches)
+        self.lanes_program = None
+        self._sequential_only = 0           # > 0 while profiling / debug capture / stamps are armed: they need the sequential program
         self.n_experts = p.n_experts
         self.has_meta = p.has_meta
         self._own = None                    # torch view of the engine's own stream (created on first use)
+
+    def _create(self, program):
+        desc, keep = model_desc(program)
+        blob = np.ascontiguousarray(program.weights, dtype=np.float32)
+        handle = C.c_void_p()
+        _check(self.lib.hello_engine_create(C.byref(desc), blob.ctypes.data, blob.nbytes, self.device, C.byref(handle)))
+        return handle, keep
+
+    def small_launch_handle(self):
+        """The native engine a launch of a few sites should run on: for a model of several independent chains (two read
+        technologies, three experts, a meta network: MixtureOfExpertsAdvanced.py:161-252) a second engine holding the LANED
+        program -- the same ops and weights, every chain on its own stream (``compiler.assign_lanes``), no buffer shared between
+        values -- built on first use; for a single-chain model, or while profiling / debug capture is armed, the engine itself.
+        A launch of a few sites is latency-bound: the chains' kernels are a handful of workgroups each and overlap freely."""
+        if self._sequential_only or self._lanes_recipe is None:
+            return self.handle
+        if self.lanes_handle is None:
+            r = self._lanes_recipe
+            prog = compiler.compile_model(self.spec, r["state"], fused=r["fused"], winograd=r["winograd"], arithmetic=r["arithmetic"], lanes=True)
+            if prog.n_lanes == 1:
+                self._lanes_recipe = None
+                return self.handle
+            self.lanes_handle, self._lanes_desc_arrays = self._create(prog)
+            self.lanes_program = prog
+            self._lanes_recipe = dict(r, state=None)          # (the state is not needed again)
+        return self.lanes_handle
 
     # -- stream ordering of device-path calls ---------------------------------------------------------
     class _OnStream:
@@ -197,6 +225,9 @@ class Engine:
         return Engine._OnStream(self, device, stream)
 
     def close(self):
+        if getattr(self, "lanes_handle", None):
+            self.lib.hello_engine_destroy(self.lanes_handle)
+            self.lanes_handle = None
         if getattr(self, "handle", None):
             self.lib.hello_engine_destroy(self.handle)
             self.handle = None
@@ -312,9 +343,13 @@ class Engine:
             lp = logits.ctypes.data
             mp = meta.ctypes.data if meta is not None else None
             pp = post.ctypes.data if posteriors else None
+        # a launch of a few sites of a multi-chain model runs the laned program (the chains concurrently; the same bits)
+        native = self.small_launch_handle() if S <= LANES_MAX_SITES else self.handle
+        self._last_native = native
+
         def launch(handle):
             _check(self.lib.hello_engine_forward(
-                self.handle, p0, rpa0.ctypes.data, p1 or None, rpa1.ctypes.data if rpa1 is not None else None,
+                native, p0, rpa0.ctypes.data, p1 or None, rpa1.ctypes.data if rpa1 is not None else None,
                 aps.ctypes.data, pf or None, S, A, n0, n1, lp, mp, pp, flags, handle))
         if on_device:
             with self.on_stream(reads0.device, stream) as handle:
@@ -352,10 +387,12 @@ class Engine:
 
     def synchronize(self):
         _check(self.lib.hello_engine_synchronize(self.handle))
+        if self.lanes_handle:
+            _check(self.lib.hello_engine_synchronize(self.lanes_handle))
 
     def last_forward_ms(self) -> float:
         ms = C.c_float()
-        _check(self.lib.hello_engine_last_forward_ms(self.handle, C.byref(ms)))
+        _check(self.lib.hello_engine_last_forward_ms(getattr(self, "_last_native", None) or self.handle, C.byref(ms)))
         return float(ms.value)
 
     def set_profiling(self, max_forwards: int, only: Optional[str] = None):
@@ -365,10 +402,12 @@ class Engine:
         kind = 0 if only is None else {v: k for k, v in compiler.OP_NAMES.items()}[only]
         _check(self.lib.hello_engine_set_profiling_filter(self.handle, kind))
         _check(self.lib.hello_engine_set_profiling(self.handle, int(max_forwards)))
+        self._sequential_only = (self._sequential_only & ~1) | (1 if max_forwards > 0 else 0)     # per-op events time the sequential program
 
     def capture_op_output(self, op_index: Optional[int]):
         """Debug: snapshot the output of op ``op_index`` of every following forward (None disarms)."""
         _check(self.lib.hello_engine_debug_capture(self.handle, -1 if op_index is None else int(op_index)))
+        self._sequential_only = (self._sequential_only & ~2) | (0 if op_index is None else 2)
 
     def read_op_output(self) -> np.ndarray:
         """The snapshot of the last forward, float32 [rows, positions, channels] (rows of the op's domain)."""
@@ -384,6 +423,7 @@ class Engine:
         if not hasattr(self.lib, "hello_engine_debug_stamps"):
             raise RuntimeError(f"{_LIB_PATH} was built before the kernel-timeline diagnostic (hello_engine_debug_stamps): rebuild it")
         _check(self.lib.hello_engine_debug_stamps(self.handle, int(mode)))
+        self._sequential_only = (self._sequential_only & ~4) | (4 if mode else 0)
 
     def read_stamps(self):
         """-> (uint64 [workgroups, waves, groups per workgroup, slots], number of workgroups of the bulk launch) of the last

@@ -279,8 +279,8 @@ class SiteServer:
         self._engines = list(engines)
         for cb in self._keep:
             _check(self.lib.hello_site_server_add_scorer(self.handle, cb, None))
-        for e in self._engines:
-            _check(self.lib.hello_site_server_add_engine(self.handle, e.handle))
+        for e in self._engines:                     # the server's launches are a few sites each: the laned program of a multi-chain model
+            _check(self.lib.hello_site_server_add_engine(self.handle, e.small_launch_handle()))
         self.n_scorers = len(self._keep) + len(self._engines)
 
     @property

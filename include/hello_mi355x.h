@@ -119,6 +119,15 @@ typedef enum hello_op_kind {
                                         the default: results differ from exact fp32 at the 1e-6 level of the activations */
 #define HELLO_FLAG_BF16X3_32 128     /* with HELLO_FLAG_BF16X3 ("bf16x3+32"): the six 32 -> 32 convolutions of the ResidualBlock(32)s too */
 #define HELLO_FLAG_MIX_REST 8        /* MIX: dst[a] = src0[a] - (src1[site(a)] - src0[a])  (:372-383)  */
+/* Lanes (an addition within ABI version 2): bits 8..10 of `flags` name the stream an op runs on, 0 = the call's own stream.  A model
+ * of two read technologies / three experts is several INDEPENDENT chains (MixtureOfExpertsAdvanced.py:161-252: read convolver +
+ * compressor + expert per technology, the combined expert, the meta network); a launch of a few sites is latency-bound -- every chain
+ * is a handful of workgroups -- so a program for SMALL launches puts the chains on lanes and the engine runs them concurrently,
+ * ordering lanes with events wherever an op reads what another lane wrote (derived from the buffer ids).  Such a program must write
+ * every scratch buffer from ONE op (no buffer reuse): hello_engine_create refuses it otherwise.  Same kernels, same bits. */
+#define HELLO_FLAG_LANE_SHIFT 8
+#define HELLO_FLAG_LANE_MASK  (7 << HELLO_FLAG_LANE_SHIFT)
+#define HELLO_MAX_LANES 8
 
 typedef struct hello_op {
     int32_t kind;        /* hello_op_kind */

@@ -565,3 +565,39 @@ def test_unsupported_layers_are_named_with_their_state_dict_key():
         net.network = torch.nn.Sequential(torch.nn.AdaptiveAvgPool1d(1), torch.nn.ReLU(), torch.nn.Linear(4, 1), torch.nn.ReLU())
         with pytest.raises(NotImplementedError, match=r"pooling head at moeMerged\.x\.network\.0.*AdaptiveAvgPool1d"):
             loader._convert(net, "moeMerged.x")
+
+
+def test_lane_assignment_finds_the_forwards_independent_chains():
+    """compiler.assign_lanes: the chains of a MoEAttention forward (MixtureOfExpertsAdvanced.py:161-252) -- technology 0, technology 1,
+    the combined expert behind combiner0, combiner1 + the meta network -- get their own lanes; a single-technology model stays one
+    lane; a laned program writes every scratch buffer from exactly one op (the engine derives the cross-lane waits from buffer ids
+    and refuses anything else) and reads nothing before it was written."""
+    shift = compiler.FLAG_LANE_SHIFT
+    for cfg, want in (("single_tech", 1), ("single_tech_hp", 1), ("hybrid_no_ensemble", 3), ("hybrid_full", 4), ("hybrid_ensemble2", 4), ("merged_hybrid", 4)):
+        spec = ns.build(cfg)
+        state = weights.synth_state(spec, seed=1)
+        prog = compiler.compile_model(spec, state, lanes=True)
+        base = compiler.compile_model(spec, state)
+        assert prog.n_lanes == want and base.n_lanes == 1, cfg
+        # the same ops over the same weights, submitted in another order (by estimated start time: compiler.schedule_lanes)
+        assert sorted((o.kind, o.name, o.w_off) for o in prog.ops) == sorted((o.kind, o.name, o.w_off) for o in base.ops) and np.array_equal(prog.weights, base.weights)
+        assert all((o.flags >> shift) & 7 == 0 for o in base.ops) and {(o.flags >> shift) & 7 for o in prog.ops} == set(range(want))
+        if want == 1:
+            assert prog.buffers == base.buffers
+            continue
+        writers, lane_of_writer = {}, {}
+        for i, o in enumerate(prog.ops):
+            front = o.kind == compiler.OP_XATTN_FRONT
+            for b in (o.src0, o.src1, compiler.BUF_NONE if front else o.res):
+                assert b < compiler.BUF_FIRST_SCRATCH or b in writers, (cfg, i, b)
+            for b in ([] if o.kind == compiler.OP_HEAD else [o.dst]) + ([o.res] if front else []):
+                assert b not in writers, (cfg, i, b)
+                writers[b] = i
+                lane_of_writer[b] = (o.flags >> shift) & 7
+        # the two technologies' read convolvers sit on different lanes, and each lane is one chain: an op's lane is the lane of a producer
+        rc = [(o.flags >> shift) & 7 for o in prog.ops if o.kind == compiler.OP_READCONV_FUSED]
+        assert len(rc) == 2 and rc[0] != rc[1]
+        for o in prog.ops:
+            ins = [b for b in (o.src0, o.src1) if b >= compiler.BUF_FIRST_SCRATCH]
+            if ins and (o.flags >> shift) & 7 not in {lane_of_writer[b] for b in ins}:
+                assert o.name.startswith(("moeMerged.combiner", "moeMerged.alleleConvCombiner", "moeMerged.siteConvCombiner")) or "meta" in o.name.lower(), (cfg, o.name)
