@@ -62,7 +62,8 @@ def test_shared_call_is_bit_identical_to_the_direct_per_site_call(model_file, co
         direct.providePredictions = False
         assert {k: float(v) for k, v in shared_net(fd, seg).items()} == {k: float(v) for k, v in direct(fd, seg).items()}
         stats = shared_net.server_stats()
-        assert stats["sites"] == 25 and stats["launches"] == 25 and stats["errors"] == 0 and stats["engines"] == 2
+        # two engines for a single-chain model (their launches run out of phase), one for a model whose small launches run lanes
+        assert stats["sites"] == 25 and stats["launches"] == 25 and stats["errors"] == 0 and stats["engines"] == (2 if config == "single_tech" else 1)
         # a second "worker" finds the running server instead of starting one
         again = loader.load(path, shared=True, connect_only=True)
         assert again.info["pid"] == shared_net.info["pid"] and again.info["slot"] != shared_net.info["slot"]

@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--calls", type=int, default=2000)
     ap.add_argument("--shared", action="store_true", help="workers load the model with shared=True: one scoring server for all of them")
-    ap.add_argument("--engines", type=int, default=2, help="engines (scorer threads) of the shared server")
+    ap.add_argument("--engines", type=int, default=0, help="engines (scorer threads) of the shared server; 0 = the server picks (2; 1 for laned models)")
     ap.add_argument("--config", default="C2", help="bench.py configuration (model + synthetic sites)")
     ap.add_argument("--json", action="store_true", help="print ONE JSON line (bench.py's `per_site_shared` leg) instead of the table")
     args = ap.parse_args()
@@ -88,6 +88,8 @@ def main():
     shutil.rmtree(tmp, ignore_errors=True)         # the model file and the rendezvous directory of this run (the server unlinks its own files)
     if args.json:
         stats = max((r[3] for r in rates), key=lambda s: s["sites"]) if args.shared else None
+        if stats is not None:
+            args.engines = stats["engines"]
         print(json.dumps({"value": round(sum(r[2] for r in rates), 1), "unit": "sites/s", "workers": args.workers, "calls_per_worker": args.calls,
                           "by_wall_clock_of_slowest": round(args.workers * args.calls / wall, 1), "config": args.config,
                           "ms_per_call_mean": round(1e3 * args.workers / sum(r[2] for r in rates), 4),
@@ -96,6 +98,8 @@ def main():
         return
     for _, rank, rate, _ in rates:
         print(f"  worker {rank}: {rate:8.0f} sites/s ({1e3 / rate:.3f} ms per call)")
+    if args.shared:
+        args.engines = max((r[3] for r in rates), key=lambda s: s["sites"])["engines"]          # what the server chose
     form = f"loader.load(path, shared=True): one server process, {args.engines} engine(s)" if args.shared else "an engine per worker"
     print(f"{args.workers} worker processes ({args.config}), one site per call each, {form}: {sum(r[2] for r in rates):,.0f} sites/s in aggregate "
           f"({args.workers * args.calls / wall:,.0f} by the wall clock of the slowest worker)")
