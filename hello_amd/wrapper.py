@@ -182,11 +182,12 @@ class ScoringNetwork:
                                          rpa1 if eng.program.channels1 else None,
                                          ref if eng.program.uses_ref else None, posteriors=True)
         results, col = [], 0
-        scalars = [torch.from_numpy(np.ascontiguousarray(post[r])).unbind(0) for r in range(4)]   # 0-dim tensors, once
+        n_pairs_total = post.shape[1]
+        scalars = torch.from_numpy(np.ascontiguousarray(post).reshape(-1)).unbind(0)      # 0-dim tensors of all four rows, with one call
         for s, alleles in enumerate(names):
             keys = pair_keys(alleles)
             n = len(keys)
-            rows = [dict(zip(keys, scalars[r][col:col + n])) for r in range(4)]
+            rows = [dict(zip(keys, scalars[r * n_pairs_total + col:r * n_pairs_total + col + n])) for r in range(4)]
             col += n
             if self.providePredictions:
                 m = torch.from_numpy(meta[s].copy()) if eng.has_meta else _SINGLE_EXPERT_META.clone()
