@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from hello_amd import netspec as ns, synth, weights
-from tests.util import FIXTURES, load_fixture
+from tests.util import FIXTURES, load_fixture, oracle_per_site
 
 pytestmark = pytest.mark.gpu
 
@@ -635,8 +635,7 @@ def _stress_against_oracle(label, cfg, kw, gain, n_sites):
     # alleles, whose expert input 2a - s is exactly 0, comes out 0.07 away in probability from the same site scored
     # alone -- the reference's batched form disagreeing with its own per-site form.  The engine sums each segment
     # directly, i.e. agrees with the per-site form, which is what a call through the plug-in surface computes.
-    oracle = mo.Oracle(spec, state, backend="torch")
-    want, want_meta = mo.forward_batch(oracle, batch, chunk_sites=1)
+    want, want_meta = oracle_per_site(spec, state, batch)
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(logits - want).max() <= 2e-5 * scale + 2e-4, (label, gain, float(np.abs(logits - want).max()), scale)
     assert np.abs(sigmoid(logits) - sigmoid(want)).max() < PROB_ATOL
@@ -708,7 +707,7 @@ def test_bf16x3_mode_frames_and_posteriors(cfg, kw, mode):
     assert np.array_equal(logits, again) and np.array_equal(post, post2)
     exact_logits, _, exact_post = exact.forward_batch(batch, posteriors=True)
     if cfg not in _ORACLE_LOGITS:                # the oracle's answer does not depend on the engine's mode: once per model
-        _ORACLE_LOGITS[cfg] = mo.forward_batch(mo.Oracle(spec, state, backend="torch"), batch, chunk_sites=1)[0]
+        _ORACLE_LOGITS[cfg] = oracle_per_site(spec, state, batch)[0]
     want = _ORACLE_LOGITS[cfg]
     d_oracle = float(np.abs(sigmoid(logits) - sigmoid(want)).max())
     d_exact = float(np.abs(post - exact_post).max())
@@ -762,7 +761,7 @@ def test_sites_with_many_alleles(cfg):
     batch = synth.SiteBatch(reads0, rpa0, aps, pool.ref_onehot[:aps.shape[0]].copy(), reads1, rpa1)
     eng = Engine(spec, state, device=0)
     logits, meta, post = eng.forward_batch(batch, posteriors=True)
-    want, want_meta = mo.forward_batch(mo.Oracle(spec, state, backend="torch"), batch, chunk_sites=1)
+    want, want_meta = oracle_per_site(spec, state, batch)
     np.testing.assert_allclose(logits, want, **LOGIT_TOL)
     if want_meta is not None:
         assert np.abs(meta - want_meta).max() < PROB_ATOL

@@ -109,3 +109,27 @@ def canonical_pickle(name, tmp_dir):
     with gzip.open(os.path.join(GOLDEN, f"canonical_{name}.wrapper.dnn.gz"), "rb") as src, open(out, "wb") as dst:
         dst.write(src.read())
     return out
+
+
+def oracle_per_site(spec, state, batch, backend="torch", workers=8):
+    """``mo.forward_batch(Oracle(spec, state, backend), batch, chunk_sites=1)`` -- the oracle one site per call, the reference's per-site
+    form -- with the sites spread over ``workers`` threads (the convolution back ends release the interpreter lock; every thread
+    its own Oracle; one BLAS / torch thread each, so that a box with few or slow cores is not oversubscribed).  Same numbers: a
+    site's result does not depend on the others'.  -> (logits [E, A], meta [S, 3] | None)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from oracle import moe_oracle as mo
+    n = batch.n_sites
+    workers = max(1, min(workers, n, len(os.sched_getaffinity(0))))
+    edges = np.linspace(0, n, workers + 1).astype(int)
+    spans = [(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+    before = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        with ThreadPoolExecutor(len(spans)) as pool:
+            parts = list(pool.map(lambda ab: mo.forward_batch(mo.Oracle(spec, state, backend=backend), batch.site_slice(*ab), chunk_sites=1), spans))
+    finally:
+        torch.set_num_threads(before)
+    logits = np.concatenate([p[0] for p in parts], axis=1)
+    meta = None if parts[0][1] is None else np.concatenate([p[1] for p in parts], axis=0)
+    return logits, meta
