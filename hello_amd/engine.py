@@ -24,7 +24,9 @@ _LIB_PATH = os.environ.get("HELLO_LIB") or os.path.join(os.path.dirname(os.path.
                                                         "libhello_mi355x.so")
 HELLO_IN_DEVICE, HELLO_OUT_DEVICE, HELLO_LAYOUT_RCL = 1, 2, 4
 ABI_VERSION = 2          # HELLO_ABI_VERSION of include/hello_mi355x.h
-LANES_MAX_SITES = 64     # launches of at most this many sites run the laned program of a multi-chain model (Engine.forward)
+LANES_MAX_SITES = 4096   # launches of at most this many sites run the laned program of a multi-chain model (Engine.forward): measured
+                         # against the sequential program, hybrid_full: 1 site -34 %, 256 sites -22 %, 2 048 -7 %, 8 192 -1.5 % (C4: -21 / -11 / -3 / -1 %);
+                         # the largest launches keep the sequential program (it reuses buffers; per-op profiling times it)
 
 
 class HelloOp(C.Structure):
@@ -343,7 +345,7 @@ class Engine:
             lp = logits.ctypes.data
             mp = meta.ctypes.data if meta is not None else None
             pp = post.ctypes.data if posteriors else None
-        # a launch of a few sites of a multi-chain model runs the laned program (the chains concurrently; the same bits)
+        # a launch of a multi-chain model runs the laned program up to LANES_MAX_SITES sites (the chains concurrently; the same bits)
         native = self.small_launch_handle() if S <= LANES_MAX_SITES else self.handle
         self._last_native = native
 
