@@ -677,28 +677,44 @@ _SMALL_LAUNCH_US = {OP_READCONV_FUSED: 75.0, OP_COMPRESSOR_FUSED: 55.0, OP_XATTN
 
 
 def schedule_lanes(ops: List[Op]) -> List[Op]:
-    """Submission order of a laned program (virtual buffer ids): by estimated START time -- an op starts when its producers and
-    its lane's previous op have finished.  The host submits ~40 launches of a three-expert model one after the other (~4 us each):
-    in program order the last chain's first kernel would be submitted after every other chain's last one, long after its inputs
-    were ready.  Any order that keeps producers before consumers and a lane's ops in their order is correct (streams are in
-    order; the engine puts events between lanes)."""
+    """Submission order of a laned program (virtual buffer ids).  The host submits the ~40 launches of a three-expert model one after
+    the other (~5 us each: 220 us, about as long as the longest chain runs): what it submits first should be what the result waits
+    for longest.  List scheduling by bottom level: among the ops whose producers and whose lane's previous op have been submitted,
+    take the one with the longest remaining path to the end (its own estimated time + the longest chain of consumers / lane
+    successors behind it).  Every such order is correct: producers precede consumers (a stream may only wait for an event that has
+    been recorded) and a lane's ops keep their order (streams are first in, first out)."""
     shift = FLAG_LANE_SHIFT
-    finish: Dict[int, float] = {}             # virtual id -> time its producer finishes
-    lane_free: Dict[int, float] = {}
-    start = []
+    n = len(ops)
+    producer: Dict[int, int] = {}
+    preds: List[set] = [set() for _ in range(n)]
+    last_on_lane: Dict[int, int] = {}
     for i, o in enumerate(ops):
         front = o.kind == OP_XATTN_FRONT
-        ready = max([finish.get(v, 0.0) for v in (o.src0, o.src1, BUF_NONE if front else o.res) if v >= 1000] + [0.0])
+        for v in (o.src0, o.src1, BUF_NONE if front else o.res):
+            if v >= 1000 and v in producer:
+                preds[i].add(producer[v])
         lane = (o.flags >> shift) & 7
-        t0 = max(ready, lane_free.get(lane, 0.0))
-        t1 = t0 + _SMALL_LAUNCH_US.get(o.kind, 6.0)
-        lane_free[lane] = t1
+        if lane in last_on_lane:
+            preds[i].add(last_on_lane[lane])
+        last_on_lane[lane] = i
         if o.kind != OP_HEAD:
-            finish[o.dst] = t1
+            producer[o.dst] = i
         if front:
-            finish[o.res] = t1
-        start.append((t0, i))
-    return [ops[i] for _, i in sorted(start)]
+            producer[o.res] = i
+    succs: List[List[int]] = [[] for _ in range(n)]
+    for i in range(n):
+        for j in preds[i]:
+            succs[j].append(i)
+    bottom = [0.0] * n
+    for i in reversed(range(n)):                       # program order is topological
+        bottom[i] = _SMALL_LAUNCH_US.get(ops[i].kind, 6.0) + max([bottom[j] for j in succs[i]] + [0.0])
+    done, order = set(), []
+    while len(order) < n:
+        ready = [i for i in range(n) if i not in done and preds[i] <= done]
+        pick = max(ready, key=lambda i: (bottom[i], -i))
+        done.add(pick)
+        order.append(pick)
+    return [ops[i] for i in order]
 
 
 def _allocate(ops: List[Op], values: Dict[int, Value], reuse: bool = True):
