@@ -24,10 +24,12 @@ _LIB_PATH = os.environ.get("HELLO_LIB") or os.path.join(os.path.dirname(os.path.
                                                         "libhello_mi355x.so")
 HELLO_IN_DEVICE, HELLO_OUT_DEVICE, HELLO_LAYOUT_RCL = 1, 2, 4
 ABI_VERSION = 2          # HELLO_ABI_VERSION of include/hello_mi355x.h
-LANES_MAX_SITES = 4096   # launches of at most this many sites run the laned program of a multi-chain model (Engine.forward): measured
-                         # against the sequential program, hybrid_full: 1 site -34 %, 256 sites -22 %, 2 048 -7 %, 8 192 -1.5 % (C4: -21 / -11 / -3 / -1 %);
-                         # the largest launches keep the sequential program (it reuses buffers; per-op profiling times it)
-
+LANES_MAX_SITES = 64     # launches of at most this many sites run the laned program of a multi-chain model (Engine.forward).  ONE engine
+                         # alone on a card gains from lanes at every size (hybrid_full: 1 site -34 %, 256 sites -22 %, 2 048 -7 %, 8 192
+                         # -1.5 %; C4: -21 / -11 / -3 / -1 %), but several engines sharing a card (HostPipeline(engines=[...]), the
+                         # 256-site small-batch form) LOSE beyond the latency regime -- their lanes' streams oversubscribe the hardware
+                         # queues (four engines at 256 sites: C4 277 k -> 204 k sites/s).  Hence the default; Engine(lanes_max_sites=...)
+                         # raises it for an engine that has the card to itself.
 
 class HelloOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("domain", C.c_int32), ("src0", C.c_int32), ("src1", C.c_int32),
@@ -139,7 +141,7 @@ class Engine:
     """One compiled model resident on one GPU (one instance per process and device)."""
 
     def __init__(self, spec: ns.ModelSpec, state, device: int = 0, fused: bool = True, winograd: bool = True,
-                 program: Optional["compiler.Program"] = None, arithmetic: Optional[str] = None):
+                 program: Optional["compiler.Program"] = None, arithmetic: Optional[str] = None, lanes_max_sites: Optional[int] = None):
         """``program``: an already compiled (or deliberately edited) program to load instead of compiling.
         ``arithmetic``: "fp32" (exact fp32 everywhere, the default), "bf16x3" -- the read convolver's seven 64 -> 64 trunk
         convolutions on the bf16 matrix cores as 3-term splits (x w ~= xh wh + xh wl + xl wh; ~2^-17 per product, the
@@ -150,6 +152,7 @@ class Engine:
         itself in a split mode through a fixture of tests/conftest.py, not through this constructor)."""
         self.lib = load_library()
         self.spec = spec
+        self.lanes_max_sites = lanes_max_sites      # None: the module's LANES_MAX_SITES at call time
         # the laned program for small launches is compiled from the same options on first use (None: this engine was handed a
         # finished program, or the model is a single chain)
         self._lanes_recipe = None if program is not None else dict(state=state, fused=fused, winograd=winograd, arithmetic=arithmetic or "fp32")
@@ -345,8 +348,8 @@ class Engine:
             lp = logits.ctypes.data
             mp = meta.ctypes.data if meta is not None else None
             pp = post.ctypes.data if posteriors else None
-        # a launch of a multi-chain model runs the laned program up to LANES_MAX_SITES sites (the chains concurrently; the same bits)
-        native = self.small_launch_handle() if S <= LANES_MAX_SITES else self.handle
+        # a small launch of a multi-chain model runs the laned program (the chains concurrently; the same bits)
+        native = self.small_launch_handle() if S <= (LANES_MAX_SITES if self.lanes_max_sites is None else self.lanes_max_sites) else self.handle
         self._last_native = native
 
         def launch(handle):

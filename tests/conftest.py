@@ -33,13 +33,13 @@ def suite_arithmetic():
     from hello_amd import compiler, engine
     plain = engine.Engine.__init__
 
-    def init(self, spec, state, device=0, fused=True, winograd=True, program=None, arithmetic=None):
+    def init(self, spec, state, device=0, fused=True, winograd=True, program=None, arithmetic=None, lanes_max_sites=None):
         if program is None and arithmetic is None:
             try:
                 program = compiler.compile_model(spec, state, fused=fused, winograd=winograd, arithmetic=mode)
             except ValueError:
                 program = None          # the mode does not exist for this model / these options: exact fp32
-        plain(self, spec, state, device=device, fused=fused, winograd=winograd, program=program, arithmetic=arithmetic)
+        plain(self, spec, state, device=device, fused=fused, winograd=winograd, program=program, arithmetic=arithmetic, lanes_max_sites=lanes_max_sites)
     engine.Engine.__init__ = init
     try:
         yield mode
